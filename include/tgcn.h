@@ -1,0 +1,112 @@
+/*
+ * tgcn.h -- C ABI of the MI355X-native LightGCN propagation + scoring path.
+ *
+ * This is the drop-in boundary.  The reference (sergey-volokhin/TextGCN) has no FFI:
+ * its plug-in API is Python subclass/override, and every numeric step is a torch ATen call.  Each
+ * entry point below replaces the ATen call(s) named in its comment (file:line in /root/reference);
+ * the Python class textgcn_amd.LightGCN keeps the reference's BaseModel method surface on top of it
+ * (INTEGRATION.md shows the binding a TextGCN maintainer would add).
+ *
+ * Conventions
+ *   - plain pointers + sizes only; all pointers are DEVICE pointers unless the name says `_host`;
+ *   - every buffer is caller-owned; the library allocates nothing and keeps no state between calls;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the null stream) and the
+ *     call returns without synchronising;
+ *   - return value: TGCN_OK (0) or a negative error code; tgcn_last_error() gives the message of the
+ *     last failure on the calling thread;
+ *   - matrices are row-major fp32; index arrays are int32 unless stated (all reference configs have
+ *     N = |U|+|I| < 2^24 and nnz(A) < 2^31).
+ */
+#ifndef TGCN_H_
+#define TGCN_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TGCN_ABI_VERSION 1
+
+#define TGCN_OK 0
+#define TGCN_ERR_ARG (-1)         /* bad argument (null pointer, size, unsupported d/k ...) */
+#define TGCN_ERR_HIP (-2)         /* a HIP runtime call failed */
+#define TGCN_ERR_UNSUPPORTED (-3) /* valid request this build has no kernel for */
+
+typedef void *tgcn_stream_t; /* hipStream_t */
+
+int tgcn_abi_version(void);
+const char *tgcn_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Long-row split plan (optional).  A row whose stored-entry count exceeds `threshold` is cut into
+ * chunks [chunk_beg[c], chunk_end[c]) of at most `threshold` consecutive entries; chunk c belongs to
+ * long row number chunk_long[c]; long row l is matrix row long_rows[l] and owns chunks
+ * [long_chunk_ptr[l], long_chunk_ptr[l+1]).  Each chunk is summed sequentially by one wavefront into
+ * workspace[c, 0:d]; a second launch adds a row's chunk sums in chunk order (deterministic, no
+ * atomics).  Rows at or below the threshold are summed exactly as the reference's CPU kernel does.
+ * Built on the host by textgcn_amd.graph.SplitPlan from rowptr.
+ */
+typedef struct tgcn_split_plan {
+    int32_t threshold;
+    int32_t n_chunks;
+    int32_t n_long;
+    int32_t _pad;
+    const int32_t *chunk_beg;      /* [n_chunks] offsets into colidx/vals */
+    const int32_t *chunk_end;      /* [n_chunks] */
+    const int32_t *long_rows;      /* [n_long]   local row ids */
+    const int32_t *long_chunk_ptr; /* [n_long+1] */
+    float *workspace;              /* [n_chunks, d] fp32 scratch */
+} tgcn_split_plan_t;
+
+/* kernel selection for tgcn_spmm_csr_f32 (`flags & 0xff`); results are bit-identical across variants */
+#define TGCN_SPMM_AUTO 0
+#define TGCN_SPMM_WAVE_PER_ROW 1  /* one wave64 per row, lane = d/64 consecutive columns */
+#define TGCN_SPMM_GROUP_PER_ROW 2 /* d/4 lanes per row (float4 each), 256/d rows per wave; d in {32,64,128,256} */
+
+/* K1 + K3: one LightGCN layer  Y = A . X  with the layer combination fused in.
+ *   replaces torch.sparse.mm(norm_matrix, emb_matrix)              TextGCN/base_model.py:148
+ *   and the running part of torch.mean(torch.stack(vectors), 0)    TextGCN/base_model.py:157
+ * A is CSR over `n_rows` local rows (rowptr[0..n_rows], absolute offsets into colidx/vals; column
+ * ids index rows of X; entries of a row in ascending column order = the reference's coalesced COO
+ * order, TextGCN/dataset.py:138).  X is [n_src_rows, d].
+ *   y[r,:]        = sum over the row's entries, in order, of fmaf(val, X[col,:], y)   (exact fp32 chain)
+ *   Y[r,:]        = y                                   if Y       != NULL
+ *   acc_out[r,:]  = (acc_in[r,:] + y) / acc_div         if acc_out != NULL  (acc_div == 1: no division)
+ * acc_in may alias acc_out.  Layer k of K:  acc_in = E0 rows (k = 1) or the running sum, acc_div =
+ * K+1 on the last layer -- exactly the reference's sequential sum then one division.
+ * `plan` may be NULL (every row summed by one wave: bit-identical to the reference's CPU result). */
+int tgcn_spmm_csr_f32(const int32_t *rowptr, const int32_t *colidx, const float *vals, int64_t n_rows,
+                      const float *X, int64_t n_src_rows, int32_t d, float *Y, const float *acc_in,
+                      float *acc_out, float acc_div, const tgcn_split_plan_t *plan, uint32_t flags,
+                      tgcn_stream_t stream);
+
+/* K5: S[b, i] = <U[user_ids[b], :], It[i, :]>  (user_ids == NULL: U rows 0..B-1), S row stride lds.
+ *   replaces torch.matmul(users_emb, items_emb.t())                TextGCN/base_model.py:179
+ *   (+ the users_emb[batch_users] gather at base_model.py:254)
+ * fp32 MFMA (v_mfma_f32_32x32x2_f32): each dot product is the k-ordered fmaf chain from +0. */
+int tgcn_score_dense_f32(const float *U, const int64_t *user_ids, int32_t B, const float *It, int32_t I,
+                         int32_t d, float *S, int64_t lds, tgcn_stream_t stream);
+
+/* K6: S[b, mask_items[e]] = -inf for e in [mask_rowptr[b], mask_rowptr[b+1]).
+ *   replaces the pandas explode + advanced-index assignment        TextGCN/base_model.py:257-258 */
+int tgcn_mask_f32(float *S, int64_t lds, int32_t B, int32_t I, const int32_t *mask_rowptr,
+                  const int32_t *mask_items, tgcn_stream_t stream);
+
+/* K7 (+K8): per-row top-k of S[B, I], ordered by (value descending, index ascending).
+ *   replaces torch.topk(rating, k=max(self.k))                      TextGCN/base_model.py:261
+ *   round4 != 0 also applies probs.round(decimals=4)                TextGCN/base_model.py:263
+ *   (ATen: nearbyintf(x * 1e4f) / 1e4f).  1 <= k <= 64, k <= I. */
+int tgcn_topk_f32(const float *S, int64_t lds, int32_t B, int32_t I, int32_t k, int32_t round4,
+                  float *out_val, int64_t *out_idx, tgcn_stream_t stream);
+
+/* K9: out[r] = <U[users[r], :], V[items[r], :]>   (users/items may be NULL: row r itself).
+ *   replaces torch.sum(users_emb * items_emb, dim=1)               TextGCN/base_model.py:171
+ *   and the gathers at base_model.py:189-193 */
+int tgcn_score_pairwise_f32(const float *U, const int64_t *users, const float *V, const int64_t *items,
+                            int64_t n, int32_t d, float *out, tgcn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TGCN_H_ */

@@ -1,0 +1,156 @@
+"""Parity of the HIP scoring kernels (fp32 MFMA dense scores, mask, top-k, pairwise) against the oracle and
+the reference's golden vectors."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import bits, normwise
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('b,i,d', [(5, 4, 64), (60, 40, 48), (130, 257, 64), (257, 1000, 128), (33, 129, 100),
+                                   (128, 128, 256), (1, 70, 6)])
+def test_dense_scores_bit_exact_vs_oracle(cuda, oracle, b, i, d):
+    from textgcn_amd import scoring
+    rng = np.random.default_rng(b * 1000 + i + d)
+    u = rng.standard_normal((b, d)).astype(np.float32)
+    it = rng.standard_normal((i, d)).astype(np.float32)
+    ref = oracle.score_dense(u, it)
+    s = scoring.score_dense(torch.from_numpy(u).to(cuda), torch.from_numpy(it).to(cuda))
+    assert np.array_equal(bits(s.cpu().numpy()), bits(ref))
+
+
+def test_dense_scores_layout_asymmetric(cuda):
+    """A = I against an asymmetric B catches a transposed C write."""
+    from textgcn_amd import scoring
+    d = 64
+    u = torch.eye(d, device=cuda)
+    it = torch.arange(200 * d, device=cuda, dtype=torch.float32).reshape(200, d) / 7.0
+    s = scoring.score_dense(u, it)
+    assert torch.equal(s, it.t().contiguous())
+
+
+def test_dense_scores_user_gather(cuda, oracle):
+    from textgcn_amd import scoring
+    rng = np.random.default_rng(5)
+    table = rng.standard_normal((500, 64)).astype(np.float32)
+    it = rng.standard_normal((300, 64)).astype(np.float32)
+    ids = rng.permutation(500)[:200].astype(np.int64)
+    ref = oracle.score_dense(table[ids], it)
+    s = scoring.score_dense(torch.from_numpy(table).to(cuda), torch.from_numpy(it).to(cuda),
+                            user_ids=torch.from_numpy(ids).to(cuda))
+    assert np.array_equal(bits(s.cpu().numpy()), bits(ref))
+
+
+@pytest.mark.parametrize('name', ['a', 'k4d128', 'd48'])
+def test_scores_mask_topk_vs_reference(golden, cuda, name):
+    """G2: rating, masked rating and top-10 (+ round) equal the reference's own outputs."""
+    from textgcn_amd import scoring
+    from textgcn_amd.graph import train_mask_csr
+    g = golden('g2_synth60')
+    n_u = int(g['n_users'])
+    ue = torch.from_numpy(g[f'{name}_users_emb']).to(cuda)
+    ie = torch.from_numpy(g[f'{name}_items_emb']).to(cuda)
+    s = scoring.score_dense(ue, ie)
+    assert normwise(s.cpu().numpy(), g[f'{name}_rating']) <= 1e-6
+    rp, items = train_mask_csr(g['train_u'], g['train_i'], n_u)
+    scoring.mask_train(s, torch.from_numpy(rp.astype(np.int32)).to(cuda), torch.from_numpy(items).to(cuda))
+    sm = s.cpu().numpy()
+    assert np.array_equal(np.isneginf(sm), np.isneginf(g[f'{name}_masked']))
+    v, i = scoring.topk(s, 10, round4=True)
+    assert np.array_equal(i.cpu().numpy(), g[f'{name}_topk_idx'])
+    assert np.array_equal(bits(v.cpu().numpy()), bits(g[f'{name}_topk_val']))
+
+
+def test_dummy_predictions_vs_reference(golden, cuda):
+    """G1 (data/dummy, k=3 of 4 items): finite prefix identical, -inf tail made of masked train items."""
+    from textgcn_amd import scoring
+    from textgcn_amd.graph import train_mask_csr
+    g = golden('g1_dummy')
+    s = scoring.score_dense(torch.from_numpy(g['users_emb']).to(cuda), torch.from_numpy(g['items_emb']).to(cuda))
+    assert np.array_equal(bits(s.cpu().numpy()), bits(g['rating']))
+    rp, items = train_mask_csr(g['train_u'], g['train_i'], 5)
+    scoring.mask_train(s, torch.from_numpy(rp.astype(np.int32)).to(cuda), torch.from_numpy(items).to(cuda))
+    assert np.array_equal(bits(s.cpu().numpy()), bits(g['masked']))
+    v, i = scoring.topk(s, 3, round4=True)
+    v, i = v.cpu().numpy(), i.cpu().numpy()
+    for b in range(5):
+        fin = np.isfinite(g['topk_val'][b])
+        assert np.array_equal(i[b][fin], g['topk_idx'][b][fin])
+        assert np.array_equal(bits(v[b][fin]), bits(g['topk_val'][b][fin]))
+        masked = set(np.nonzero(np.isneginf(g['masked'][b]))[0])
+        assert set(i[b][~fin]) <= masked and np.all(np.isneginf(v[b][~fin]))
+
+
+@pytest.mark.parametrize('b,i,k', [(7, 64, 64), (3, 65, 1), (40, 1000, 40), (5, 50000, 40), (2, 5, 5), (9, 300, 20)])
+def test_topk_vs_oracle_with_ties_and_inf(cuda, oracle, b, i, k):
+    from textgcn_amd import scoring
+    rng = np.random.default_rng(b + i + k)
+    # few distinct values -> many ties; sprinkle -inf
+    s = rng.integers(0, 50, size=(b, i)).astype(np.float32) / 8.0
+    s[rng.random((b, i)) < 0.1] = -np.inf
+    if b > 1:
+        s[1, :] = -np.inf          # a fully masked row
+    rv, ri = oracle.topk(s, k, round4=False)
+    v, idx = scoring.topk(torch.from_numpy(s).to(cuda), k)
+    assert np.array_equal(idx.cpu().numpy(), ri)
+    assert np.array_equal(bits(v.cpu().numpy()), bits(rv))
+
+
+def test_topk_strided_rows_and_round(cuda, oracle):
+    from textgcn_amd import scoring
+    rng = np.random.default_rng(0)
+    big = rng.standard_normal((6, 1003)).astype(np.float32)
+    t = torch.from_numpy(big).to(cuda)[:, :999]            # row stride 1003, unaligned rows
+    rv, ri = oracle.topk(big[:, :999], 40, round4=True)
+    v, idx = scoring.topk(t, 40, round4=True)
+    assert np.array_equal(idx.cpu().numpy(), ri) and np.array_equal(bits(v.cpu().numpy()), bits(rv))
+
+
+def test_topk_rejects_bad_k(cuda):
+    from textgcn_amd import scoring
+    s = torch.zeros((2, 10), device=cuda)
+    with pytest.raises(RuntimeError):
+        scoring.topk(s, 0)
+    with pytest.raises(RuntimeError):
+        scoring.topk(s, 11)
+    with pytest.raises(RuntimeError):
+        scoring.topk(torch.zeros((2, 100), device=cuda), 65)
+
+
+def test_pairwise_bit_exact_vs_oracle(cuda, oracle):
+    from textgcn_amd import scoring
+    rng = np.random.default_rng(2)
+    ut = rng.standard_normal((100, 64)).astype(np.float32)
+    vt = rng.standard_normal((80, 64)).astype(np.float32)
+    users = rng.integers(0, 100, 500).astype(np.int64)
+    items = rng.integers(0, 80, 500).astype(np.int64)
+    ref = oracle.score_pairwise(ut[users], vt[items])
+    out = scoring.score_pairwise(torch.from_numpy(ut).to(cuda), torch.from_numpy(vt).to(cuda),
+                                 torch.from_numpy(users).to(cuda), torch.from_numpy(items).to(cuda))
+    assert np.array_equal(bits(out.cpu().numpy()), bits(ref))
+
+
+def test_full_size_c2_batch_properties(cuda, oracle):
+    """One B=2048 batch against I=50k items (config 2 shape): sampled entries vs the oracle; top-40 of the
+    masked scores equals a torch sort of the same device matrix wherever values are distinct."""
+    from textgcn_amd import scoring
+    rng = np.random.default_rng(9)
+    b, i, d, k = 2048, 50000, 64, 40
+    u = (rng.standard_normal((b, d)) * 0.1).astype(np.float32)
+    it = (rng.standard_normal((i, d)) * 0.1).astype(np.float32)
+    ud, itd = torch.from_numpy(u).to(cuda), torch.from_numpy(it).to(cuda)
+    s = scoring.score_dense(ud, itd)
+    rows = rng.integers(0, b, 64)
+    cols = rng.integers(0, i, 64)
+    ref = oracle.score_pairwise(u[rows], it[cols])
+    assert np.array_equal(bits(s[torch.from_numpy(rows).to(cuda), torch.from_numpy(cols).to(cuda)].cpu().numpy()), bits(ref))
+    # mask: 50 random items per user
+    mi = np.sort(rng.integers(0, i, size=(b, 50)), axis=1).astype(np.int32)
+    rp = (np.arange(b + 1) * 50).astype(np.int32)
+    scoring.mask_train(s, torch.from_numpy(rp).to(cuda), torch.from_numpy(mi.ravel()).to(cuda))
+    assert torch.isneginf(s[0, int(mi[0, 0])]) and int(torch.isneginf(s).sum()) == len(np.unique(np.arange(b)[:, None] * i + mi))
+    v, idx = scoring.topk(s, k)
+    tv, ti = torch.sort(s, dim=1, descending=True, stable=True)   # stable: ties keep ascending index
+    assert torch.equal(v, tv[:, :k]) and torch.equal(idx, ti[:, :k])

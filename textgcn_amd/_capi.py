@@ -1,0 +1,71 @@
+"""ctypes binding of libtgcn.so (include/tgcn.h).  There is NO fallback: if the HIP library is missing
+or a call fails, a RuntimeError is raised -- the product path never routes through torch ops or the
+CPU oracle instead."""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_uint32, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, '_lib', 'libtgcn.so')
+
+TGCN_ABI_VERSION = 1
+SPMM_AUTO, SPMM_WAVE_PER_ROW, SPMM_GROUP_PER_ROW = 0, 1, 2
+
+
+class SplitPlanStruct(Structure):
+    """mirror of tgcn_split_plan_t"""
+    _fields_ = [('threshold', c_int32), ('n_chunks', c_int32), ('n_long', c_int32), ('_pad', c_int32),
+                ('chunk_beg', c_void_p), ('chunk_end', c_void_p), ('long_rows', c_void_p),
+                ('long_chunk_ptr', c_void_p), ('workspace', c_void_p)]
+
+
+_SIGNATURES = {
+    'tgcn_abi_version': (ctypes.c_int, []),
+    'tgcn_last_error': (c_char_p, []),
+    'tgcn_spmm_csr_f32': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p,
+                                         c_void_p, c_void_p, c_float, POINTER(SplitPlanStruct), c_uint32, c_void_p]),
+    'tgcn_score_dense_f32': (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_int64,
+                                            c_void_p]),
+    'tgcn_mask_f32': (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    'tgcn_topk_f32': (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    'tgcn_score_pairwise_f32': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p,
+                                               c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def lib():
+    """Load libtgcn.so once; loud failure if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f'{LIB_PATH} is missing: build it with `python -m textgcn_amd.build` (hipcc, gfx950). '
+                'textgcn_amd has no CPU / torch fallback for its kernels.')
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        if handle.tgcn_abi_version() != TGCN_ABI_VERSION:
+            raise RuntimeError(f'libtgcn.so ABI {handle.tgcn_abi_version()} != binding {TGCN_ABI_VERSION}; rebuild')
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().tgcn_last_error().decode(errors='replace')
+        raise RuntimeError(f'{what} failed (code {rc}): {msg}')
+
+
+def ptr(t):
+    """device pointer of a torch tensor (None -> NULL)"""
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def current_stream(device):
+    import torch
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)

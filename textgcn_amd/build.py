@@ -1,0 +1,56 @@
+"""Build recipe of libtgcn.so (HIP kernels + C ABI), in-tree, gfx950 only.
+
+    python -m textgcn_amd.build [--force] [--verbose]
+
+hipcc cross-compiles without a GPU, so the build container produces the .so that travels to the GPU box
+(`*.so` is git-ignored, not gpurun-ignored).
+"""
+import os
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+CSRC = os.path.join(_HERE, 'csrc')
+LIB_DIR = os.path.join(_HERE, '_lib')
+LIB = os.path.join(LIB_DIR, 'libtgcn.so')
+SOURCES = ['tgcn_core.hip', 'tgcn_spmm.hip', 'tgcn_score.hip']
+HEADERS = [os.path.join(ROOT, 'include', 'tgcn.h'), os.path.join(CSRC, 'tgcn_internal.h')]
+ARCH = 'gfx950'
+
+
+def hipcc():
+    for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError('hipcc not found')
+
+
+def flags():
+    return [f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-shared',
+            '-ffp-contract=off',  # fused multiply-adds are written explicitly (fmaf / MFMA); nothing else may fuse
+            '-fno-fast-math', f'-I{os.path.join(ROOT, "include")}', f'-I{CSRC}']
+
+
+def stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_lib(force=False, verbose=False):
+    if not force and not stale():
+        return LIB
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cmd = [hipcc()] + flags() + [os.path.join(CSRC, s) for s in SOURCES] + ['-o', LIB]
+    if verbose:
+        cmd.append('-Rpass-analysis=kernel-resource-usage')
+        print(' '.join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build_lib(force='--force' in sys.argv, verbose='--verbose' in sys.argv))

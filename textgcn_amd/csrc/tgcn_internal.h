@@ -1,0 +1,49 @@
+// Internal helpers shared by the translation units of libtgcn.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "tgcn.h"
+
+namespace tgcn {
+
+void set_error(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+
+inline int fail_arg(const char *what)
+{
+    set_error("invalid argument: %s", what);
+    return TGCN_ERR_ARG;
+}
+
+// checks the launch that was just enqueued (does not synchronise)
+inline int check_launch(const char *kernel)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", kernel, hipGetErrorString(e));
+        return TGCN_ERR_HIP;
+    }
+    return TGCN_OK;
+}
+
+#define TGCN_REQUIRE(cond, what) \
+    do {                         \
+        if (!(cond))             \
+            return ::tgcn::fail_arg(what); \
+    } while (0)
+
+constexpr int kWave = 64;
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
+
+// wave-uniform value -> SGPR (lets the compiler use scalar loads / scalar address math)
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ float readlane_f(float v, int lane)
+{
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+}  // namespace tgcn

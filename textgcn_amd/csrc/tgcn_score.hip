@@ -1,0 +1,320 @@
+// K5..K9: scoring.  Dense user x item scores on the fp32 matrix cores, train-item mask, per-row top-k,
+// pairwise dots.  gfx950 only.
+//
+// Replaces torch.matmul (TextGCN/base_model.py:179), the pandas explode + -inf scatter
+// (base_model.py:257-258), torch.topk (base_model.py:261), .round(decimals=4) (base_model.py:263) and
+// torch.sum(u*i, dim=1) (base_model.py:171).
+//
+// Numerics contract: every score is the k-ordered fp32 fmaf chain from +0 over the embedding dimension
+// (v_mfma_f32_32x32x2_f32 accumulates exactly that chain), which the parity tests check bit for bit.
+// top-k order is (value descending, index ascending).
+#include <climits>
+
+#include "tgcn_internal.h"
+
+namespace tgcn {
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+// ------------------------------------------------------------------------------------------------
+// dense scores: S[B, I] = U[user_ids] . It^T
+//
+// Workgroup = 4 waves, output tile 128 users x 128 items, K walked in chunks of 64 through LDS.
+// Wave w owns users [32w, 32w+32) x all 128 items of the tile: 4 accumulators of 32x32.
+// MFMA operand layout (32x32x2 f32): lane l supplies A[row = l&31][k = l>>5] and B[k = l>>5][col = l&31],
+// i.e. the two half-waves h = l>>5 hold k = 2t and k = 2t+1 of step t.  To feed that without a per-lane
+// select, each group of four k is stored in LDS as (k0, k2, k1, k3): half h reads the float2 at 4q + 2h
+// and uses .x for step 2q (k = 4q + h) and .y for step 2q+1 (k = 4q + 2 + h) -- ascending k, so every
+// dot product is the k-ordered fmaf chain.  Row stride 66 floats: the ds_read_b64 of a half-wave
+// (rows 0..31, fixed q) covers banks (2*row + 4q + 2h) mod 64 -- all 64 banks once, conflict-free.
+constexpr int kTile = 128;
+constexpr int kKC = 64;
+constexpr int kLdsRow = kKC + 2;
+
+struct DenseArgs {
+    const float *__restrict__ U;
+    const int64_t *__restrict__ user_ids;
+    const float *__restrict__ It;
+    float *__restrict__ S;
+    int64_t lds;
+    int B, I, d;
+};
+
+// stage rows [row0, row0+128) x k [k0, k0+64) of a row-major [n_rows, d] table (optionally gathered
+// through ids) into LDS, zero-filled outside the table
+__device__ __forceinline__ void stage_tile(float *__restrict__ dst, const float *__restrict__ src,
+                                           const int64_t *__restrict__ ids, int row0, int n_rows, int k0, int d)
+{
+    const int t = threadIdx.x;
+    const bool vec = (d & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < (kTile * kKC / 4) / 256; ++i) {
+        const int f = i * 256 + t;
+        const int r = f >> 4;  // 16 float4 per row chunk
+        const int q = f & 15;
+        const int row = row0 + r;
+        const int k = k0 + q * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < n_rows && k < d) {
+            const int64_t srow = ids ? ids[row] : (int64_t)row;
+            const float *p = src + (size_t)srow * d + k;
+            if (vec) {
+                v = *reinterpret_cast<const float4 *>(p);
+            } else {
+                v.x = p[0];
+                if (k + 1 < d) v.y = p[1];
+                if (k + 2 < d) v.z = p[2];
+                if (k + 3 < d) v.w = p[3];
+            }
+        }
+        float *o = dst + r * kLdsRow + q * 4;
+        *reinterpret_cast<float2 *>(o) = make_float2(v.x, v.z);
+        *reinterpret_cast<float2 *>(o + 2) = make_float2(v.y, v.w);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_score_dense(const DenseArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float smem[2 * kTile * kLdsRow];
+    float *ldsU = smem;
+    float *ldsI = smem + kTile * kLdsRow;
+    const int lane = lane_id();
+    const int w = threadIdx.x >> 6;
+    const int r32 = lane & 31;
+    const int h = lane >> 5;
+    const int i0 = blockIdx.x * kTile;
+    const int u0 = blockIdx.y * kTile;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            acc[n][r] = 0.0f;
+
+    for (int k0 = 0; k0 < a.d; k0 += kKC) {
+        if (k0)
+            __syncthreads();
+        stage_tile(ldsU, a.U, a.user_ids, u0, a.B, k0, a.d);
+        stage_tile(ldsI, a.It, nullptr, i0, a.I, k0, a.d);
+        __syncthreads();
+        const float *pu = ldsU + (w * 32 + r32) * kLdsRow + 2 * h;
+        const float *pi = ldsI + r32 * kLdsRow + 2 * h;
+#pragma unroll 4
+        for (int q = 0; q < kKC / 4; ++q) {
+            const float2 a2 = *reinterpret_cast<const float2 *>(pu + q * 4);
+            float2 b2[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                b2[n] = *reinterpret_cast<const float2 *>(pi + n * 32 * kLdsRow + q * 4);
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.x, b2[n].x, acc[n], 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.y, b2[n].y, acc[n], 0, 0, 0);
+        }
+    }
+
+    // C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int item = i0 + n * 32 + r32;
+        const bool item_ok = item < a.I;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int user = u0 + w * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (item_ok && user < a.B)
+                a.S[(size_t)user * a.lds + item] = acc[n][r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// train-item mask: one wave per user row
+__global__ __launch_bounds__(256) void k_mask(float *__restrict__ S, int64_t lds, int B, int I,
+                                              const int *__restrict__ mask_rowptr, const int *__restrict__ mask_items)
+{
+    const int b = uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (b >= B)
+        return;
+    const int beg = mask_rowptr[b], end = mask_rowptr[b + 1];
+    for (int e = beg + lane_id(); e < end; e += kWave) {
+        const int it = mask_items[e];
+        if (it >= 0 && it < I)
+            S[(size_t)b * lds + it] = -INFINITY;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-row top-k.  The running list lives in registers, lane j = j-th best (value desc, index asc).
+struct TopList {
+    float v;
+    int i;
+};
+
+__device__ __forceinline__ bool better(float av, int ai, float bv, int bi)
+{
+    return av > bv || (av == bv && ai < bi);
+}
+
+// insert (cv, ci) (wave-uniform) into the sorted 64-entry list; entries past the end fall off
+__device__ __forceinline__ void list_insert(TopList &e, float cv, int ci, int lane)
+{
+    const bool beats = better(e.v, e.i, cv, ci);
+    const int pos = __popcll(__ballot(beats));  // sorted list: `beats` is a prefix of lanes
+    const float uv = __shfl_up(e.v, 1);
+    const int ui = __shfl_up(e.i, 1);
+    if (lane == pos) {
+        e.v = cv;
+        e.i = ci;
+    } else if (lane > pos) {
+        e.v = uv;
+        e.i = ui;
+    }
+}
+
+// offer one value per lane (sv at index si, `on` = lane holds a real element); k-th entry is the bar
+__device__ __forceinline__ void list_offer(TopList &e, float sv, int si, bool on, int k, int lane)
+{
+    float tv = readlane_f(e.v, k - 1);
+    int ti = __builtin_amdgcn_readlane(e.i, k - 1);
+    unsigned long long m = __ballot(on && better(sv, si, tv, ti));
+    while (m) {
+        const int f = __ffsll((long long)m) - 1;
+        const float cv = readlane_f(sv, f);
+        const int ci = __builtin_amdgcn_readlane(si, f);
+        list_insert(e, cv, ci, lane);
+        tv = readlane_f(e.v, k - 1);
+        ti = __builtin_amdgcn_readlane(e.i, k - 1);
+        m &= ~(1ull << f);
+        m &= __ballot(on && better(sv, si, tv, ti));
+    }
+}
+
+// one workgroup (4 waves) per row: each wave scans a quarter of the row, wave 0 merges
+__global__ __launch_bounds__(256) void k_topk(const float *__restrict__ S, int64_t lds, int B, int I, int k, int round4,
+                                              float *__restrict__ out_val, int64_t *__restrict__ out_idx)
+{
+    __shared__ float sv[4][kWave];
+    __shared__ int si[4][kWave];
+    const int b = blockIdx.x;
+    const int lane = lane_id();
+    const int w = threadIdx.x >> 6;
+    const float *__restrict__ row = S + (size_t)b * lds;
+    TopList e{-INFINITY, INT_MAX};
+    // quarter boundaries on multiples of 4 so that aligned float4 reads stay inside one quarter
+    const int per = (((I + 3) / 4 + 3) / 4) * 4;
+    const int beg = min(I, w * per), end = min(I, beg + per);
+    const bool vec_ok = (lds & 3) == 0 && ((size_t)row & 15) == 0;
+    for (int base = beg; base < end; base += kWave * 4) {
+        const int i0 = base + lane * 4;
+        float x[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        if (vec_ok && i0 + 3 < end) {
+            const float4 t = *reinterpret_cast<const float4 *>(row + i0);
+            x[0] = t.x, x[1] = t.y, x[2] = t.z, x[3] = t.w;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + u < end)
+                    x[u] = row[i0 + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            list_offer(e, x[u], i0 + u, i0 + u < end, k, lane);
+    }
+    sv[w][lane] = e.v;
+    si[w][lane] = e.i;
+    __syncthreads();
+    if (w != 0)
+        return;
+    for (int o = 1; o < 4; ++o)
+        list_offer(e, sv[o][lane], si[o][lane], lane < k && si[o][lane] != INT_MAX, k, lane);
+    if (lane < k) {
+        float v = e.v;
+        if (round4)
+            v = nearbyintf(v * 10000.0f) / 10000.0f;  // ATen round(decimals=4)
+        out_val[(size_t)b * k + lane] = v;
+        out_idx[(size_t)b * k + lane] = e.i;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pairwise dots: one lane per pair, k-ordered chain (tiny workloads: a training batch)
+__global__ __launch_bounds__(256) void k_score_pairwise(const float *__restrict__ U, const int64_t *__restrict__ users,
+                                                        const float *__restrict__ V, const int64_t *__restrict__ items,
+                                                        int64_t n, int d, float *__restrict__ out)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n)
+        return;
+    const float *u = U + (size_t)(users ? users[r] : r) * d;
+    const float *v = V + (size_t)(items ? items[r] : r) * d;
+    float s = 0.0f;
+    for (int k = 0; k < d; ++k)
+        s = fmaf(u[k], v[k], s);
+    out[r] = s;
+}
+
+}  // namespace
+}  // namespace tgcn
+
+using namespace tgcn;
+
+extern "C" int tgcn_score_dense_f32(const float *U, const int64_t *user_ids, int32_t B, const float *It, int32_t I,
+                                    int32_t d, float *S, int64_t lds, tgcn_stream_t stream)
+{
+    TGCN_REQUIRE(B >= 0 && I >= 0, "negative size");
+    TGCN_REQUIRE(d > 0 && d <= 4096, "d out of range");
+    if (B == 0 || I == 0)
+        return TGCN_OK;
+    TGCN_REQUIRE(U && It && S, "NULL pointer");
+    TGCN_REQUIRE(lds >= I, "lds < I");
+    DenseArgs a{U, user_ids, It, S, lds, B, I, d};
+    const dim3 grid((I + kTile - 1) / kTile, (B + kTile - 1) / kTile);
+    TGCN_REQUIRE(grid.y <= 65535, "B too large for one launch (max 65535*128 rows)");
+    hipLaunchKernelGGL(k_score_dense, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return check_launch("k_score_dense");
+}
+
+extern "C" int tgcn_mask_f32(float *S, int64_t lds, int32_t B, int32_t I, const int32_t *mask_rowptr,
+                             const int32_t *mask_items, tgcn_stream_t stream)
+{
+    TGCN_REQUIRE(B >= 0 && I >= 0, "negative size");
+    if (B == 0 || I == 0)
+        return TGCN_OK;
+    TGCN_REQUIRE(S && mask_rowptr, "NULL pointer");
+    TGCN_REQUIRE(lds >= I, "lds < I");
+    hipLaunchKernelGGL(k_mask, dim3((B + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), S, lds, B, I,
+                       mask_rowptr, mask_items);
+    return check_launch("k_mask");
+}
+
+extern "C" int tgcn_topk_f32(const float *S, int64_t lds, int32_t B, int32_t I, int32_t k, int32_t round4,
+                             float *out_val, int64_t *out_idx, tgcn_stream_t stream)
+{
+    TGCN_REQUIRE(B >= 0, "negative B");
+    TGCN_REQUIRE(k >= 1 && k <= 64, "k must be in [1, 64]");
+    TGCN_REQUIRE(I >= k, "k exceeds the number of items");
+    if (B == 0)
+        return TGCN_OK;
+    TGCN_REQUIRE(S && out_val && out_idx, "NULL pointer");
+    TGCN_REQUIRE(lds >= I, "lds < I");
+    hipLaunchKernelGGL(k_topk, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), S, lds, B, I, k, round4,
+                       out_val, out_idx);
+    return check_launch("k_topk");
+}
+
+extern "C" int tgcn_score_pairwise_f32(const float *U, const int64_t *users, const float *V, const int64_t *items,
+                                       int64_t n, int32_t d, float *out, tgcn_stream_t stream)
+{
+    TGCN_REQUIRE(n >= 0, "negative n");
+    TGCN_REQUIRE(d > 0, "d must be positive");
+    if (n == 0)
+        return TGCN_OK;
+    TGCN_REQUIRE(U && V && out, "NULL pointer");
+    hipLaunchKernelGGL(k_score_pairwise, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), U, users, V, items, n, d, out);
+    return check_launch("k_score_pairwise");
+}

@@ -1,0 +1,411 @@
+// K1 + K3: CSR SpMM  Y = A.X  (fp32) with the LightGCN layer combination fused into the epilogue.
+//
+// Replaces torch.sparse.mm (TextGCN/base_model.py:148) and the running sum of
+// torch.mean(torch.stack(...)) (base_model.py:157).  gfx950 only.
+//
+// Numerics contract: every output element is the fp32 fmaf chain over the row's stored entries in
+// ascending column order, starting from +0 -- the order torch's CPU COO kernel uses --
+// so the result is bit-identical to the reference's CPU forward.  Rows longer than the split plan's
+// threshold are the one exception: their chunks are chained independently and the chunk sums are
+// added in chunk order by a second launch (deterministic; differs from the reference in rounding only).
+//
+// Roofline: HBM-bound gather.  Algorithmic bytes per layer:
+//   nnz*(4+4) + (rows+1)*4 + n_src*d*4 (X read once) + rows*d*4 (Y) [+ acc read/write]
+//
+// Kernels
+//   k_spmm_wave<VEC,UNROLL>   one wave64 per row; lane owns VEC consecutive columns (d = 64*VEC).
+//                             The row's (col, val) pairs are loaded 64 at a time, coalesced, and
+//                             broadcast with v_readlane into SGPRs: per entry one scalar address
+//                             computation, one 256*VEC-byte coalesced row load, VEC v_fma.
+//   k_spmm_group<G,UNROLL>    G = d/4 lanes per row, float4 per lane, 64/G rows per wave: short rows
+//                             (the common case: mean degree 10..100) keep all 64 lanes loading 16 B
+//                             each and 4x (d=64) more rows in flight per CU.  Broadcast inside a group
+//                             is ds_bpermute (__shfl with width G).
+//   k_spmm_generic            any d: wave per row, 64-column slabs.
+//   k_spmm_long_reduce<VEC>   adds the chunk sums of split rows and applies the epilogue.
+#include <climits>
+
+#include "tgcn_internal.h"
+
+namespace tgcn {
+namespace {
+
+struct SpmmArgs {
+    const int *__restrict__ rowptr;
+    const int *__restrict__ colidx;
+    const float *__restrict__ vals;
+    const float *__restrict__ X;
+    float *__restrict__ Y;
+    const float *acc_in;  // may alias acc_out
+    float *acc_out;
+    float acc_div;
+    int n_rows;
+    int d;
+    int row_waves;  // waves [0,row_waves) own rows, waves [row_waves, row_waves+n_chunks) own chunks
+    int threshold;  // rows with more entries than this are left to the chunk waves
+    int n_chunks;
+    const int *__restrict__ chunk_beg;
+    const int *__restrict__ chunk_end;
+    float *__restrict__ ws;
+};
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(const float *p, float (&x)[VEC])
+{
+    if constexpr (VEC == 1) {
+        x[0] = *p;
+    } else if constexpr (VEC == 2) {
+        const float2 t = *reinterpret_cast<const float2 *>(p);
+        x[0] = t.x, x[1] = t.y;
+    } else {
+        static_assert(VEC == 4, "VEC must be 1, 2 or 4");
+        const float4 t = *reinterpret_cast<const float4 *>(p);
+        x[0] = t.x, x[1] = t.y, x[2] = t.z, x[3] = t.w;
+    }
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_vec(float *p, const float (&x)[VEC])
+{
+    if constexpr (VEC == 1) {
+        *p = x[0];
+    } else if constexpr (VEC == 2) {
+        *reinterpret_cast<float2 *>(p) = make_float2(x[0], x[1]);
+    } else {
+        *reinterpret_cast<float4 *>(p) = make_float4(x[0], x[1], x[2], x[3]);
+    }
+}
+
+// Y / acc epilogue for VEC consecutive columns starting at `off` (element offset of row r, column c)
+template <int VEC>
+__device__ __forceinline__ void epilogue(const SpmmArgs &a, size_t off, const float (&y)[VEC])
+{
+    if (a.Y)
+        store_vec<VEC>(a.Y + off, y);
+    if (a.acc_out) {
+        float t[VEC];
+        load_vec<VEC>(a.acc_in + off, t);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            t[k] = t[k] + y[k];
+            if (a.acc_div != 1.0f)
+                t[k] = t[k] / a.acc_div;  // IEEE division: the reference divides (torch.mean), base_model.py:157
+        }
+        store_vec<VEC>(a.acc_out + off, t);
+    }
+}
+
+// One wave walks entries [beg, end) (wave-uniform bounds) of one row; lane owns columns
+// [lane*VEC, lane*VEC+VEC).  acc continues the fmaf chain.
+template <int VEC, int UNROLL>
+__device__ __forceinline__ void accumulate_wave(const SpmmArgs &a, int beg, int end, int lane, float (&acc)[VEC])
+{
+    const float *__restrict__ Xl = a.X + lane * VEC;
+    const size_t d = (size_t)a.d;
+    for (int base = beg; base < end; base += kWave) {
+        const int n = min(kWave, end - base);  // uniform
+        int c = 0;
+        float v = 0.0f;
+        if (lane < n) {
+            c = a.colidx[base + lane];
+            v = a.vals[base + lane];
+        }
+        int j = 0;
+        for (; j + UNROLL <= n; j += UNROLL) {
+            float x[UNROLL][VEC];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int cj = __builtin_amdgcn_readlane(c, j + u);
+                load_vec<VEC>(Xl + (size_t)cj * d, x[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const float vj = readlane_f(v, j + u);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k)
+                    acc[k] = fmaf(vj, x[u][k], acc[k]);
+            }
+        }
+        if (j < n) {  // tail: same shape, clamped index + uniform predicate, so the loads still overlap
+            float x[UNROLL][VEC];
+#pragma unroll
+            for (int u = 0; u < UNROLL - 1; ++u) {
+                const int cj = __builtin_amdgcn_readlane(c, min(j + u, n - 1));
+                load_vec<VEC>(Xl + (size_t)cj * d, x[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL - 1; ++u) {
+                if (j + u < n) {
+                    const float vj = readlane_f(v, j + u);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k)
+                        acc[k] = fmaf(vj, x[u][k], acc[k]);
+                }
+            }
+        }
+    }
+}
+
+// chunk wave: partial chain of one chunk of a long row -> workspace
+template <int VEC, int UNROLL>
+__device__ __forceinline__ void chunk_wave(const SpmmArgs &a, int chunk, int lane)
+{
+    const int beg = a.chunk_beg[chunk];
+    const int end = a.chunk_end[chunk];
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k)
+        acc[k] = 0.0f;
+    accumulate_wave<VEC, UNROLL>(a, beg, end, lane, acc);
+    store_vec<VEC>(a.ws + (size_t)chunk * a.d + lane * VEC, acc);
+}
+
+template <int VEC, int UNROLL>
+__global__ __launch_bounds__(256) void k_spmm_wave(const SpmmArgs a)
+{
+    const int lane = lane_id();
+    const int wave = uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (wave >= a.row_waves) {
+        if (wave - a.row_waves < a.n_chunks)
+            chunk_wave<VEC, UNROLL>(a, wave - a.row_waves, lane);
+        return;
+    }
+    const int row = wave;
+    const int beg = a.rowptr[row];
+    const int end = a.rowptr[row + 1];
+    if (end - beg > a.threshold)
+        return;  // long row: chunk waves + k_spmm_long_reduce
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k)
+        acc[k] = 0.0f;
+    accumulate_wave<VEC, UNROLL>(a, beg, end, lane, acc);
+    epilogue<VEC>(a, (size_t)row * a.d + lane * VEC, acc);
+}
+
+// G lanes per row, float4 per lane (d == 4*G), R = 64/G rows per wave.
+template <int G, int UNROLL>
+__global__ __launch_bounds__(256) void k_spmm_group(const SpmmArgs a)
+{
+    constexpr int R = kWave / G;
+    constexpr int D = 4 * G;
+    constexpr int VEC = D / kWave;  // for the chunk waves (wave-per-chunk layout)
+    const int lane = lane_id();
+    const int wave = uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (wave >= a.row_waves) {
+        if (wave - a.row_waves < a.n_chunks)
+            chunk_wave<VEC, 8>(a, wave - a.row_waves, lane);
+        return;
+    }
+    const int gl = lane & (G - 1);
+    const int row = wave * R + lane / G;
+    const bool valid = row < a.n_rows;
+    int beg = 0, end = 0;
+    if (valid) {
+        beg = a.rowptr[row];
+        end = a.rowptr[row + 1];
+    }
+    const bool is_long = (end - beg) > a.threshold;
+    if (is_long)
+        end = beg;
+    const float *__restrict__ Xl = a.X + gl * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int base = beg; base < end; base += G) {
+        const int n = min(G, end - base);  // uniform inside a group
+        int c = 0;
+        float v = 0.0f;
+        if (gl < n) {
+            c = a.colidx[base + gl];
+            v = a.vals[base + gl];
+        }
+        for (int j = 0; j < n; j += UNROLL) {
+            float4 x[UNROLL];
+            float vv[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int jj = min(j + u, n - 1);
+                const int cj = __shfl(c, jj, G);
+                vv[u] = __shfl(v, jj, G);
+                x[u] = *reinterpret_cast<const float4 *>(Xl + (size_t)cj * D);
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                if (j + u < n) {
+                    acc.x = fmaf(vv[u], x[u].x, acc.x);
+                    acc.y = fmaf(vv[u], x[u].y, acc.y);
+                    acc.z = fmaf(vv[u], x[u].z, acc.z);
+                    acc.w = fmaf(vv[u], x[u].w, acc.w);
+                }
+            }
+        }
+    }
+    if (valid && !is_long) {
+        const float y[4] = {acc.x, acc.y, acc.z, acc.w};
+        epilogue<4>(a, (size_t)row * D + gl * 4, y);
+    }
+}
+
+// any d: wave per row, one 64-column slab at a time (re-walks the row per slab; d <= 64 is one pass)
+__global__ __launch_bounds__(256) void k_spmm_generic(const SpmmArgs a)
+{
+    const int lane = lane_id();
+    const int row = uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (row >= a.n_rows)
+        return;
+    const int beg = a.rowptr[row];
+    const int end = a.rowptr[row + 1];
+    const size_t d = (size_t)a.d;
+    for (int c0 = 0; c0 < a.d; c0 += kWave) {
+        const int col = c0 + lane;
+        const bool on = col < a.d;
+        float acc = 0.0f;
+        for (int base = beg; base < end; base += kWave) {
+            const int n = min(kWave, end - base);
+            int c = 0;
+            float v = 0.0f;
+            if (lane < n) {
+                c = a.colidx[base + lane];
+                v = a.vals[base + lane];
+            }
+            for (int j = 0; j < n; j += 4) {
+                float x[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int cj = __builtin_amdgcn_readlane(c, min(j + u, n - 1));
+                    x[u] = on ? a.X[(size_t)cj * d + col] : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (j + u < n)
+                        acc = fmaf(readlane_f(v, min(j + u, n - 1)), x[u], acc);
+            }
+        }
+        if (on) {
+            const float y[1] = {acc};
+            epilogue<1>(a, (size_t)row * d + col, y);
+        }
+    }
+}
+
+// one wave per split row: y = ((p0 + p1) + p2) + ...  in chunk order, then the usual epilogue
+template <int VEC>
+__global__ __launch_bounds__(256) void k_spmm_long_reduce(const SpmmArgs a, const int *__restrict__ long_rows,
+                                                          const int *__restrict__ long_chunk_ptr, int n_long)
+{
+    const int lane = lane_id();
+    const int l = uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (l >= n_long)
+        return;
+    const int row = long_rows[l];
+    const int c0 = long_chunk_ptr[l], c1 = long_chunk_ptr[l + 1];
+    float y[VEC];
+    load_vec<VEC>(a.ws + (size_t)c0 * a.d + lane * VEC, y);
+    for (int c = c0 + 1; c < c1; ++c) {
+        float p[VEC];
+        load_vec<VEC>(a.ws + (size_t)c * a.d + lane * VEC, p);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k)
+            y[k] = y[k] + p[k];
+    }
+    epilogue<VEC>(a, (size_t)row * a.d + lane * VEC, y);
+}
+
+template <int VEC>
+int launch_wave(const SpmmArgs &a, int unroll, int grid, hipStream_t s)
+{
+    switch (unroll) {
+        case 4: hipLaunchKernelGGL((k_spmm_wave<VEC, 4>), dim3(grid), dim3(256), 0, s, a); break;
+        case 16: hipLaunchKernelGGL((k_spmm_wave<VEC, 16>), dim3(grid), dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((k_spmm_wave<VEC, 8>), dim3(grid), dim3(256), 0, s, a); break;
+    }
+    return check_launch("k_spmm_wave");
+}
+
+template <int G>
+int launch_group(const SpmmArgs &a, int unroll, int grid, hipStream_t s)
+{
+    switch (unroll) {
+        case 2: hipLaunchKernelGGL((k_spmm_group<G, 2>), dim3(grid), dim3(256), 0, s, a); break;
+        case 8: hipLaunchKernelGGL((k_spmm_group<G, 8>), dim3(grid), dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((k_spmm_group<G, 4>), dim3(grid), dim3(256), 0, s, a); break;
+    }
+    return check_launch("k_spmm_group");
+}
+
+}  // namespace
+}  // namespace tgcn
+
+using namespace tgcn;
+
+extern "C" int tgcn_spmm_csr_f32(const int32_t *rowptr, const int32_t *colidx, const float *vals, int64_t n_rows,
+                                 const float *X, int64_t n_src_rows, int32_t d, float *Y, const float *acc_in,
+                                 float *acc_out, float acc_div, const tgcn_split_plan_t *plan, uint32_t flags,
+                                 tgcn_stream_t stream)
+{
+    TGCN_REQUIRE(n_rows >= 0 && n_rows < INT_MAX - 256, "n_rows out of range");
+    TGCN_REQUIRE(d > 0 && d <= 4096, "d out of range");
+    TGCN_REQUIRE(n_src_rows >= 0 && n_src_rows < INT_MAX, "n_src_rows out of range");
+    if (n_rows == 0)
+        return TGCN_OK;
+    TGCN_REQUIRE(rowptr && X, "rowptr / X is NULL");
+    TGCN_REQUIRE(colidx && vals, "colidx / vals is NULL");
+    TGCN_REQUIRE(Y || acc_out, "both Y and acc_out are NULL: nothing to compute");
+    TGCN_REQUIRE(!acc_out || acc_in, "acc_out given without acc_in");
+    TGCN_REQUIRE(acc_div != 0.0f, "acc_div must be non-zero");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+
+    int variant = flags & 0xff;
+    const int unroll = (flags >> 8) & 0xff;
+    const bool vec_ok = (d == 64 || d == 128 || d == 256);
+    if (variant == TGCN_SPMM_AUTO)
+        variant = vec_ok ? TGCN_SPMM_GROUP_PER_ROW : TGCN_SPMM_WAVE_PER_ROW;
+    if (variant == TGCN_SPMM_GROUP_PER_ROW && !vec_ok)
+        variant = TGCN_SPMM_WAVE_PER_ROW;
+    TGCN_REQUIRE(variant == TGCN_SPMM_WAVE_PER_ROW || variant == TGCN_SPMM_GROUP_PER_ROW, "unknown kernel variant");
+
+    SpmmArgs a;
+    a.rowptr = rowptr, a.colidx = colidx, a.vals = vals, a.X = X, a.Y = Y;
+    a.acc_in = acc_in, a.acc_out = acc_out, a.acc_div = acc_div;
+    a.n_rows = (int)n_rows, a.d = d;
+    a.threshold = INT_MAX, a.n_chunks = 0, a.chunk_beg = nullptr, a.chunk_end = nullptr, a.ws = nullptr;
+    const bool split = plan && plan->n_chunks > 0 && vec_ok;
+    if (split) {
+        TGCN_REQUIRE(plan->threshold > 0, "plan->threshold must be positive");
+        TGCN_REQUIRE(plan->chunk_beg && plan->chunk_end && plan->long_rows && plan->long_chunk_ptr && plan->workspace,
+                     "split plan has NULL members");
+        TGCN_REQUIRE(plan->n_long > 0, "split plan has chunks but no long rows");
+        a.threshold = plan->threshold, a.n_chunks = plan->n_chunks;
+        a.chunk_beg = plan->chunk_beg, a.chunk_end = plan->chunk_end, a.ws = plan->workspace;
+    }
+
+    int rc;
+    if (!vec_ok) {
+        a.row_waves = a.n_rows;
+        const int grid = (a.n_rows + 3) / 4;
+        hipLaunchKernelGGL(k_spmm_generic, dim3(grid), dim3(256), 0, s, a);
+        return check_launch("k_spmm_generic");
+    }
+    if (variant == TGCN_SPMM_WAVE_PER_ROW) {
+        a.row_waves = a.n_rows;
+        const int grid = (a.row_waves + a.n_chunks + 3) / 4;
+        rc = d == 64 ? launch_wave<1>(a, unroll, grid, s) : d == 128 ? launch_wave<2>(a, unroll, grid, s) : launch_wave<4>(a, unroll, grid, s);
+    } else {
+        const int rows_per_wave = 256 / d;  // 64 / (d/4)
+        a.row_waves = (a.n_rows + rows_per_wave - 1) / rows_per_wave;
+        const int grid = (a.row_waves + a.n_chunks + 3) / 4;
+        rc = d == 64 ? launch_group<16>(a, unroll, grid, s) : d == 128 ? launch_group<32>(a, unroll, grid, s) : launch_group<64>(a, unroll, grid, s);
+    }
+    if (rc != TGCN_OK)
+        return rc;
+    if (split) {
+        const int grid = (plan->n_long + 3) / 4;
+        if (d == 64)
+            hipLaunchKernelGGL((k_spmm_long_reduce<1>), dim3(grid), dim3(256), 0, s, a, plan->long_rows, plan->long_chunk_ptr, plan->n_long);
+        else if (d == 128)
+            hipLaunchKernelGGL((k_spmm_long_reduce<2>), dim3(grid), dim3(256), 0, s, a, plan->long_rows, plan->long_chunk_ptr, plan->n_long);
+        else
+            hipLaunchKernelGGL((k_spmm_long_reduce<4>), dim3(grid), dim3(256), 0, s, a, plan->long_rows, plan->long_chunk_ptr, plan->n_long);
+        rc = check_launch("k_spmm_long_reduce");
+    }
+    return rc;
+}

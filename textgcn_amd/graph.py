@@ -1,0 +1,170 @@
+"""The hot path's input format: the symmetric-normalised user-item Laplacian, as CSR.
+
+Restates what TextGCN/dataset.py:122-157 (_precalculate_normalization + _convert_sp_mat_to_sp_tensor)
+produces -- a coalesced COO matrix sorted by (row, col) with fp32 values -- without the reference's DOK /
+dgl detour (infeasible at nnz = 100M).  Index work is integer and bit-exact; values follow
+the reference's float64 expression (d_r * a_rc) * d_c rounded once to fp32.
+
+Host side is numpy (this is one-off graph construction, not the timed path); device side is three int32 /
+fp32 torch tensors handed to the C ABI by pointer.
+"""
+from dataclasses import dataclass
+
+import numpy as np
+
+INT32_MAX = np.iinfo(np.int32).max
+
+
+def _as_index(a, name):
+    a = np.asarray(a)
+    if a.dtype.kind not in 'iu':
+        raise TypeError(f'{name} must be an integer array, got {a.dtype}')
+    return a.astype(np.int64, copy=False).ravel()
+
+
+@dataclass
+class NormGraph:
+    """Normalised Laplacian A (N x N, N = n_users + n_items), rows 0..U-1 users, U..N-1 items."""
+    n_users: int
+    n_items: int
+    rowptr: np.ndarray   # int64 [N+1]
+    colidx: np.ndarray   # int32 [nnz]   ascending inside a row
+    vals: np.ndarray     # float32 [nnz]
+
+    @property
+    def n(self):
+        return self.n_users + self.n_items
+
+    @property
+    def nnz(self):
+        return int(self.rowptr[-1])
+
+    # ------------------------------------------------------------------ builders
+    @classmethod
+    def from_pairs(cls, train_u, train_i, n_users, n_items):
+        """Build from the train interactions (internal ids), as dataset.py:122-138 does.
+
+        A = R^ + R^T (duplicate train rows add up, dataset.py:132), deg = row sums (:133),
+        d = deg^-0.5 in float64 with inf -> 0 (:134-135), value = (d_r * a_rc) * d_c (:136-137) -> fp32 (:156).
+        """
+        u = _as_index(train_u, 'train_u')
+        i = _as_index(train_i, 'train_i')
+        if u.shape != i.shape:
+            raise ValueError('train_u and train_i differ in length')
+        n_users, n_items = int(n_users), int(n_items)
+        n = n_users + n_items
+        if n >= INT32_MAX or 2 * len(u) >= INT32_MAX:
+            raise ValueError('graph too large for int32 indices')
+        if len(u) and (u.min() < 0 or u.max() >= n_users or i.min() < 0 or i.max() >= n_items):
+            raise ValueError('interaction id out of range')
+        # user rows: key = u * n_items + i ; item rows: key = i * n_users + u  (two half-size sorts)
+        ku, mu = np.unique(u * np.int64(max(n_items, 1)) + i, return_counts=True)
+        ki, mi = np.unique(i * np.int64(max(n_users, 1)) + u, return_counts=True)
+        ru, cu = np.divmod(ku, max(n_items, 1))
+        ri, ci = np.divmod(ki, max(n_users, 1))
+        rows = np.concatenate([ru, ri + n_users])
+        cols = np.concatenate([cu + n_users, ci])
+        mult = np.concatenate([mu, mi]).astype(np.float64)
+        deg = np.bincount(rows, weights=mult, minlength=n)
+        with np.errstate(divide='ignore'):
+            d_inv = np.power(deg, -0.5)
+        d_inv[np.isinf(d_inv)] = 0.0
+        vals = ((d_inv[rows] * mult) * d_inv[cols]).astype(np.float32)
+        rowptr = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(np.bincount(rows, minlength=n), out=rowptr[1:])
+        return cls(n_users, n_items, rowptr, cols.astype(np.int32), vals)
+
+    @classmethod
+    def from_coo(cls, idx, val, n_users, n_items):
+        """Adopt an existing coalesced COO (e.g. a reference dataset's ``norm_matrix``): idx [2, nnz]
+        sorted by (row, col), val fp32.  Accepts numpy arrays or a torch sparse COO tensor in `idx`."""
+        if hasattr(idx, 'is_sparse') and idx.is_sparse:
+            t = idx.coalesce()
+            val = t.values().detach().cpu().numpy()
+            idx = t.indices().detach().cpu().numpy()
+        idx = np.asarray(idx)
+        val = np.asarray(val, dtype=np.float32)
+        n = int(n_users) + int(n_items)
+        rows, cols = _as_index(idx[0], 'rows'), _as_index(idx[1], 'cols')
+        if len(rows) >= INT32_MAX or n >= INT32_MAX:
+            raise ValueError('graph too large for int32 indices')
+        if len(rows):
+            if rows.min() < 0 or rows.max() >= n or cols.min() < 0 or cols.max() >= n:
+                raise ValueError('COO index out of range')
+            key = rows * np.int64(n) + cols
+            if np.any(key[1:] <= key[:-1]):
+                raise ValueError('COO must be coalesced: sorted by (row, col) without duplicates')
+        rowptr = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(np.bincount(rows, minlength=n), out=rowptr[1:])
+        return cls(int(n_users), int(n_items), rowptr, cols.astype(np.int32), val.copy())
+
+    # ------------------------------------------------------------------ views
+    def to_coo(self):
+        """(idx int64 [2, nnz], val fp32) in the reference's coalesced order."""
+        rows = np.repeat(np.arange(self.n, dtype=np.int64), np.diff(self.rowptr))
+        return np.stack([rows, self.colidx.astype(np.int64)]), self.vals
+
+    def degrees(self):
+        return np.diff(self.rowptr)
+
+    def transpose_perm(self):
+        """perm with (A^T).vals == vals[perm] on the same (symmetric) structure: entry e = (r, c) of the
+        transpose takes the value stored at (c, r).  Used for dropped (non-symmetric) matrices."""
+        idx, _ = self.to_coo()
+        key_t = idx[1] * np.int64(self.n) + idx[0]
+        perm = np.argsort(key_t, kind='stable')
+        # structure is symmetric: sorted transposed keys == original keys
+        return perm.astype(np.int64)
+
+    # ------------------------------------------------------------------ 1-D row partition
+    def partition(self, world):
+        """nnz-balanced contiguous row blocks, separately for users and items.
+        Returns (user_bounds [world+1], item_bounds [world+1]) in global row ids (items offset by U)."""
+        def cut(lo, hi):
+            if hi == lo:
+                return np.full(world + 1, lo, dtype=np.int64)
+            # weight = entries + 1 per row so that empty rows are spread too
+            w = (self.rowptr[lo + 1:hi + 1] - self.rowptr[lo]) + np.arange(1, hi - lo + 1)
+            targets = w[-1] * np.arange(1, world) / world
+            inner = lo + 1 + np.searchsorted(w, targets, side='left')
+            b = np.concatenate([[lo], np.minimum(inner, hi), [hi]]).astype(np.int64)
+            return np.maximum.accumulate(b)
+        return cut(0, self.n_users), cut(self.n_users, self.n)
+
+    def row_block(self, r0, r1):
+        """CSR of rows [r0, r1): (rowptr int64 rebased to 0, colidx, vals) -- views, no copy of the big arrays."""
+        a, b = int(self.rowptr[r0]), int(self.rowptr[r1])
+        return self.rowptr[r0:r1 + 1] - a, self.colidx[a:b], self.vals[a:b]
+
+
+def split_plan_arrays(rowptr, threshold):
+    """Host arrays of a tgcn_split_plan_t for a (local) rowptr: rows with more than `threshold` entries are
+    cut into chunks of at most `threshold` entries.  Returns None when no row is long."""
+    rowptr = np.asarray(rowptr, dtype=np.int64)
+    lens = np.diff(rowptr)
+    long_rows = np.nonzero(lens > threshold)[0]
+    if len(long_rows) == 0:
+        return None
+    counts = -(-lens[long_rows] // threshold)
+    long_chunk_ptr = np.zeros(len(long_rows) + 1, dtype=np.int64)
+    np.cumsum(counts, out=long_chunk_ptr[1:])
+    owner = np.repeat(np.arange(len(long_rows)), counts)
+    within = np.arange(long_chunk_ptr[-1]) - long_chunk_ptr[owner]
+    beg = rowptr[long_rows][owner] + within * threshold
+    end = np.minimum(beg + threshold, rowptr[long_rows + 1][owner])
+    return {
+        'threshold': int(threshold),
+        'chunk_beg': beg.astype(np.int32), 'chunk_end': end.astype(np.int32),
+        'long_rows': long_rows.astype(np.int32), 'long_chunk_ptr': long_chunk_ptr.astype(np.int32),
+    }
+
+
+def train_mask_csr(train_u, train_i, n_users):
+    """CSR over all users of their train items (ascending): the device form of
+    base_model.py:257 `train_user_dict[batch_users].explode()`.  Returns (rowptr int64 [U+1], items int32)."""
+    u = _as_index(train_u, 'train_u')
+    i = _as_index(train_i, 'train_i')
+    order = np.lexsort((i, u))
+    rowptr = np.zeros(int(n_users) + 1, dtype=np.int64)
+    np.cumsum(np.bincount(u, minlength=int(n_users)), out=rowptr[1:])
+    return rowptr, i[order].astype(np.int32)

@@ -1,0 +1,143 @@
+"""K-layer LightGCN propagation on the HIP path (single GPU, or one rank's row block of a sharded graph).
+
+Replaces the loop of TextGCN/base_model.py:93-106 (representation): K x torch.sparse.mm (:148), the
+torch.cat of the two embedding tables (:91) and torch.mean(torch.stack(...)) (:157).  Device memory is
+plain torch tensors; the arithmetic is tgcn_spmm_csr_f32 (include/tgcn.h).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _capi
+from .graph import NormGraph, split_plan_arrays
+
+DEFAULT_SPLIT_THRESHOLD = 2048
+
+
+class DeviceCSR:
+    """CSR of a contiguous block of rows of A on one device (+ optional long-row split plan)."""
+
+    def __init__(self, rowptr, colidx, vals, n_src_rows, device, split_threshold=None):
+        rowptr = np.asarray(rowptr, dtype=np.int64)
+        if rowptr[-1] >= np.iinfo(np.int32).max:
+            raise ValueError('row block has >= 2^31 entries')
+        self.n_rows = len(rowptr) - 1
+        self.n_src_rows = int(n_src_rows)
+        self.nnz = int(rowptr[-1])
+        self.device = torch.device(device)
+        self.rowptr = torch.from_numpy(rowptr.astype(np.int32)).to(self.device)
+        self.colidx = torch.from_numpy(np.ascontiguousarray(colidx, dtype=np.int32)).to(self.device)
+        self.vals = torch.from_numpy(np.ascontiguousarray(vals, dtype=np.float32)).to(self.device)
+        self._plan_host = split_plan_arrays(rowptr, split_threshold) if split_threshold else None
+        self._plan_dev = None
+        self._plan_struct = {}
+        if self._plan_host is not None:
+            self._plan_dev = {k: torch.from_numpy(v).to(self.device) for k, v in self._plan_host.items()
+                              if k != 'threshold'}
+
+    @property
+    def n_chunks(self):
+        return 0 if self._plan_host is None else len(self._plan_host['chunk_beg'])
+
+    def plan(self, d):
+        """ctypes pointer to a tgcn_split_plan_t for embedding width d (workspace allocated once per d)."""
+        if self._plan_host is None:
+            return None
+        if d not in self._plan_struct:
+            ws = torch.empty((self.n_chunks, d), dtype=torch.float32, device=self.device)
+            p = self._plan_dev
+            st = _capi.SplitPlanStruct(self._plan_host['threshold'], self.n_chunks, len(self._plan_host['long_rows']), 0,
+                                       p['chunk_beg'].data_ptr(), p['chunk_end'].data_ptr(), p['long_rows'].data_ptr(),
+                                       p['long_chunk_ptr'].data_ptr(), ws.data_ptr())
+            self._plan_struct[d] = (st, ws)
+        return ctypes.byref(self._plan_struct[d][0])
+
+
+def _check_dense(t, name, device, rows=None, d=None):
+    if not isinstance(t, torch.Tensor) or t.dtype != torch.float32:
+        raise TypeError(f'{name} must be a float32 torch tensor')
+    if t.device != device:
+        raise ValueError(f'{name} is on {t.device}, expected {device}')
+    if not t.is_contiguous():
+        raise ValueError(f'{name} must be contiguous')
+    if t.dim() != 2 or (rows is not None and t.shape[0] != rows) or (d is not None and t.shape[1] != d):
+        raise ValueError(f'{name} has shape {tuple(t.shape)}, expected ({rows}, {d})')
+
+
+def spmm(csr, x, y=None, acc_in=None, acc_out=None, acc_div=1.0, exact=False, variant=_capi.SPMM_AUTO, unroll=0):
+    """One layer: y = A_block . x, optionally acc_out = (acc_in + y) / acc_div (see tgcn_spmm_csr_f32).
+
+    x [n_src_rows, d]; y / acc_in / acc_out [n_rows, d] (y or acc_out may be None).  exact=True ignores the
+    long-row plan: every row is one sequential fmaf chain, bit-identical to the reference's CPU kernel."""
+    dev = csr.device
+    if dev.type != 'cuda':
+        raise RuntimeError('textgcn_amd kernels run on a ROCm GPU only (device is %s)' % dev)
+    _check_dense(x, 'x', dev, csr.n_src_rows)
+    d = x.shape[1]
+    for t, name in ((y, 'y'), (acc_in, 'acc_in'), (acc_out, 'acc_out')):
+        if t is not None:
+            _check_dense(t, name, dev, csr.n_rows, d)
+    if y is not None and y.data_ptr() == x.data_ptr():
+        raise ValueError('y must not alias x')
+    plan = None if exact else csr.plan(d)
+    rc = _capi.lib().tgcn_spmm_csr_f32(
+        _capi.ptr(csr.rowptr), _capi.ptr(csr.colidx), _capi.ptr(csr.vals), csr.n_rows, _capi.ptr(x), csr.n_src_rows, d,
+        _capi.ptr(y), _capi.ptr(acc_in), _capi.ptr(acc_out), float(acc_div), plan, (variant & 0xff) | (unroll << 8),
+        _capi.current_stream(dev))
+    _capi.check(rc, 'tgcn_spmm_csr_f32')
+    return y if y is not None else acc_out
+
+
+class Propagator:
+    """Whole-graph K-layer forward on one GPU.
+
+    forward(e0) -> combined [N, d]  ==  mean(E0..EK)  (or EK when single=True, base_model.py:159-164),
+    E(k+1) = A . E(k).  Buffers are allocated once per embedding width and reused.
+    """
+
+    def __init__(self, graph: NormGraph, device, split_threshold=DEFAULT_SPLIT_THRESHOLD):
+        self.graph = graph
+        self.device = torch.device(device)
+        self.csr = DeviceCSR(graph.rowptr, graph.colidx, graph.vals, graph.n, self.device, split_threshold)
+        self._buf = {}
+
+    def buffers(self, d):
+        if d not in self._buf:
+            n = self.graph.n
+            self._buf[d] = tuple(torch.empty((n, d), dtype=torch.float32, device=self.device) for _ in range(3))
+        return self._buf[d]
+
+    def forward(self, e0, n_layers, single=False, exact=False, out=None, keep_layers=False, variant=_capi.SPMM_AUTO,
+                unroll=0):
+        n = self.graph.n
+        _check_dense(e0, 'e0', self.device, n)
+        d = e0.shape[1]
+        ping, pong, acc = self.buffers(d)
+        if out is None:
+            out = torch.empty((n, d), dtype=torch.float32, device=self.device)
+        layers = [e0] if keep_layers else None
+        if n_layers == 0:
+            out.copy_(e0)
+            return (out, layers) if keep_layers else out
+        x = e0
+        for k in range(1, n_layers + 1):
+            last = k == n_layers
+            if keep_layers:
+                y = torch.empty((n, d), dtype=torch.float32, device=self.device)
+            else:
+                y = ping if (k & 1) else pong
+            if single:
+                spmm(self.csr, x, y=out if (last and not keep_layers) else y, exact=exact, variant=variant, unroll=unroll)
+                if last and keep_layers:
+                    out.copy_(y)
+            else:
+                # running layer sum: acc = E0 + E1 (k = 1), acc += Ek, divided by K+1 on the last layer;
+                # the last layer's own Y is not needed (no store)
+                spmm(self.csr, x, y=None if (last and not keep_layers) else y, acc_in=e0 if k == 1 else acc,
+                     acc_out=out if last else acc, acc_div=float(n_layers + 1) if last else 1.0, exact=exact,
+                     variant=variant, unroll=unroll)
+            if keep_layers:
+                layers.append(y)
+            x = y
+        return (out, layers) if keep_layers else out

@@ -1,0 +1,87 @@
+"""Scoring wrappers over the C ABI: dense user x item scores (fp32 MFMA), train-item mask, top-k, pairwise.
+
+Replaces torch.matmul (TextGCN/base_model.py:179), the pandas explode + -inf scatter (:257-258),
+torch.topk + round (:261-263) and torch.sum(u*i, 1) (:171).
+"""
+import torch
+
+from . import _capi
+
+
+def _dev(t):
+    if t.device.type != 'cuda':
+        raise RuntimeError('textgcn_amd kernels run on a ROCm GPU only (tensor is on %s)' % t.device)
+    return t.device
+
+
+def _f32c(t, name):
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise TypeError(f'{name} must be a contiguous float32 tensor')
+    return t
+
+
+def score_dense(users_emb, items_emb, user_ids=None, out=None):
+    """S[b, i] = <users_emb[user_ids[b]], items_emb[i]>  (user_ids None: rows of users_emb in order)."""
+    dev = _dev(users_emb)
+    _f32c(users_emb, 'users_emb'), _f32c(items_emb, 'items_emb')
+    if users_emb.dim() != 2 or items_emb.dim() != 2 or users_emb.shape[1] != items_emb.shape[1]:
+        raise ValueError('users_emb / items_emb must be [*, d] with equal d')
+    if user_ids is not None:
+        if user_ids.dtype != torch.int64 or not user_ids.is_contiguous() or user_ids.device != dev:
+            raise TypeError('user_ids must be a contiguous int64 tensor on the same device')
+        b = user_ids.numel()
+    else:
+        b = users_emb.shape[0]
+    n_items, d = items_emb.shape
+    if out is None:
+        out = torch.empty((b, n_items), dtype=torch.float32, device=dev)
+    elif out.shape != (b, n_items) or out.dtype != torch.float32 or out.stride(1) != 1:
+        raise ValueError('out must be float32 [B, I] with unit inner stride')
+    rc = _capi.lib().tgcn_score_dense_f32(_capi.ptr(users_emb), _capi.ptr(user_ids), b, _capi.ptr(items_emb), n_items, d,
+                                          _capi.ptr(out), out.stride(0), _capi.current_stream(dev))
+    _capi.check(rc, 'tgcn_score_dense_f32')
+    return out
+
+
+def mask_train(scores, mask_rowptr, mask_items):
+    """scores[b, mask_items[e]] = -inf for e in [mask_rowptr[b], mask_rowptr[b+1]) -- in place."""
+    dev = _dev(scores)
+    if mask_rowptr.dtype != torch.int32 or mask_items.dtype != torch.int32:
+        raise TypeError('mask arrays must be int32')
+    if mask_rowptr.numel() != scores.shape[0] + 1:
+        raise ValueError('mask_rowptr must have B+1 entries')
+    rc = _capi.lib().tgcn_mask_f32(_capi.ptr(scores), scores.stride(0), scores.shape[0], scores.shape[1],
+                                   _capi.ptr(mask_rowptr), _capi.ptr(mask_items), _capi.current_stream(dev))
+    _capi.check(rc, 'tgcn_mask_f32')
+    return scores
+
+
+def topk(scores, k, round4=False):
+    """(values [B,k] fp32, indices [B,k] int64), ordered by (value desc, index asc)."""
+    dev = _dev(scores)
+    if scores.dtype != torch.float32 or scores.dim() != 2 or scores.stride(1) != 1:
+        raise TypeError('scores must be float32 [B, I] with unit inner stride')
+    b = scores.shape[0]
+    val = torch.empty((b, k), dtype=torch.float32, device=dev)
+    idx = torch.empty((b, k), dtype=torch.int64, device=dev)
+    rc = _capi.lib().tgcn_topk_f32(_capi.ptr(scores), scores.stride(0), b, scores.shape[1], int(k), 1 if round4 else 0,
+                                   _capi.ptr(val), _capi.ptr(idx), _capi.current_stream(dev))
+    _capi.check(rc, 'tgcn_topk_f32')
+    return val, idx
+
+
+def score_pairwise(u_table, v_table, users=None, items=None):
+    """out[r] = <u_table[users[r]], v_table[items[r]]> (None: row r)."""
+    dev = _dev(u_table)
+    _f32c(u_table, 'u_table'), _f32c(v_table, 'v_table')
+    n = users.numel() if users is not None else u_table.shape[0]
+    if (items.numel() if items is not None else v_table.shape[0]) != n:
+        raise ValueError('users / items differ in length')
+    for t in (users, items):
+        if t is not None and (t.dtype != torch.int64 or not t.is_contiguous()):
+            raise TypeError('index tensors must be contiguous int64')
+    out = torch.empty((n,), dtype=torch.float32, device=dev)
+    rc = _capi.lib().tgcn_score_pairwise_f32(_capi.ptr(u_table), _capi.ptr(users), _capi.ptr(v_table), _capi.ptr(items), n,
+                                             u_table.shape[1], _capi.ptr(out), _capi.current_stream(dev))
+    _capi.check(rc, 'tgcn_score_pairwise_f32')
+    return out
