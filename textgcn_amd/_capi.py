@@ -45,6 +45,7 @@ def lib():
             raise RuntimeError(
                 f'{LIB_PATH} is missing: build it with `python -m textgcn_amd.build` (hipcc, gfx950). '
                 'textgcn_amd has no CPU / torch fallback for its kernels.')
+        import torch  # noqa: F401  -- first: libtgcn.so binds to the HIP runtime bundled with torch (build.py)
         handle = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the .so lacks a declared symbol

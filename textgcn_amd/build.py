@@ -26,10 +26,21 @@ def hipcc():
     raise RuntimeError('hipcc not found')
 
 
+def torch_lib_dir():
+    """PyTorch-ROCm wheels bundle their own HIP runtime (torch/lib/libamdhip64.so, SONAME without version).
+    libtgcn.so must bind to THAT copy: kernels are launched on torch's streams with torch's allocations, and
+    a second runtime instance in the process (/opt/rocm's libamdhip64.so.7) sees no device."""
+    import importlib.util
+    spec = importlib.util.find_spec('torch')
+    return os.path.join(os.path.dirname(spec.origin), 'lib')
+
+
 def flags():
+    tl = torch_lib_dir()
     return [f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-shared',
             '-ffp-contract=off',  # fused multiply-adds are written explicitly (fmaf / MFMA); nothing else may fuse
-            '-fno-fast-math', f'-I{os.path.join(ROOT, "include")}', f'-I{CSRC}']
+            '-fno-fast-math', f'-I{os.path.join(ROOT, "include")}', f'-I{CSRC}',
+            '-no-hip-rt', f'-L{tl}', '-lamdhip64', f'-Wl,-rpath,{tl}', '-Wl,-rpath,/opt/rocm/lib']
 
 
 def stale():
