@@ -1,0 +1,194 @@
+"""End-to-end drop-in checks on the GPU: the LightGCN class against the reference's own outputs (golden G1-G3)
+and training-path gradients against a torch fp64 restatement."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, bits, normwise
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(**kw):
+    base = dict(k=[1, 2, 3], emb_size=64, n_layers=3, device='cuda:0', load=None, batch_size=2048, quiet=True, save=False,
+                dropout=0.4, single=False, exact=True, lr=0.001, epochs=1, reg_lambda=1e-4, evaluate_every=1, neg_samples=1,
+                save_path='.', uid='t')
+    base.update(kw)
+    return types.SimpleNamespace(**base)
+
+
+def _set_weights(model, eu, ei):
+    with torch.no_grad():
+        model.embedding_user.weight.copy_(torch.from_numpy(eu))
+        model.embedding_item.weight.copy_(torch.from_numpy(ei))
+
+
+def test_dummy_end_to_end_matches_reference(golden, cuda, tmp_path):
+    """BASELINE config 1: data/dummy, lgcn, d=64, K=3: representation bit-identical, ranked top-k identical on
+    the finite prefix, metrics identical, predictions.tsv identical where the reference's order is defined."""
+    from textgcn_amd.interactions import InteractionData
+    from textgcn_amd.model import LightGCN
+    g = golden('g1_dummy')
+    ds = InteractionData(folder=os.path.join(GOLDEN, 'dummy'), k=[1, 2, 3])
+    m = LightGCN(_params(save_path=str(tmp_path)), ds)
+    _set_weights(m, g['emb_user'], g['emb_item'])
+    ue, ie = m.representation
+    assert np.array_equal(bits(ue.cpu().numpy()), bits(g['users_emb']))
+    assert np.array_equal(bits(ie.cpu().numpy()), bits(g['items_emb']))
+    pred, scores = m.predict(range(ds.n_users), with_scores=True, save=True)
+    pred, scores = np.asarray(pred), np.asarray(scores, dtype=np.float32)
+    for b in range(5):
+        fin = np.isfinite(g['topk_val'][b])
+        assert np.array_equal(pred[b][fin], g['topk_idx'][b][fin])
+        assert np.array_equal(bits(scores[b][fin]), bits(g['topk_val'][b][fin]))
+    res = m.evaluate()
+    for name in ('recall', 'precision', 'hit', 'ndcg', 'f1'):
+        assert np.allclose(res[name], g[f'metric_{name}'], atol=1e-12)
+    ours = open(os.path.join(str(tmp_path), 'predictions.tsv')).read().splitlines()
+    ref = bytes(g['predictions_tsv']).decode().splitlines()
+    assert ours[0] == ref[0] and len(ours) == len(ref)
+    for lo, lr in zip(ours[1:], ref[1:]):
+        uo, po, so = lo.split('\t')
+        ur, pr, sr = lr.split('\t')
+        assert uo == ur
+        n_fin = sum(1 for x in eval(sr, {'inf': float('inf')}) if np.isfinite(x))
+        assert eval(po)[:n_fin] == eval(pr)[:n_fin]
+        assert eval(so, {'inf': float('inf')})[:n_fin] == eval(sr, {'inf': float('inf')})[:n_fin]
+
+
+@pytest.mark.parametrize('name,extra', [('a', {}), ('single', {'single': True}), ('k4d128', {'emb_size': 128, 'n_layers': 4}),
+                                        ('d48', {'emb_size': 48, 'n_layers': 2})])
+def test_synth60_model_vs_reference(golden, cuda, tmp_path, name, extra):
+    """G2 through the model class built from a reference-style dataset object (norm_matrix COO + pandas dicts)."""
+    import pandas as pd
+    from textgcn_amd.model import LightGCN
+    g = golden('g2_synth60')
+    n_u, n_i = int(g['n_users']), int(g['n_items'])
+    train = pd.DataFrame({'user_id': g['train_u'], 'asin': g['train_i']})
+    test = pd.DataFrame({'user_id': g['test_u'], 'asin': g['test_i']})
+    ds = types.SimpleNamespace(   # what base_model.py:54-62 reads from a reference BaseDataset
+        n_users=n_u, n_items=n_i,
+        norm_matrix=torch.sparse_coo_tensor(torch.from_numpy(g['norm_idx']), torch.from_numpy(g['norm_val']), (n_u + n_i,) * 2).coalesce(),
+        true_test_lil=test.groupby('user_id')['asin'].aggregate(list).values.tolist(),
+        train_user_dict=train.groupby('user_id')['asin'].aggregate(list), test_df=test,
+        user_mapping=pd.DataFrame({'remap_id': range(n_u), 'org_id': [f'u{x}' for x in range(n_u)]}),
+        item_mapping=pd.DataFrame({'remap_id': range(n_i), 'org_id': [f'i{x}' for x in range(n_i)]}))
+    m = LightGCN(_params(k=[5, 10], batch_size=32, save_path=str(tmp_path), **extra), ds)
+    d = int(g[f'{name}_d'])
+    _set_weights(m, g[f'{name}_layer0'][:n_u], g[f'{name}_layer0'][n_u:])
+    ue, ie = m.representation
+    assert np.array_equal(bits(ue.cpu().numpy()), bits(g[f'{name}_users_emb']))
+    assert np.array_equal(bits(ie.cpu().numpy()), bits(g[f'{name}_items_emb']))
+    pred, scores = m.predict(np.arange(n_u), with_scores=True)
+    assert np.array_equal(np.asarray(pred), g[f'{name}_topk_idx'])
+    assert np.array_equal(bits(np.asarray(scores, dtype=np.float32)), bits(g[f'{name}_topk_val']))
+    res = m.evaluate()
+    for met in ('recall', 'precision', 'hit', 'ndcg', 'f1'):
+        assert np.allclose(res[met], g[f'{name}_metric_{met}'], atol=1e-12), met
+    assert d == m.emb_size
+
+
+def test_training_mode_dropout_forward_matches_reference(golden, cuda):
+    """G3: same torch seed -> same dropped edges -> same training-mode representation as the reference."""
+    from textgcn_amd.graph import NormGraph
+    from textgcn_amd.model import LightGCN
+    import pandas as pd
+    g, g3 = golden('g2_synth60'), golden('g3_dropout')
+    n_u, n_i = int(g['n_users']), int(g['n_items'])
+    train = pd.DataFrame({'user_id': g['train_u'], 'asin': g['train_i']})
+    test = pd.DataFrame({'user_id': g['test_u'], 'asin': g['test_i']})
+    ds = types.SimpleNamespace(n_users=n_u, n_items=n_i, graph=NormGraph.from_pairs(g['train_u'], g['train_i'], n_u, n_i),
+                               true_test_lil=test.groupby('user_id')['asin'].aggregate(list).values.tolist(),
+                               train_user_dict=train.groupby('user_id')['asin'].aggregate(list), test_df=test,
+                               user_mapping=pd.DataFrame({'remap_id': range(n_u), 'org_id': range(n_u)}),
+                               item_mapping=pd.DataFrame({'remap_id': range(n_i), 'org_id': range(n_i)}), norm_matrix=None)
+    m = LightGCN(_params(k=[5], dropout=float(g3['p'])), ds)
+    _set_weights(m, g['a_layer0'][:n_u], g['a_layer0'][n_u:])
+    m.training = True
+    torch.manual_seed(123)
+    with torch.no_grad():
+        ue, ie = m.representation
+    assert np.array_equal(bits(ue.cpu().numpy()), bits(g3['users_emb']))
+    assert np.array_equal(bits(ie.cpu().numpy()), bits(g3['items_emb']))
+
+
+@pytest.mark.parametrize('single', [False, True])
+def test_backward_matches_fp64_autograd(golden, cuda, single):
+    """d loss / d E0 through the HIP forward+backward vs torch autograd on a dense fp64 restatement, with a
+    dropped (non-symmetric) matrix."""
+    from textgcn_amd.graph import NormGraph
+    from textgcn_amd.model import LightGCN
+    import pandas as pd
+    g = golden('g2_synth60')
+    n_u, n_i = int(g['n_users']), int(g['n_items'])
+    train = pd.DataFrame({'user_id': g['train_u'], 'asin': g['train_i']})
+    test = pd.DataFrame({'user_id': g['test_u'], 'asin': g['test_i']})
+    gr = NormGraph.from_pairs(g['train_u'], g['train_i'], n_u, n_i)
+    ds = types.SimpleNamespace(n_users=n_u, n_items=n_i, graph=gr,
+                               true_test_lil=test.groupby('user_id')['asin'].aggregate(list).values.tolist(),
+                               train_user_dict=train.groupby('user_id')['asin'].aggregate(list), test_df=test,
+                               user_mapping=pd.DataFrame({'remap_id': range(n_u), 'org_id': range(n_u)}),
+                               item_mapping=pd.DataFrame({'remap_id': range(n_i), 'org_id': range(n_i)}), norm_matrix=None)
+    m = LightGCN(_params(k=[5], dropout=0.4, single=single), ds)
+    m.training = True
+    torch.manual_seed(7)
+    keep = (torch.rand(gr.nnz) < 0.6)
+    torch.manual_seed(7)
+    ue, ie = m.representation
+    w = torch.randn(n_u + n_i, 64, device=cuda, generator=torch.Generator(device=cuda).manual_seed(1))
+    loss = (torch.cat([ue, ie]) * w).sum()
+    loss.backward()
+    gu, gi = m.embedding_user.weight.grad, m.embedding_item.weight.grad
+    # fp64 dense restatement
+    idx, val = gr.to_coo()
+    a = torch.zeros(n_u + n_i, n_u + n_i, dtype=torch.float64)
+    v = torch.from_numpy(val).double() / 0.6
+    a[idx[0][keep.numpy()], idx[1][keep.numpy()]] = v[keep]
+    e0 = torch.cat([m.embedding_user.weight, m.embedding_item.weight]).detach().cpu().double().requires_grad_(True)
+    cur, layers = e0, [e0]
+    for _ in range(3):
+        cur = a @ cur
+        layers.append(cur)
+    out = layers[-1] if single else torch.stack(layers).mean(0)
+    (out * w.cpu().double()).sum().backward()
+    assert normwise(torch.cat([gu, gi]).cpu().numpy(), e0.grad.numpy()) <= 1e-5
+    assert normwise(torch.cat([ue, ie]).detach().cpu().numpy(), out.detach().numpy()) <= 1e-5
+
+
+def test_fit_runs_and_checkpoint_roundtrip(cuda, tmp_path):
+    """A short training run on a synthetic TSV dataset: loss finite, parameters move, checkpoint keys are the
+    reference's, reload reproduces predictions."""
+    from textgcn_amd import synth
+    from textgcn_amd.interactions import InteractionData
+    from textgcn_amd.model import LightGCN
+    u, i = synth.interactions(120, 80, 1500, seed=3)
+    rng = np.random.default_rng(0)
+    folder = tmp_path / 'data'
+    folder.mkdir()
+    te = rng.random(len(u)) < 0.1
+    for name, sel in (('train.tsv', ~te), ('test.tsv', te)):
+        with open(folder / name, 'w') as f:
+            f.write('user_id\tasin\n')
+            for a, b in zip(u[sel], i[sel]):
+                f.write(f'u{a:04d}\ti{b:04d}\n')
+    # every user / item must appear in train for the id maps
+    p = _params(k=[5, 10], batch_size=256, epochs=2, evaluate_every=1, save=True, save_path=str(tmp_path), exact=False, data=str(folder))
+    try:
+        ds = InteractionData(p)
+    except AssertionError:
+        pytest.skip('random split left a test user without train rows')
+    m = LightGCN(p, ds)
+    before = m.embedding_user.weight.detach().clone()
+    loader = torch.utils.data.DataLoader(ds, batch_size=256, shuffle=True)
+    m.fit(loader)
+    assert not torch.equal(before, m.embedding_user.weight.detach())
+    assert os.path.exists(tmp_path / 'latest_checkpoint.pkl') and os.path.exists(tmp_path / 'best.pkl')
+    sd = torch.load(tmp_path / 'latest_checkpoint.pkl')
+    assert sorted(sd.keys()) == ['embedding_item.weight', 'embedding_user.weight']
+    pred = m.predict(np.arange(ds.n_users))
+    p2 = _params(k=[5, 10], batch_size=256, load=str(tmp_path), save_path=str(tmp_path), exact=False, data=str(folder))
+    m2 = LightGCN(p2, ds)
+    assert m2.predict(np.arange(ds.n_users)) == pred

@@ -313,10 +313,12 @@ __global__ __launch_bounds__(256) void k_spmm_long_reduce(const SpmmArgs a, cons
 template <int VEC>
 int launch_wave(const SpmmArgs &a, int unroll, int grid, hipStream_t s)
 {
+    if (unroll == 0)
+        unroll = VEC == 4 ? 8 : 16;
     switch (unroll) {
         case 4: hipLaunchKernelGGL((k_spmm_wave<VEC, 4>), dim3(grid), dim3(256), 0, s, a); break;
-        case 16: hipLaunchKernelGGL((k_spmm_wave<VEC, 16>), dim3(grid), dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL((k_spmm_wave<VEC, 8>), dim3(grid), dim3(256), 0, s, a); break;
+        case 8: hipLaunchKernelGGL((k_spmm_wave<VEC, 8>), dim3(grid), dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((k_spmm_wave<VEC, 16>), dim3(grid), dim3(256), 0, s, a); break;
     }
     return check_launch("k_spmm_wave");
 }
@@ -357,8 +359,10 @@ extern "C" int tgcn_spmm_csr_f32(const int32_t *rowptr, const int32_t *colidx, c
     int variant = flags & 0xff;
     const int unroll = (flags >> 8) & 0xff;
     const bool vec_ok = (d == 64 || d == 128 || d == 256);
+    // measured on MI355X (profiles/r01_spmm_variants.md): the gather is cache-bandwidth bound; wave-per-row with
+    // 16 row loads in flight is as fast as or faster than the group layout on every graph tried
     if (variant == TGCN_SPMM_AUTO)
-        variant = vec_ok ? TGCN_SPMM_GROUP_PER_ROW : TGCN_SPMM_WAVE_PER_ROW;
+        variant = TGCN_SPMM_WAVE_PER_ROW;
     if (variant == TGCN_SPMM_GROUP_PER_ROW && !vec_ok)
         variant = TGCN_SPMM_WAVE_PER_ROW;
     TGCN_REQUIRE(variant == TGCN_SPMM_WAVE_PER_ROW || variant == TGCN_SPMM_GROUP_PER_ROW, "unknown kernel variant");

@@ -1,0 +1,384 @@
+"""LightGCN with the reference's BaseModel method surface, computed by the HIP path.
+
+Drop-in for TextGCN/base_model.py (BaseModel): same constructor `(params, dataset)`, same hook methods
+(`_copy_params`, `_copy_dataset_params`, `_init_embeddings`, `_add_vars`), same public members
+(`representation`, `layer_aggregation`, `layer_combination`, `score_pairwise`, `score_batchwise`, `predict`,
+`evaluate`, `fit`, `get_loss`, `bpr_loss`, `reg_loss`, `load_model`, `checkpoint`, `embedding_user`,
+`embedding_item`, `k`, `batch_size`, `n_layers`, `emb_size`, `training`) and the same state_dict keys
+(`embedding_user.weight`, `embedding_item.weight`), so `main.py`'s lgcn flow runs unchanged with this class in
+its registry.
+
+What changed underneath: the K x torch.sparse.mm + cat + stack/mean of `representation`
+is tgcn_spmm_csr_f32 with the layer sum fused (K1-K4); matmul / mask / topk / round of `predict` are
+tgcn_score_* / tgcn_mask / tgcn_topk (K5-K8) fed from a device CSR of the train items instead of a pandas
+explode per batch; training differentiates through the same kernel (backward = transposed product) and edge
+dropout keeps the CSR structure, zeroing values (K10).
+"""
+import logging
+import os
+import shutil
+from collections import defaultdict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import scoring
+from .graph import NormGraph, train_mask_csr
+from .metrics import METRICS, early_stop, ranking_metrics
+from .propagate import DEFAULT_SPLIT_THRESHOLD, DeviceCSR, Propagator, spmm
+
+
+class _Propagate(torch.autograd.Function):
+    """out = combine(E0, A E0, ..., A^K E0) with A given by (structure, values); backward is the same kernel on
+    the transposed values: dE0 = sum_k (A^T)^k G / (K+1)  (Horner: g <- A^T g + G'), or (A^T)^K G for --single."""
+
+    @staticmethod
+    def forward(ctx, e0, model, vals, vals_t):
+        ctx.model, ctx.vals_t = model, vals_t
+        eng = model._engine
+        out = torch.empty_like(e0)
+        eng.forward(e0.detach(), model.n_layers, single=model._single, exact=model.exact, out=out, vals=vals)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        model = ctx.model
+        eng = model._engine
+        K = model.n_layers
+        grad = grad.contiguous()
+        if K == 0:
+            return grad, None, None, None
+        ping, pong, _ = eng.buffers(grad.shape[1])
+        if model._single:
+            x = grad
+            for k in range(K):
+                y = torch.empty_like(grad) if k == K - 1 else (ping if k % 2 == 0 else pong)
+                spmm(eng.csr, x, y=y, exact=model.exact, vals=ctx.vals_t)
+                x = y
+            return x, None, None, None
+        g0 = grad / float(K + 1)
+        x = g0
+        for k in range(K):
+            y = torch.empty_like(grad) if k == K - 1 else (ping if k % 2 == 0 else pong)
+            spmm(eng.csr, x, y=None, acc_in=g0, acc_out=y, exact=model.exact, vals=ctx.vals_t)
+            x = y
+        return x, None, None, None
+
+
+class LightGCN(nn.Module):
+    """reference: TextGCN/base_model.py:17-299 (class BaseModel)."""
+
+    exact = False   # True: no long-row split -> every row is one fmaf chain (bit-identical to the CPU reference)
+
+    def __init__(self, params, dataset):
+        super().__init__()
+        self._copy_params(params)
+        self._copy_dataset_params(dataset)
+        self._init_embeddings(params.emb_size)
+        self._add_vars(params)
+        self.load_model(getattr(params, 'load', None))
+        self.to(self.device)
+
+    # ------------------------------------------------------------------ construction hooks (base_model.py:33-75)
+    def _copy_params(self, params):
+        g = lambda name, default=None: getattr(params, name, default)  # noqa: E731
+        self.k = sorted(g('k', [20, 40]))
+        self.lr = g('lr', 0.001)
+        self.uid = g('uid', 'model')
+        self.save = g('save', False)
+        self.quiet = g('quiet', True)
+        self.epochs = g('epochs', 1)
+        self.logger = g('logger') or logging.getLogger('textgcn_amd')
+        self.device = torch.device(g('device', 'cuda' if torch.cuda.is_available() else 'cpu'))
+        self.dropout = g('dropout', 0.4)
+        self.emb_size = g('emb_size', 64)
+        self.n_layers = g('n_layers', 3)
+        self.save_path = g('save_path', '.')
+        self.batch_size = g('batch_size', 2048)
+        self.reg_lambda = g('reg_lambda', 1e-4)
+        self.evaluate_every = g('evaluate_every', 25)
+        self.neg_samples = g('neg_samples', 1)
+        self.slurm = g('slurm', False) or self.quiet
+        self._single = bool(g('single', False))
+        if self._single:   # base_model.py:51-52
+            self.layer_combination = self.layer_combination_single
+        if g('exact') is not None:
+            self.exact = bool(g('exact'))
+        self._split_threshold = g('split_threshold', DEFAULT_SPLIT_THRESHOLD)
+
+    def _copy_dataset_params(self, dataset):
+        self.n_users = dataset.n_users
+        self.n_items = dataset.n_items
+        self.norm_matrix = dataset.norm_matrix if not hasattr(dataset, 'graph') else None   # reference container (lazy in ours)
+        self._dataset = dataset
+        self.true_test_lil = dataset.true_test_lil
+        self.train_user_dict = dataset.train_user_dict
+        self.test_users = np.sort(np.asarray(dataset.test_df.user_id.unique()))
+        self.user_mapping_dict = dict(dataset.user_mapping[['remap_id', 'org_id']].values)
+        self.item_mapping_dict = dict(dataset.item_mapping[['remap_id', 'org_id']].values)
+        # hot-path inputs: CSR Laplacian + CSR of train items per user
+        if hasattr(dataset, 'graph'):
+            self.graph = dataset.graph
+        else:   # a reference BaseDataset: adopt its coalesced COO (dataset.py:138)
+            self.graph = NormGraph.from_coo(dataset.norm_matrix, None, self.n_users, self.n_items)
+        if hasattr(dataset, 'mask_rowptr'):
+            rp, items = dataset.mask_rowptr, dataset.mask_items
+        else:
+            tud = dataset.train_user_dict
+            users = np.repeat(np.asarray(tud.index), [len(v) for v in tud.values])
+            rp, items = train_mask_csr(users, np.concatenate([np.asarray(v) for v in tud.values]), self.n_users)
+        self._mask_rowptr_host, self._mask_items_host = np.asarray(rp, dtype=np.int64), np.asarray(items, dtype=np.int32)
+
+    def _init_embeddings(self, emb_size):
+        """base_model.py:64-69; the two tables are views of ONE contiguous [N, d] buffer so the layer-0 matrix
+        needs no torch.cat (K2)."""
+        n = self.n_users + self.n_items
+        self._flat = torch.empty((n, emb_size), dtype=torch.float32, device=self.device)
+        self.embedding_user = nn.Embedding(self.n_users, emb_size, _weight=self._flat[:self.n_users])
+        self.embedding_item = nn.Embedding(self.n_items, emb_size, _weight=self._flat[self.n_users:])
+        nn.init.normal_(self.embedding_user.weight, std=0.1)
+        nn.init.normal_(self.embedding_item.weight, std=0.1)
+
+    def _add_vars(self, params):
+        self.metrics = list(METRICS)
+        self.metrics_logger = {m: np.zeros((0, len(self.k))) for m in self.metrics}
+        self.training = False
+        self._engine_obj = None
+        self._mask_dev = None
+        self._drop = None
+
+    # ------------------------------------------------------------------ engine (device state, built lazily)
+    @property
+    def _engine(self):
+        if self._engine_obj is None:
+            if self.device.type != 'cuda':
+                raise RuntimeError('LightGCN computes on a ROCm GPU only; there is no CPU fallback '
+                                   f'(model device is {self.device})')
+            self._engine_obj = Propagator(self.graph, self.device, split_threshold=self._split_threshold)
+        return self._engine_obj
+
+    def _mask(self):
+        if self._mask_dev is None:
+            self._mask_dev = (torch.from_numpy(self._mask_rowptr_host).to(self.device),
+                              torch.from_numpy(self._mask_items_host).to(self.device))
+        return self._mask_dev
+
+    def _e0(self):
+        """[N, d] layer-0 matrix (base_model.py:88-91) without a copy when the tables still share storage."""
+        wu, wi = self.embedding_user.weight, self.embedding_item.weight
+        if (wu.is_contiguous() and wi.is_contiguous()
+                and wi.data_ptr() == wu.data_ptr() + wu.numel() * 4 and wu.untyped_storage().data_ptr() == wi.untyped_storage().data_ptr()):
+            flat = torch.as_strided(wu.detach(), (self.n_users + self.n_items, wu.shape[1]), (wu.shape[1], 1))
+            if torch.is_grad_enabled() and (wu.requires_grad or wi.requires_grad):
+                return torch.cat([wu, wi])   # autograd needs the graph edge; forward cost is one copy
+            return flat
+        return torch.cat([wu, wi])
+
+    @property
+    def embedding_matrix(self):
+        return self._e0()
+
+    # ------------------------------------------------------------------ dropout (base_model.py:77-86)
+    def _dropout_values(self):
+        """Edge dropout as value masking on the fixed CSR: keep entry e iff rand[e] < 1 - p, kept values scaled
+        by 1/(1-p).  The uniform draw is torch.rand(nnz) on the CPU generator exactly as base_model.py:82, so a
+        seeded run drops the same edges as the reference.  Returns (vals, vals_transposed) device tensors."""
+        g = self.graph
+        if self._drop is None:
+            scaled = (g.vals / np.float32(1 - self.dropout)).astype(np.float32)
+            self._drop = (torch.from_numpy(scaled).to(self.device), torch.from_numpy(g.transpose_perm()).to(self.device))
+        scaled, perm = self._drop
+        keep = (torch.rand(g.nnz) < (1 - self.dropout)).to(self.device)
+        vals = torch.where(keep, scaled, torch.zeros_like(scaled))
+        return vals, vals[perm]
+
+    # ------------------------------------------------------------------ forward (base_model.py:93-106)
+    @property
+    def representation(self):
+        e0 = self._e0()
+        if self.training and self.dropout > 0:
+            vals, vals_t = self._dropout_values()
+        else:
+            vals = vals_t = None   # A is symmetric: A^T = A
+        if torch.is_grad_enabled() and e0.requires_grad:
+            out = _Propagate.apply(e0, self, vals, vals_t)
+        else:
+            out = self._engine.forward(e0.detach(), self.n_layers, single=self._single, exact=self.exact, vals=vals)
+        return torch.split(out, [self.n_users, self.n_items])
+
+    def layer_aggregation(self, norm_matrix, emb_matrix):
+        """base_model.py:141-148.  `norm_matrix` is accepted for signature compatibility; the product always uses
+        the model's CSR (the same matrix) unless a NormGraph / DeviceCSR is passed explicitly."""
+        csr = norm_matrix if isinstance(norm_matrix, DeviceCSR) else self._engine.csr
+        y = torch.empty_like(emb_matrix)
+        spmm(csr, emb_matrix.contiguous(), y=y, exact=self.exact)
+        return y
+
+    def layer_combination(self, vectors):
+        """base_model.py:150-157: mean over layers == sequential sum then one division (fused in the kernel on
+        the `representation` path; this standalone form exists for callers that hold the list)."""
+        s = vectors[0]
+        for v in vectors[1:]:
+            s = s + v
+        return s / torch.tensor(float(len(vectors)), device=s.device)
+
+    def layer_combination_single(self, vectors):
+        return vectors[-1]
+
+    # ------------------------------------------------------------------ scoring (base_model.py:166-179)
+    def score_pairwise(self, users_emb, items_emb, users, items):
+        if torch.is_grad_enabled() and (users_emb.requires_grad or items_emb.requires_grad):
+            return torch.sum(users_emb * items_emb, dim=1)   # training: autograd through a tiny elementwise op
+        return scoring.score_pairwise(users_emb.contiguous(), items_emb.contiguous())
+
+    def score_batchwise(self, users_emb, items_emb, users):
+        return scoring.score_dense(users_emb.contiguous(), items_emb.contiguous())
+
+    # ------------------------------------------------------------------ losses (base_model.py:181-210)
+    def get_loss(self, data):
+        users, pos, *negs = data.to(self.device).t()
+        return self.bpr_loss(users, pos, negs) + self.reg_loss(users, pos, negs)
+
+    def bpr_loss(self, users, pos, negs):
+        users_emb, items_emb = self.representation
+        users_emb = users_emb[users]
+        pos_scores = self.score_pairwise(users_emb, items_emb[pos], users, pos)
+        loss = 0
+        for neg in negs:
+            neg_scores = self.score_pairwise(users_emb, items_emb[neg], users, neg)
+            loss += torch.mean(F.selu(neg_scores - pos_scores))
+        loss /= len(negs)
+        self._loss_values['bpr'] += loss
+        return loss
+
+    def reg_loss(self, users, pos, negs):
+        loss = (self.embedding_user(users).norm(2).pow(2)
+                + self.embedding_item(pos).norm(2).pow(2)
+                + self.embedding_item(torch.stack(negs)).norm(2).pow(2).mean())
+        res = self.reg_lambda * loss / len(users) / 2
+        self._loss_values['reg'] += res
+        return res
+
+    # ------------------------------------------------------------------ training loop (base_model.py:108-139)
+    def fit(self, batches):
+        self.optimizer = torch.optim.Adam(self.parameters(), lr=self.lr)
+        for epoch in range(1, self.epochs + 1):
+            self.train()
+            self.training = True
+            self._loss_values = defaultdict(float)
+            for data in batches:
+                self.optimizer.zero_grad()
+                batch_loss = self.get_loss(data)
+                assert not batch_loss.isnan(), f'loss is NA at epoch {epoch}'
+                batch_loss.backward()
+                self.optimizer.step()
+            if epoch % self.evaluate_every:
+                continue
+            self.logger.info(f"Epoch {epoch}: {' '.join([f'{k} = {v:.4f}' for k, v in self._loss_values.items()])}")
+            self.evaluate(epoch)
+            self.checkpoint(epoch)
+            if early_stop(self.metrics_logger):
+                self.logger.warning(f'Early stopping triggerred at epoch {epoch}')
+                break
+        else:
+            self.checkpoint(self.epochs)
+
+    # ------------------------------------------------------------------ evaluate / predict (base_model.py:212-276)
+    @torch.no_grad()
+    def evaluate(self, epoch=None):
+        self.eval()
+        self.training = False
+        predictions, _ = self.predict(self.test_users, with_scores=True)
+        results = ranking_metrics(self.true_test_lil, np.asarray(predictions), self.k)
+        self.logger.info(' ' * 11 + ''.join([f'@{i:<6}' for i in self.k]))
+        for m in results:
+            self.metrics_logger[m] = np.append(self.metrics_logger[m], [results[m]], axis=0)
+            self.logger.info(f'{m:11}' + ' '.join([f'{j:.4f}' for j in results[m]]))
+        return results
+
+    def _batch_mask(self, batch_users):
+        """device CSR (rowptr, items) of the train items of `batch_users` (host-side slicing of the mask CSR)."""
+        rp, it = self._mask_rowptr_host, self._mask_items_host
+        cnt = rp[batch_users + 1] - rp[batch_users]
+        rowptr = np.zeros(len(batch_users) + 1, dtype=np.int32)
+        np.cumsum(cnt, out=rowptr[1:])
+        if len(batch_users) and np.all(np.diff(batch_users) == 1):
+            items = it[rp[batch_users[0]]:rp[batch_users[-1] + 1]]
+        else:
+            items = np.concatenate([it[rp[u]:rp[u + 1]] for u in batch_users]) if len(batch_users) else it[:0]
+        return torch.from_numpy(rowptr).to(self.device), torch.from_numpy(np.ascontiguousarray(items)).to(self.device)
+
+    @torch.no_grad()
+    def predict(self, users, save: bool = False, with_scores: bool = False):
+        self.training = False
+        users = np.asarray(list(users) if not isinstance(users, np.ndarray) else users, dtype=np.int64)
+        kmax = max(self.k)
+        y_val, y_idx = [], []
+        users_emb, items_emb = self.representation
+        users_emb, items_emb = users_emb.contiguous(), items_emb.contiguous()
+        custom = 'score_batchwise' in self.__dict__ or type(self).score_batchwise is not LightGCN.score_batchwise
+        for j in range(0, len(users), self.batch_size):
+            batch = users[j:j + self.batch_size]
+            ids = torch.from_numpy(batch).to(self.device)
+            if custom:   # an override (e.g. LTR) returns the [B, I] matrix; mask + top-k stay on the HIP path
+                rating = self.score_batchwise(users_emb[ids], items_emb, ids).contiguous()
+            else:        # gather fused into the GEMM's operand load (base_model.py:254)
+                rating = scoring.score_dense(users_emb, items_emb, user_ids=ids)
+            rp, it = self._batch_mask(batch)
+            scoring.mask_train(rating, rp, it)                       # base_model.py:257-258
+            v, i = scoring.topk(rating, kmax, round4=True)           # base_model.py:261-263
+            y_val.append(v)
+            y_idx.append(i)
+        predictions = torch.cat(y_idx).tolist() if y_idx else []
+        scores = torch.cat(y_val).tolist() if y_val else []
+        if save:
+            self._save_predictions(users, predictions, scores)
+        if with_scores:
+            return predictions, scores
+        return predictions
+
+    def _save_predictions(self, users, predictions, scores):
+        """predictions.tsv in the reference's format (base_model.py:268-273): original ids, python-list cells."""
+        import pandas as pd
+        pred_unmapped = [[self.item_mapping_dict[i] for i in row] for row in predictions]
+        users_unmapped = [self.user_mapping_dict[u] for u in users.tolist()]
+        path = os.path.join(self.save_path, 'predictions.tsv')
+        pd.DataFrame({'user_id': users_unmapped, 'y_pred': pred_unmapped, 'scores': scores}).to_csv(path, sep='\t', index=False)
+        self.logger.info(f'Predictions are saved in `{path}`')
+
+    # ------------------------------------------------------------------ checkpoints (base_model.py:278-299)
+    def load_model(self, load_path):
+        if load_path is None:
+            self.logger.info(f'Created model {self.uid}')
+            return
+        if os.path.isdir(load_path):
+            load_path = os.path.join(load_path, 'best.pkl')
+        self.logger.info(f'Loading model {load_path}')
+        self.load_state_dict(torch.load(load_path, map_location=self.device))
+        self.logger.info('Performance of the loaded model:')
+        self.evaluate()
+        self.metrics_logger = {m: np.zeros((0, len(self.k))) for m in self.metrics}
+
+    def checkpoint(self, epoch):
+        if not self.save:
+            return
+        latest = os.path.join(self.save_path, 'latest_checkpoint.pkl')
+        torch.save(self.state_dict(), latest)
+        rec = self.metrics_logger[self.metrics[0]]
+        if len(rec) and rec[:, 0].max() == rec[-1][0]:
+            self.logger.info(f'Updating best model at epoch {epoch}')
+            shutil.copyfile(latest, os.path.join(self.save_path, 'best.pkl'))
+
+
+def get_class(name):
+    """Registry in the shape of the reference's main.get_class (main.py:16-22): name -> [DatasetCls, ModelCls]."""
+    from .interactions import InteractionData
+    table = {'lgcn': [InteractionData, LightGCN]}
+    try:
+        from .ltr import LTRData, LTRLinear
+        table['ltr_linear'] = [LTRData, LTRLinear]
+    except ImportError:
+        pass
+    return table[name]

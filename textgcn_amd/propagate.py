@@ -12,7 +12,7 @@ import torch
 from . import _capi
 from .graph import NormGraph, split_plan_arrays
 
-DEFAULT_SPLIT_THRESHOLD = 2048
+DEFAULT_SPLIT_THRESHOLD = 1024
 
 
 class DeviceCSR:
@@ -65,11 +65,13 @@ def _check_dense(t, name, device, rows=None, d=None):
         raise ValueError(f'{name} has shape {tuple(t.shape)}, expected ({rows}, {d})')
 
 
-def spmm(csr, x, y=None, acc_in=None, acc_out=None, acc_div=1.0, exact=False, variant=_capi.SPMM_AUTO, unroll=0):
+def spmm(csr, x, y=None, acc_in=None, acc_out=None, acc_div=1.0, exact=False, variant=_capi.SPMM_AUTO, unroll=0,
+         vals=None):
     """One layer: y = A_block . x, optionally acc_out = (acc_in + y) / acc_div (see tgcn_spmm_csr_f32).
 
     x [n_src_rows, d]; y / acc_in / acc_out [n_rows, d] (y or acc_out may be None).  exact=True ignores the
-    long-row plan: every row is one sequential fmaf chain, bit-identical to the reference's CPU kernel."""
+    long-row plan: every row is one sequential fmaf chain, bit-identical to the reference's CPU kernel.
+    vals: optional replacement of the stored values on the same structure (edge dropout, transposed values)."""
     dev = csr.device
     if dev.type != 'cuda':
         raise RuntimeError('textgcn_amd kernels run on a ROCm GPU only (device is %s)' % dev)
@@ -81,8 +83,12 @@ def spmm(csr, x, y=None, acc_in=None, acc_out=None, acc_div=1.0, exact=False, va
     if y is not None and y.data_ptr() == x.data_ptr():
         raise ValueError('y must not alias x')
     plan = None if exact else csr.plan(d)
+    if vals is None:
+        vals = csr.vals
+    elif vals.dtype != torch.float32 or vals.numel() != csr.nnz or vals.device != dev or not vals.is_contiguous():
+        raise ValueError('vals must be a contiguous float32 device tensor with one entry per stored element')
     rc = _capi.lib().tgcn_spmm_csr_f32(
-        _capi.ptr(csr.rowptr), _capi.ptr(csr.colidx), _capi.ptr(csr.vals), csr.n_rows, _capi.ptr(x), csr.n_src_rows, d,
+        _capi.ptr(csr.rowptr), _capi.ptr(csr.colidx), _capi.ptr(vals), csr.n_rows, _capi.ptr(x), csr.n_src_rows, d,
         _capi.ptr(y), _capi.ptr(acc_in), _capi.ptr(acc_out), float(acc_div), plan, (variant & 0xff) | (unroll << 8),
         _capi.current_stream(dev))
     _capi.check(rc, 'tgcn_spmm_csr_f32')
@@ -109,7 +115,7 @@ class Propagator:
         return self._buf[d]
 
     def forward(self, e0, n_layers, single=False, exact=False, out=None, keep_layers=False, variant=_capi.SPMM_AUTO,
-                unroll=0):
+                unroll=0, vals=None):
         n = self.graph.n
         _check_dense(e0, 'e0', self.device, n)
         d = e0.shape[1]
@@ -128,7 +134,8 @@ class Propagator:
             else:
                 y = ping if (k & 1) else pong
             if single:
-                spmm(self.csr, x, y=out if (last and not keep_layers) else y, exact=exact, variant=variant, unroll=unroll)
+                spmm(self.csr, x, y=out if (last and not keep_layers) else y, exact=exact, variant=variant, unroll=unroll,
+                     vals=vals)
                 if last and keep_layers:
                     out.copy_(y)
             else:
@@ -136,7 +143,7 @@ class Propagator:
                 # the last layer's own Y is not needed (no store)
                 spmm(self.csr, x, y=None if (last and not keep_layers) else y, acc_in=e0 if k == 1 else acc,
                      acc_out=out if last else acc, acc_div=float(n_layers + 1) if last else 1.0, exact=exact,
-                     variant=variant, unroll=unroll)
+                     variant=variant, unroll=unroll, vals=vals)
             if keep_layers:
                 layers.append(y)
             x = y

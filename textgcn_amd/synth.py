@@ -11,6 +11,8 @@ CONFIGS = {
     'c2': (100_000, 50_000, 5_000_000, 64, 3),
     'c3': (180_000, 60_000, 1_600_000, 128, 4),
     'c4': (5_000_000, 2_000_000, 100_000_000, 64, 3),
+    # cache experiment: same entry count as c2 on a 4 MB embedding table (L2-resident gathers)
+    'l2': (12_000, 4_000, 5_000_000, 64, 3),
     # small shapes for tests / smoke
     'tiny': (300, 200, 4_000, 64, 3),
     'small': (5_000, 3_000, 150_000, 64, 3),
