@@ -35,7 +35,8 @@ def test_dummy_end_to_end_matches_reference(golden, cuda, tmp_path):
     ds = InteractionData(folder=os.path.join(GOLDEN, 'dummy'), k=[1, 2, 3])
     m = LightGCN(_params(save_path=str(tmp_path)), ds)
     _set_weights(m, g['emb_user'], g['emb_item'])
-    ue, ie = m.representation
+    with torch.no_grad():
+        ue, ie = m.representation
     assert np.array_equal(bits(ue.cpu().numpy()), bits(g['users_emb']))
     assert np.array_equal(bits(ie.cpu().numpy()), bits(g['items_emb']))
     pred, scores = m.predict(range(ds.n_users), with_scores=True, save=True)
@@ -79,7 +80,8 @@ def test_synth60_model_vs_reference(golden, cuda, tmp_path, name, extra):
     m = LightGCN(_params(k=[5, 10], batch_size=32, save_path=str(tmp_path), **extra), ds)
     d = int(g[f'{name}_d'])
     _set_weights(m, g[f'{name}_layer0'][:n_u], g[f'{name}_layer0'][n_u:])
-    ue, ie = m.representation
+    with torch.no_grad():
+        ue, ie = m.representation
     assert np.array_equal(bits(ue.cpu().numpy()), bits(g[f'{name}_users_emb']))
     assert np.array_equal(bits(ie.cpu().numpy()), bits(g[f'{name}_items_emb']))
     pred, scores = m.predict(np.arange(n_u), with_scores=True)
