@@ -40,8 +40,8 @@ const char *tgcn_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Long-row split plan (optional).  A row whose stored-entry count exceeds `threshold` is cut into
- * chunks [chunk_beg[c], chunk_end[c]) of at most `threshold` consecutive entries; chunk c belongs to
- * long row number chunk_long[c]; long row l is matrix row long_rows[l] and owns chunks
+ * chunks [chunk_beg[c], chunk_end[c]) of at most `threshold` consecutive entries; long row l is matrix row
+ * long_rows[l] and owns chunks
  * [long_chunk_ptr[l], long_chunk_ptr[l+1]).  Each chunk is summed sequentially by one wavefront into
  * workspace[c, 0:d]; a second launch adds a row's chunk sums in chunk order (deterministic, no
  * atomics).  Rows at or below the threshold are summed exactly as the reference's CPU kernel does.
@@ -99,6 +99,21 @@ int tgcn_mask_f32(float *S, int64_t lds, int32_t B, int32_t I, const int32_t *ma
  *   (ATen: nearbyintf(x * 1e4f) / 1e4f).  1 <= k <= 64, k <= I. */
 int tgcn_topk_f32(const float *S, int64_t lds, int32_t B, int32_t I, int32_t k, int32_t round4,
                   float *out_val, int64_t *out_idx, tgcn_stream_t stream);
+
+/* K5+K6+K7+K8 fused: out = top-k over items of the masked scores of B users, without materialising [B, I].
+ *   replaces, per predict batch: torch.matmul + explode/-inf scatter + torch.topk + round
+ *                                                                  TextGCN/base_model.py:254-263
+ * Users are U[user_ids[b], :] (user_ids == NULL: rows 0..B-1); mask_rowptr/mask_items is a CSR over the B
+ * batch rows of each user's train items, ascending (mask_rowptr == NULL: no mask).  Result identical to
+ * tgcn_score_dense_f32 -> tgcn_mask_f32 -> tgcn_topk_f32 on the same inputs (same k-ordered fmaf chains, same
+ * (value desc, index asc) order; masked items appear, with -inf, only when fewer than k items are unmasked).
+ * `workspace`: device scratch of at least tgcn_score_topk_workspace_bytes(B, I, d, k) bytes, 256-byte aligned,
+ * caller-owned; nothing in it needs initialising or survives the call.  1 <= k <= 64, k <= I. */
+int64_t tgcn_score_topk_workspace_bytes(int32_t B, int32_t I, int32_t d, int32_t k);
+int tgcn_score_topk_f32(const float *U, const int64_t *user_ids, int32_t B, const float *It, int32_t I, int32_t d,
+                        const int32_t *mask_rowptr, const int32_t *mask_items, int32_t k, int32_t round4,
+                        float *out_val, int64_t *out_idx, void *workspace, int64_t workspace_bytes,
+                        tgcn_stream_t stream);
 
 /* K9: out[r] = <U[users[r], :], V[items[r], :]>   (users/items may be NULL: row r itself).
  *   replaces torch.sum(users_emb * items_emb, dim=1)               TextGCN/base_model.py:171

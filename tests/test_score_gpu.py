@@ -154,3 +154,97 @@ def test_full_size_c2_batch_properties(cuda, oracle):
     v, idx = scoring.topk(s, k)
     tv, ti = torch.sort(s, dim=1, descending=True, stable=True)   # stable: ties keep ascending index
     assert torch.equal(v, tv[:, :k]) and torch.equal(idx, ti[:, :k])
+
+
+# ------------------------------------------------------------------------------------------------ fused path
+def _fused_vs_dense(cuda, u, it, k, mask=None, user_ids=None, round4=True):
+    """tgcn_score_topk_f32 must equal tgcn_score_dense_f32 -> tgcn_mask_f32 -> tgcn_topk_f32 bit for bit."""
+    from textgcn_amd import scoring
+    ud, itd = torch.from_numpy(u).to(cuda), torch.from_numpy(it).to(cuda)
+    ids = None if user_ids is None else torch.from_numpy(user_ids).to(cuda)
+    rp = it_ = None
+    if mask is not None:
+        rp = torch.from_numpy(mask[0].astype(np.int32)).to(cuda)
+        it_ = torch.from_numpy(mask[1].astype(np.int32)).to(cuda)
+    s = scoring.score_dense(ud, itd, user_ids=ids)
+    if mask is not None:
+        scoring.mask_train(s, rp, it_)
+    rv, ri = scoring.topk(s, k, round4=round4)
+    v, i = scoring.score_topk(ud, itd, k, user_ids=ids, mask_rowptr=rp, mask_items=it_, round4=round4)
+    torch.cuda.synchronize()
+    assert torch.equal(i, ri), (i != ri).sum().item()
+    assert np.array_equal(bits(v.cpu().numpy()), bits(rv.cpu().numpy()))
+    return v, i
+
+
+def _rand_mask(rng, b, n_items, lo, hi):
+    cnt = rng.integers(lo, hi + 1, size=b)
+    rp = np.zeros(b + 1, dtype=np.int64)
+    np.cumsum(cnt, out=rp[1:])
+    items = np.concatenate([np.sort(rng.choice(n_items, size=c, replace=False)) for c in cnt]) if rp[-1] else np.zeros(0, np.int64)
+    return rp, items
+
+
+@pytest.mark.parametrize('b,i,d,k', [(300, 20000, 64, 40), (257, 9000, 128, 20), (130, 12345, 256, 64), (64, 10000, 100, 1),
+                                     (2048, 50000, 64, 40), (5, 8193, 48, 7)])
+def test_fused_topk_equals_dense_path(cuda, b, i, d, k):
+    rng = np.random.default_rng(b + i + d + k)
+    u = (rng.standard_normal((b, d)) * 0.1).astype(np.float32)
+    it = (rng.standard_normal((i, d)) * 0.1).astype(np.float32)
+    _fused_vs_dense(cuda, u, it, k, mask=_rand_mask(rng, b, i, 0, 120))
+    _fused_vs_dense(cuda, u, it, k, mask=None, round4=False)
+
+
+def test_fused_topk_small_catalogue_and_gather(cuda):
+    """I <= 8192 takes the dense route inside the same entry point; user_ids gather."""
+    rng = np.random.default_rng(1)
+    table = rng.standard_normal((700, 64)).astype(np.float32)
+    it = rng.standard_normal((4000, 64)).astype(np.float32)
+    ids = rng.permutation(700)[:333].astype(np.int64)
+    _fused_vs_dense(cuda, table, it, 40, mask=_rand_mask(rng, 333, 4000, 1, 50), user_ids=ids)
+    it2 = rng.standard_normal((30000, 64)).astype(np.float32)
+    _fused_vs_dense(cuda, table, it2, 40, mask=_rand_mask(rng, 333, 30000, 1, 50), user_ids=ids)
+
+
+def test_fused_topk_hard_cases(cuda):
+    """Cases built to defeat the threshold estimate: all-equal scores (no candidate passes a strict bar), scores
+    increasing with the item id, a user whose train list covers most of the catalogue (log overflow / fewer
+    than k unmasked items), duplicated item rows (ties broken by index)."""
+    rng = np.random.default_rng(2)
+    b, i, d, k = 200, 20000, 64, 40
+    u = np.abs(rng.standard_normal((b, d))).astype(np.float32) * 0.1
+    it = (rng.standard_normal((i, d)) * 0.1).astype(np.float32)
+    # (a) every item identical -> every score equal per user
+    same = np.repeat(it[:1], i, axis=0)
+    _fused_vs_dense(cuda, u, same, k, mask=_rand_mask(rng, b, i, 0, 30))
+    # (b) scores strictly increasing with the item id for every user (all-positive users x a ramp)
+    ramp = (np.arange(i, dtype=np.float32)[:, None] / i) * np.ones((1, d), dtype=np.float32)
+    _fused_vs_dense(cuda, u, ramp, k, mask=_rand_mask(rng, b, i, 0, 30))
+    # (c) heavy users: user 0 has all but 10 items masked, user 1 all but 60, user 2 has 5000 train items
+    cnt = rng.integers(0, 40, size=b)
+    cnt[0], cnt[1], cnt[2] = i - 10, i - 60, 5000
+    rp = np.zeros(b + 1, dtype=np.int64)
+    np.cumsum(cnt, out=rp[1:])
+    items = np.concatenate([np.sort(rng.choice(i, size=c, replace=False)) for c in cnt])
+    _fused_vs_dense(cuda, u, it, k, mask=(rp, items))
+    # (d) duplicated item rows: exact ties decided by the smaller index
+    dup = it.copy()
+    dup[1::2] = dup[0::2]
+    _fused_vs_dense(cuda, u, dup, k, mask=_rand_mask(rng, b, i, 0, 30))
+
+
+def test_fused_topk_vs_oracle_sample(cuda, oracle):
+    """independent check against the CPU oracle on a slice (the dense path is itself pinned to the oracle above)"""
+    from textgcn_amd import scoring
+    rng = np.random.default_rng(4)
+    b, i, d, k = 40, 9000, 64, 40
+    u = (rng.standard_normal((b, d)) * 0.1).astype(np.float32)
+    it = (rng.standard_normal((i, d)) * 0.1).astype(np.float32)
+    rp, items = _rand_mask(rng, b, i, 5, 60)
+    s = oracle.score_dense(u, it)
+    oracle.mask_train(s, rp, items)
+    rv, ri = oracle.topk(s, k, round4=True)
+    v, idx = scoring.score_topk(torch.from_numpy(u).to(cuda), torch.from_numpy(it).to(cuda), k,
+                                mask_rowptr=torch.from_numpy(rp.astype(np.int32)).to(cuda),
+                                mask_items=torch.from_numpy(items.astype(np.int32)).to(cuda), round4=True)
+    assert np.array_equal(idx.cpu().numpy(), ri) and np.array_equal(bits(v.cpu().numpy()), bits(rv))

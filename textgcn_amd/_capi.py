@@ -28,6 +28,9 @@ _SIGNATURES = {
                                             c_void_p]),
     'tgcn_mask_f32': (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     'tgcn_topk_f32': (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    'tgcn_score_topk_workspace_bytes': (c_int64, [c_int32, c_int32, c_int32, c_int32]),
+    'tgcn_score_topk_f32': (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int32,
+                                           c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     'tgcn_score_pairwise_f32': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p,
                                                c_void_p]),
 }

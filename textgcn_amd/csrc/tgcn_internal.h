@@ -46,4 +46,13 @@ __device__ __forceinline__ float readlane_f(float v, int lane)
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
+
+// launchers shared between translation units (arguments already validated by the caller)
+int launch_score_dense(const float *U, const int64_t *user_ids, int B, const float *It, int I, int d, int item_mul, float *S,
+                       int64_t lds, hipStream_t stream);
+int launch_topk(const float *S, int64_t lds, int B, int I, int k, int do_round, float *out_val, int64_t *out_idx,
+                hipStream_t stream);
+int launch_mask(float *S, int64_t lds, int B, int I, const int *mask_rowptr, const int *mask_items, int item_div,
+                hipStream_t stream);
+
 }  // namespace tgcn

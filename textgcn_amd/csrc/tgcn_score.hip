@@ -11,6 +11,7 @@
 #include <climits>
 
 #include "tgcn_internal.h"
+#include "tgcn_topk.h"
 
 namespace tgcn {
 namespace {
@@ -39,12 +40,14 @@ struct DenseArgs {
     float *__restrict__ S;
     int64_t lds;
     int B, I, d;
+    int item_mul;  // item row i lives at It[i * item_mul, :] (strided item sample; 1 = every item)
 };
 
 // stage rows [row0, row0+128) x k [k0, k0+64) of a row-major [n_rows, d] table (optionally gathered
 // through ids) into LDS, zero-filled outside the table
 __device__ __forceinline__ void stage_tile(float *__restrict__ dst, const float *__restrict__ src,
-                                           const int64_t *__restrict__ ids, int row0, int n_rows, int k0, int d)
+                                           const int64_t *__restrict__ ids, int row0, int n_rows, int k0, int d,
+                                           int row_mul = 1)
 {
     const int t = threadIdx.x;
     const bool vec = (d & 3) == 0;
@@ -57,7 +60,7 @@ __device__ __forceinline__ void stage_tile(float *__restrict__ dst, const float 
         const int k = k0 + q * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (row < n_rows && k < d) {
-            const int64_t srow = ids ? ids[row] : (int64_t)row;
+            const int64_t srow = ids ? ids[row] : (int64_t)row * row_mul;
             const float *p = src + (size_t)srow * d + k;
             if (vec) {
                 v = *reinterpret_cast<const float4 *>(p);
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(256) void k_score_dense(const DenseArgs a)
         if (k0)
             __syncthreads();
         stage_tile(ldsU, a.U, a.user_ids, u0, a.B, k0, a.d);
-        stage_tile(ldsI, a.It, nullptr, i0, a.I, k0, a.d);
+        stage_tile(ldsI, a.It, nullptr, i0, a.I, k0, a.d, a.item_mul);
         __syncthreads();
         const float *pu = ldsU + (w * 32 + r32) * kLdsRow + 2 * h;
         const float *pi = ldsI + r32 * kLdsRow + 2 * h;
@@ -133,68 +136,30 @@ __global__ __launch_bounds__(256) void k_score_dense(const DenseArgs a)
 
 // ------------------------------------------------------------------------------------------------
 // train-item mask: one wave per user row
+// item_div > 1: S holds a strided item sample (column c = item c * item_div); other items are skipped
 __global__ __launch_bounds__(256) void k_mask(float *__restrict__ S, int64_t lds, int B, int I,
-                                              const int *__restrict__ mask_rowptr, const int *__restrict__ mask_items)
+                                              const int *__restrict__ mask_rowptr, const int *__restrict__ mask_items,
+                                              int item_div)
 {
     const int b = uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (b >= B)
         return;
     const int beg = mask_rowptr[b], end = mask_rowptr[b + 1];
     for (int e = beg + lane_id(); e < end; e += kWave) {
-        const int it = mask_items[e];
+        int it = mask_items[e];
+        if (item_div > 1) {
+            if (it % item_div)
+                continue;
+            it /= item_div;
+        }
         if (it >= 0 && it < I)
             S[(size_t)b * lds + it] = -INFINITY;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// per-row top-k.  The running list lives in registers, lane j = j-th best (value desc, index asc).
-struct TopList {
-    float v;
-    int i;
-};
-
-__device__ __forceinline__ bool better(float av, int ai, float bv, int bi)
-{
-    return av > bv || (av == bv && ai < bi);
-}
-
-// insert (cv, ci) (wave-uniform) into the sorted 64-entry list; entries past the end fall off
-__device__ __forceinline__ void list_insert(TopList &e, float cv, int ci, int lane)
-{
-    const bool beats = better(e.v, e.i, cv, ci);
-    const int pos = __popcll(__ballot(beats));  // sorted list: `beats` is a prefix of lanes
-    const float uv = __shfl_up(e.v, 1);
-    const int ui = __shfl_up(e.i, 1);
-    if (lane == pos) {
-        e.v = cv;
-        e.i = ci;
-    } else if (lane > pos) {
-        e.v = uv;
-        e.i = ui;
-    }
-}
-
-// offer one value per lane (sv at index si, `on` = lane holds a real element); k-th entry is the bar
-__device__ __forceinline__ void list_offer(TopList &e, float sv, int si, bool on, int k, int lane)
-{
-    float tv = readlane_f(e.v, k - 1);
-    int ti = __builtin_amdgcn_readlane(e.i, k - 1);
-    unsigned long long m = __ballot(on && better(sv, si, tv, ti));
-    while (m) {
-        const int f = __ffsll((long long)m) - 1;
-        const float cv = readlane_f(sv, f);
-        const int ci = __builtin_amdgcn_readlane(si, f);
-        list_insert(e, cv, ci, lane);
-        tv = readlane_f(e.v, k - 1);
-        ti = __builtin_amdgcn_readlane(e.i, k - 1);
-        m &= ~(1ull << f);
-        m &= __ballot(on && better(sv, si, tv, ti));
-    }
-}
-
 // one workgroup (4 waves) per row: each wave scans a quarter of the row, wave 0 merges
-__global__ __launch_bounds__(256) void k_topk(const float *__restrict__ S, int64_t lds, int B, int I, int k, int round4,
+__global__ __launch_bounds__(256) void k_topk(const float *__restrict__ S, int64_t lds, int B, int I, int k, int do_round,
                                               float *__restrict__ out_val, int64_t *__restrict__ out_idx)
 {
     __shared__ float sv[4][kWave];
@@ -233,8 +198,8 @@ __global__ __launch_bounds__(256) void k_topk(const float *__restrict__ S, int64
         list_offer(e, sv[o][lane], si[o][lane], lane < k && si[o][lane] != INT_MAX, k, lane);
     if (lane < k) {
         float v = e.v;
-        if (round4)
-            v = nearbyintf(v * 10000.0f) / 10000.0f;  // ATen round(decimals=4)
+        if (do_round)
+            v = round4(v);
         out_val[(size_t)b * k + lane] = v;
         out_idx[(size_t)b * k + lane] = e.i;
     }
@@ -262,6 +227,30 @@ __global__ __launch_bounds__(256) void k_score_pairwise(const float *__restrict_
 
 using namespace tgcn;
 
+int tgcn::launch_score_dense(const float *U, const int64_t *user_ids, int B, const float *It, int I, int d, int item_mul,
+                             float *S, int64_t lds, hipStream_t stream)
+{
+    DenseArgs a{U, user_ids, It, S, lds, B, I, d, item_mul};
+    const dim3 grid((I + kTile - 1) / kTile, (B + kTile - 1) / kTile);
+    TGCN_REQUIRE(grid.y <= 65535, "B too large for one launch (max 65535*128 rows)");
+    hipLaunchKernelGGL(k_score_dense, grid, dim3(256), 0, stream, a);
+    return check_launch("k_score_dense");
+}
+
+int tgcn::launch_topk(const float *S, int64_t lds, int B, int I, int k, int do_round, float *out_val, int64_t *out_idx,
+                      hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_topk, dim3(B), dim3(256), 0, stream, S, lds, B, I, k, do_round, out_val, out_idx);
+    return check_launch("k_topk");
+}
+
+int tgcn::launch_mask(float *S, int64_t lds, int B, int I, const int *mask_rowptr, const int *mask_items, int item_div,
+                      hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_mask, dim3((B + 3) / 4), dim3(256), 0, stream, S, lds, B, I, mask_rowptr, mask_items, item_div);
+    return check_launch("k_mask");
+}
+
 extern "C" int tgcn_score_dense_f32(const float *U, const int64_t *user_ids, int32_t B, const float *It, int32_t I,
                                     int32_t d, float *S, int64_t lds, tgcn_stream_t stream)
 {
@@ -271,11 +260,7 @@ extern "C" int tgcn_score_dense_f32(const float *U, const int64_t *user_ids, int
         return TGCN_OK;
     TGCN_REQUIRE(U && It && S, "NULL pointer");
     TGCN_REQUIRE(lds >= I, "lds < I");
-    DenseArgs a{U, user_ids, It, S, lds, B, I, d};
-    const dim3 grid((I + kTile - 1) / kTile, (B + kTile - 1) / kTile);
-    TGCN_REQUIRE(grid.y <= 65535, "B too large for one launch (max 65535*128 rows)");
-    hipLaunchKernelGGL(k_score_dense, grid, dim3(256), 0, static_cast<hipStream_t>(stream), a);
-    return check_launch("k_score_dense");
+    return launch_score_dense(U, user_ids, B, It, I, d, 1, S, lds, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int tgcn_mask_f32(float *S, int64_t lds, int32_t B, int32_t I, const int32_t *mask_rowptr,
@@ -286,9 +271,7 @@ extern "C" int tgcn_mask_f32(float *S, int64_t lds, int32_t B, int32_t I, const 
         return TGCN_OK;
     TGCN_REQUIRE(S && mask_rowptr, "NULL pointer");
     TGCN_REQUIRE(lds >= I, "lds < I");
-    hipLaunchKernelGGL(k_mask, dim3((B + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), S, lds, B, I,
-                       mask_rowptr, mask_items);
-    return check_launch("k_mask");
+    return launch_mask(S, lds, B, I, mask_rowptr, mask_items, 1, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int tgcn_topk_f32(const float *S, int64_t lds, int32_t B, int32_t I, int32_t k, int32_t round4,
@@ -301,9 +284,7 @@ extern "C" int tgcn_topk_f32(const float *S, int64_t lds, int32_t B, int32_t I, 
         return TGCN_OK;
     TGCN_REQUIRE(S && out_val && out_idx, "NULL pointer");
     TGCN_REQUIRE(lds >= I, "lds < I");
-    hipLaunchKernelGGL(k_topk, dim3(B), dim3(256), 0, static_cast<hipStream_t>(stream), S, lds, B, I, k, round4,
-                       out_val, out_idx);
-    return check_launch("k_topk");
+    return launch_topk(S, lds, B, I, k, round4, out_val, out_idx, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int tgcn_score_pairwise_f32(const float *U, const int64_t *users, const float *V, const int64_t *items,

@@ -1,0 +1,432 @@
+// K5+K6+K7+K8 fused: top-k of masked user x item scores without materialising the [B, I] matrix.
+//
+// Replaces the per-batch chain torch.matmul -> pandas explode + -inf scatter -> torch.topk -> round of
+// TextGCN/base_model.py:254-263.  gfx950 only.
+//
+// Plan (all launches on one stream, no host round trip):
+//   1. threshold estimate.  Score every user against a strided sample of the items (every `kSampleStride`-th
+//      item, same MFMA kernel as the dense path), mask the sampled train items, take the r-th largest sample
+//      score as tau_u.  With r = 8 and stride 32 the true rank of tau_u among all items is ~256 +- 90.
+//   2. k_score_filter: the fp32 MFMA GEMM over ALL items; the 32x32 accumulators are compared against tau_u in
+//      registers and only scores > tau_u are written, as (score, item) pairs, to a log private to the lane that
+//      owns that (user, row-half) -- no atomics, no [B, I] traffic.  Items on MFMA rows (A operand, staged
+//      through LDS), users on columns (B operand, held in registers for the whole pass) so that every lane's
+//      16 results belong to ONE user and the threshold is one register.
+//   3. k_select: one wave per user merges its logs, drops train items (binary search in the user's sorted
+//      train list) and keeps the best k by (score desc, item asc).  The result is exact whenever at least k
+//      unmasked candidates were logged and no log overflowed; otherwise the user is flagged.
+//   4. k_brute: flagged users (threshold too high, log overflow, fewer than k unmasked items ...) are
+//      rescored against every item with the same k-ordered fmaf chain and selected exactly.  Rare by
+//      construction (P ~ 3e-4 per user for step 1's estimate), and it makes the whole path exact.
+// Every score is the k-ordered fp32 fmaf chain (MFMA 32x32x2 f32 or v_fma), so all four steps agree bit for
+// bit with the dense path and with the CPU restatement used in the parity tests.
+#include "tgcn_internal.h"
+#include "tgcn_topk.h"
+
+namespace tgcn {
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int kSampleStride = 32;  // items per sampled item
+constexpr int kTauRank = 8;        // tau = kTauRank-th largest masked sample score
+constexpr int kUsersPerWG = 128;   // 4 waves x 32 users
+constexpr int kStage = 64;         // items per LDS stage (2 MFMA sub-tiles of 32)
+constexpr int kSmallI = 8192;      // below this the dense path (score -> mask -> top-k) is used
+
+struct FilterArgs {
+    const float *__restrict__ U;
+    const int64_t *__restrict__ user_ids;
+    const float *__restrict__ It;
+    const float *__restrict__ tau;  // [B]
+    float2 *__restrict__ logs;      // [B][S][2][cap2]  (score, item-as-float-bits)
+    int *__restrict__ counts;       // [B][S][2]
+    int B, I, d;
+    int S;              // item splits (gridDim.y)
+    int items_per_split;  // multiple of kStage
+    int cap2;
+};
+
+// stage `rows` rows x 4*DQ columns (zero-filled past n_rows / d) with the (k0,k2,k1,k3) group swizzle
+template <int DQ>
+__device__ __forceinline__ void load_rows(float4 (&v)[(kStage * DQ) / 256], const float *__restrict__ src,
+                                          const int64_t *__restrict__ ids, int row0, int n_rows, int d)
+{
+    constexpr int N = (kStage * DQ) / 256;
+    const bool vec = (d & 3) == 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int f = i * 256 + threadIdx.x;
+        const int r = f / DQ, q = f % DQ;
+        const int row = row0 + r, k = q * 4;
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < n_rows && k < d) {
+            const int64_t srow = ids ? ids[row] : (int64_t)row;
+            const float *p = src + (size_t)srow * d + k;
+            if (vec) {
+                t = *reinterpret_cast<const float4 *>(p);
+            } else {
+                t.x = p[0];
+                if (k + 1 < d) t.y = p[1];
+                if (k + 2 < d) t.z = p[2];
+                if (k + 3 < d) t.w = p[3];
+            }
+        }
+        v[i] = t;
+    }
+}
+
+template <int DQ>
+__device__ __forceinline__ void store_rows(float *__restrict__ dst, const float4 (&v)[(kStage * DQ) / 256])
+{
+    constexpr int N = (kStage * DQ) / 256;
+    constexpr int ROW = 4 * DQ + 2;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int f = i * 256 + threadIdx.x;
+        const int r = f / DQ, q = f % DQ;
+        float *o = dst + r * ROW + q * 4;
+        *reinterpret_cast<float2 *>(o) = make_float2(v[i].x, v[i].z);
+        *reinterpret_cast<float2 *>(o + 2) = make_float2(v[i].y, v[i].w);
+    }
+}
+
+// DQ = number of 4-wide k groups held per user (d <= 4*DQ).
+template <int DQ>
+__global__ __launch_bounds__(256) void k_score_filter(const FilterArgs a)
+{
+    constexpr int ROW = 4 * DQ + 2;                      // LDS row stride in floats (bank-conflict-free ds_read_b64)
+    __shared__ __attribute__((aligned(16))) float smem[2 * kStage * ROW];  // two item stages == one 128-user tile
+    const int lane = lane_id();
+    const int w = threadIdx.x >> 6;
+    const int r32 = lane & 31;
+    const int h = lane >> 5;
+    const int u0 = blockIdx.x * kUsersPerWG;
+    const int split = blockIdx.y;
+    const int i_beg = split * a.items_per_split;
+    const int i_end = min(a.I, i_beg + a.items_per_split);
+
+    // ---- this wave's 32 users as MFMA B fragments, resident in registers for the whole pass
+    {
+        float4 v[(kStage * DQ) / 256];
+        load_rows<DQ>(v, a.U, a.user_ids, u0, a.B, a.d);
+        store_rows<DQ>(smem, v);
+        load_rows<DQ>(v, a.U, a.user_ids, u0 + kStage, a.B, a.d);
+        store_rows<DQ>(smem + kStage * ROW, v);
+    }
+    __syncthreads();
+    float2 bf[DQ];
+    {
+        const float *pu = smem + (w * 32 + r32) * ROW + 2 * h;
+#pragma unroll
+        for (int q = 0; q < DQ; ++q)
+            bf[q] = *reinterpret_cast<const float2 *>(pu + q * 4);
+    }
+    const int user = u0 + w * 32 + r32;
+    const bool user_ok = user < a.B;
+    const float tau = user_ok ? a.tau[user] : INFINITY;
+    float2 *__restrict__ log = a.logs + ((size_t)(user_ok ? user : 0) * a.S + split) * 2 * a.cap2 + (size_t)h * a.cap2;
+    int cnt = 0;
+    __syncthreads();
+
+    // ---- item stages: global -> registers (issued before the MFMA block) -> LDS (after it), double buffered
+    float4 nxt[(kStage * DQ) / 256];
+    load_rows<DQ>(nxt, a.It, nullptr, i_beg, i_end, a.d);
+    store_rows<DQ>(smem, nxt);
+    __syncthreads();
+    int buf = 0;
+    for (int s0 = i_beg; s0 < i_end; s0 += kStage) {
+        const bool more = s0 + kStage < i_end;
+        if (more)
+            load_rows<DQ>(nxt, a.It, nullptr, s0 + kStage, i_end, a.d);
+        const float *pi = smem + buf * kStage * ROW + r32 * ROW + 2 * h;
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            acc0[r] = 0.0f, acc1[r] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < DQ; ++q) {
+            const float2 a0 = *reinterpret_cast<const float2 *>(pi + q * 4);
+            const float2 a1 = *reinterpret_cast<const float2 *>(pi + 32 * ROW + q * 4);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bf[q].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, bf[q].x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bf[q].y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, bf[q].y, acc1, 0, 0, 0);
+        }
+        // C/D layout: col (user) = lane & 31, row (item) = (reg & 3) + 8 * (reg >> 2) + 4 * h
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int item = s0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (acc0[r] > tau && item < i_end) {
+                if (cnt < a.cap2)
+                    log[cnt] = make_float2(acc0[r], __int_as_float(item));
+                ++cnt;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int item = s0 + 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (acc1[r] > tau && item < i_end) {
+                if (cnt < a.cap2)
+                    log[cnt] = make_float2(acc1[r], __int_as_float(item));
+                ++cnt;
+            }
+        }
+        if (more)
+            store_rows<DQ>(smem + (buf ^ 1) * kStage * ROW, nxt);
+        __syncthreads();
+        buf ^= 1;
+    }
+    if (user_ok)
+        a.counts[((size_t)user * a.S + split) * 2 + h] = cnt;
+}
+
+struct SelectArgs {
+    const float2 *__restrict__ logs;
+    const int *__restrict__ counts;
+    const int *__restrict__ mask_rowptr;  // may be NULL
+    const int *__restrict__ mask_items;
+    float *__restrict__ out_val;
+    int64_t *__restrict__ out_idx;
+    int *__restrict__ flags;
+    int B, S, cap2, k, do_round;
+};
+
+// one wave per user
+__global__ __launch_bounds__(256) void k_select(const SelectArgs a)
+{
+    const int lane = lane_id();
+    const int b = uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (b >= a.B)
+        return;
+    int mb = 0, me = 0;
+    if (a.mask_rowptr) {
+        mb = a.mask_rowptr[b];
+        me = a.mask_rowptr[b + 1];
+    }
+    TopList e{-INFINITY, INT_MAX};
+    int n_valid = 0;
+    bool overflow = false;
+    const int n_seg = a.S * 2;
+    for (int seg = 0; seg < n_seg; ++seg) {
+        int cnt = a.counts[(size_t)b * n_seg + seg];
+        if (cnt > a.cap2) {
+            overflow = true;
+            cnt = a.cap2;
+        }
+        const float2 *__restrict__ lg = a.logs + ((size_t)b * n_seg + seg) * a.cap2;
+        for (int j0 = 0; j0 < cnt; j0 += kWave) {
+            const int j = j0 + lane;
+            bool on = j < cnt;
+            float sv = -INFINITY;
+            int si = INT_MAX;
+            if (on) {
+                const float2 t = lg[j];
+                sv = t.x;
+                si = __float_as_int(t.y);
+                if (sorted_contains(a.mask_items, mb, me, si))
+                    on = false;  // a train item of this user: base_model.py:257-258 sets it to -inf
+            }
+            n_valid += __popcll(__ballot(on));
+            list_offer(e, sv, si, on, a.k, lane);
+        }
+    }
+    const bool ok = !overflow && n_valid >= a.k;
+    if (lane == 0)
+        a.flags[b] = ok ? 0 : 1;
+    if (ok && lane < a.k) {
+        a.out_val[(size_t)b * a.k + lane] = a.do_round ? round4(e.v) : e.v;
+        a.out_idx[(size_t)b * a.k + lane] = e.i;
+    }
+}
+
+struct BruteArgs {
+    const float *__restrict__ U;
+    const int64_t *__restrict__ user_ids;
+    const float *__restrict__ It;
+    const int *__restrict__ mask_rowptr;
+    const int *__restrict__ mask_items;
+    const int *__restrict__ flags;  // NULL: every user
+    float *__restrict__ out_val;
+    int64_t *__restrict__ out_idx;
+    int B, I, d, k, do_round;
+};
+
+// exact fallback: one wave per flagged user, lane = item, k-ordered fmaf chain per item
+__global__ __launch_bounds__(64) void k_brute(const BruteArgs a)
+{
+    extern __shared__ float su[];  // the user's row
+    const int b = blockIdx.x;
+    if (a.flags && !a.flags[b])
+        return;
+    const int lane = lane_id();
+    const float *__restrict__ urow = a.U + (size_t)(a.user_ids ? a.user_ids[b] : b) * a.d;
+    for (int k = lane; k < a.d; k += kWave)
+        su[k] = urow[k];
+    __syncthreads();
+    int mb = 0, me = 0;
+    if (a.mask_rowptr) {
+        mb = a.mask_rowptr[b];
+        me = a.mask_rowptr[b + 1];
+    }
+    TopList e{-INFINITY, INT_MAX};
+    const bool vec = (a.d & 3) == 0;
+    for (int i0 = 0; i0 < a.I; i0 += kWave) {
+        const int item = i0 + lane;
+        const bool on = item < a.I;
+        float s = 0.0f;
+        if (on) {
+            const float *__restrict__ p = a.It + (size_t)item * a.d;
+            if (vec) {
+                for (int k = 0; k < a.d; k += 4) {
+                    const float4 t = *reinterpret_cast<const float4 *>(p + k);
+                    s = fmaf(su[k], t.x, s);
+                    s = fmaf(su[k + 1], t.y, s);
+                    s = fmaf(su[k + 2], t.z, s);
+                    s = fmaf(su[k + 3], t.w, s);
+                }
+            } else {
+                for (int k = 0; k < a.d; ++k)
+                    s = fmaf(su[k], p[k], s);
+            }
+            if (sorted_contains(a.mask_items, mb, me, item))
+                s = -INFINITY;
+        }
+        list_offer(e, s, item, on, a.k, lane);
+    }
+    if (lane < a.k) {
+        a.out_val[(size_t)b * a.k + lane] = a.do_round ? round4(e.v) : e.v;
+        a.out_idx[(size_t)b * a.k + lane] = e.i;
+    }
+}
+
+__global__ void k_take_column(const float *__restrict__ src, int64_t ld, int col, int n, float *__restrict__ dst)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        dst[i] = src[(size_t)i * ld + col];
+}
+
+struct Plan {
+    int S, items_per_split, cap2, m;  // m = sampled items
+    size_t off_sample, off_tauv, off_taui, off_tau, off_logs, off_counts, off_flags, total;
+    bool small;
+};
+
+size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+
+Plan make_plan(int B, int I, int d, int k)
+{
+    (void)k;
+    Plan p{};
+    p.small = I <= kSmallI || d > 256;
+    if (p.small) {
+        p.off_sample = 0;  // the [B, I] score matrix
+        p.total = align256((size_t)B * I * sizeof(float));
+        return p;
+    }
+    const int user_tiles = (B + kUsersPerWG - 1) / kUsersPerWG;
+    int S = (512 + user_tiles - 1) / user_tiles;  // >= 2 workgroups per CU in flight
+    const int max_S = max(1, I / (8 * kStage));   // at least 8 stages per split
+    S = max(1, min(min(S, 32), max_S));
+    p.items_per_split = (((I + S - 1) / S + kStage - 1) / kStage) * kStage;
+    p.S = (I + p.items_per_split - 1) / p.items_per_split;
+    p.cap2 = max(32, 1024 / (2 * p.S));
+    p.m = (I + kSampleStride - 1) / kSampleStride;
+    size_t o = 0;
+    p.off_sample = o, o += align256((size_t)B * p.m * sizeof(float));
+    p.off_tauv = o, o += align256((size_t)B * kTauRank * sizeof(float));
+    p.off_taui = o, o += align256((size_t)B * kTauRank * sizeof(int64_t));
+    p.off_tau = o, o += align256((size_t)B * sizeof(float));
+    p.off_logs = o, o += align256((size_t)B * p.S * 2 * p.cap2 * sizeof(float2));
+    p.off_counts = o, o += align256((size_t)B * p.S * 2 * sizeof(int));
+    p.off_flags = o, o += align256((size_t)B * sizeof(int));
+    p.total = o;
+    return p;
+}
+
+template <int DQ>
+int launch_filter(const FilterArgs &a, hipStream_t s)
+{
+    const dim3 grid((a.B + kUsersPerWG - 1) / kUsersPerWG, a.S);
+    hipLaunchKernelGGL((k_score_filter<DQ>), grid, dim3(256), 0, s, a);
+    return check_launch("k_score_filter");
+}
+
+}  // namespace
+}  // namespace tgcn
+
+using namespace tgcn;
+
+extern "C" int64_t tgcn_score_topk_workspace_bytes(int32_t B, int32_t I, int32_t d, int32_t k)
+{
+    if (B <= 0 || I <= 0 || d <= 0)
+        return 0;
+    return (int64_t)make_plan(B, I, d, k).total;
+}
+
+extern "C" int tgcn_score_topk_f32(const float *U, const int64_t *user_ids, int32_t B, const float *It, int32_t I,
+                                   int32_t d, const int32_t *mask_rowptr, const int32_t *mask_items, int32_t k,
+                                   int32_t round4, float *out_val, int64_t *out_idx, void *workspace,
+                                   int64_t workspace_bytes, tgcn_stream_t stream)
+{
+    TGCN_REQUIRE(B >= 0 && I >= 0, "negative size");
+    TGCN_REQUIRE(d > 0 && d <= 4096, "d out of range");
+    TGCN_REQUIRE(k >= 1 && k <= 64, "k must be in [1, 64]");
+    TGCN_REQUIRE(I >= k, "k exceeds the number of items");
+    if (B == 0)
+        return TGCN_OK;
+    TGCN_REQUIRE(U && It && out_val && out_idx, "NULL pointer");
+    TGCN_REQUIRE(!mask_rowptr || mask_items, "mask_rowptr without mask_items");
+    TGCN_REQUIRE(B <= 65535 * kUsersPerWG, "B too large for one launch");
+    const Plan p = make_plan(B, I, d, k);
+    TGCN_REQUIRE(workspace && workspace_bytes >= (int64_t)p.total, "workspace too small (tgcn_score_topk_workspace_bytes)");
+    TGCN_REQUIRE(((size_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    char *ws = static_cast<char *>(workspace);
+    int rc;
+
+    if (p.small) {  // tiny catalogues: the three-kernel dense path on a workspace-resident [B, I] matrix
+        float *S = reinterpret_cast<float *>(ws + p.off_sample);
+        if ((rc = launch_score_dense(U, user_ids, B, It, I, d, 1, S, I, s)) != TGCN_OK)
+            return rc;
+        if (mask_rowptr && (rc = launch_mask(S, I, B, I, mask_rowptr, mask_items, 1, s)) != TGCN_OK)
+            return rc;
+        return launch_topk(S, I, B, I, k, round4, out_val, out_idx, s);
+    }
+
+    // 1. tau from a strided item sample
+    float *Ss = reinterpret_cast<float *>(ws + p.off_sample);
+    float *tauv = reinterpret_cast<float *>(ws + p.off_tauv);
+    int64_t *taui = reinterpret_cast<int64_t *>(ws + p.off_taui);
+    float *tau = reinterpret_cast<float *>(ws + p.off_tau);
+    if ((rc = launch_score_dense(U, user_ids, B, It, p.m, d, kSampleStride, Ss, p.m, s)) != TGCN_OK)
+        return rc;
+    if (mask_rowptr && (rc = launch_mask(Ss, p.m, B, p.m, mask_rowptr, mask_items, kSampleStride, s)) != TGCN_OK)
+        return rc;
+    if ((rc = launch_topk(Ss, p.m, B, p.m, kTauRank, 0, tauv, taui, s)) != TGCN_OK)
+        return rc;
+    hipLaunchKernelGGL(k_take_column, dim3((B + 255) / 256), dim3(256), 0, s, tauv, (int64_t)kTauRank, kTauRank - 1, B, tau);
+    if ((rc = check_launch("k_take_column")) != TGCN_OK)
+        return rc;
+
+    // 2. filtered GEMM over all items
+    FilterArgs fa;
+    fa.U = U, fa.user_ids = user_ids, fa.It = It, fa.tau = tau;
+    fa.logs = reinterpret_cast<float2 *>(ws + p.off_logs);
+    fa.counts = reinterpret_cast<int *>(ws + p.off_counts);
+    fa.B = B, fa.I = I, fa.d = d, fa.S = p.S, fa.items_per_split = p.items_per_split, fa.cap2 = p.cap2;
+    rc = d <= 64 ? launch_filter<16>(fa, s) : d <= 128 ? launch_filter<32>(fa, s) : launch_filter<64>(fa, s);
+    if (rc != TGCN_OK)
+        return rc;
+
+    // 3. exact selection from the logs; 4. exact rescoring of flagged users
+    int *flags = reinterpret_cast<int *>(ws + p.off_flags);
+    SelectArgs sa{fa.logs, fa.counts, mask_rowptr, mask_items, out_val, out_idx, flags, B, p.S, p.cap2, k, round4};
+    hipLaunchKernelGGL(k_select, dim3((B + 3) / 4), dim3(256), 0, s, sa);
+    if ((rc = check_launch("k_select")) != TGCN_OK)
+        return rc;
+    BruteArgs ba{U, user_ids, It, mask_rowptr, mask_items, flags, out_val, out_idx, B, I, d, k, round4};
+    hipLaunchKernelGGL(k_brute, dim3(B), dim3(64), (size_t)d * sizeof(float), s, ba);
+    return check_launch("k_brute");
+}

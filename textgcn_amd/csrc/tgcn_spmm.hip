@@ -300,12 +300,18 @@ __global__ __launch_bounds__(256) void k_spmm_long_reduce(const SpmmArgs a, cons
     const int c0 = long_chunk_ptr[l], c1 = long_chunk_ptr[l + 1];
     float y[VEC];
     load_vec<VEC>(a.ws + (size_t)c0 * a.d + lane * VEC, y);
-    for (int c = c0 + 1; c < c1; ++c) {
-        float p[VEC];
-        load_vec<VEC>(a.ws + (size_t)c * a.d + lane * VEC, p);
+    // loads of up to 8 chunk sums are issued together; the additions stay in chunk order
+    for (int c = c0 + 1; c < c1; c += 8) {
+        float p[8][VEC];
 #pragma unroll
-        for (int k = 0; k < VEC; ++k)
-            y[k] = y[k] + p[k];
+        for (int u = 0; u < 8; ++u)
+            load_vec<VEC>(a.ws + (size_t)min(c + u, c1 - 1) * a.d + lane * VEC, p[u]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (c + u < c1)
+#pragma unroll
+                for (int k = 0; k < VEC; ++k)
+                    y[k] = y[k] + p[u][k];
     }
     epilogue<VEC>(a, (size_t)row * a.d + lane * VEC, y);
 }

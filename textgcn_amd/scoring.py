@@ -70,6 +70,47 @@ def topk(scores, k, round4=False):
     return val, idx
 
 
+_WORKSPACE = {}
+
+
+def _workspace(dev, nbytes):
+    """one growing scratch buffer per device (torch's caching allocator returns 256-byte aligned blocks)"""
+    buf = _WORKSPACE.get(dev)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        _WORKSPACE[dev] = buf
+    return buf
+
+
+def score_topk(users_emb, items_emb, k, user_ids=None, mask_rowptr=None, mask_items=None, round4=False):
+    """Fused predict step: top-k over all items of the masked scores (tgcn_score_topk_f32).  Same result as
+    score_dense -> mask_train -> topk, without the [B, I] matrix.  mask_* is a CSR over the batch rows."""
+    dev = _dev(users_emb)
+    _f32c(users_emb, 'users_emb'), _f32c(items_emb, 'items_emb')
+    if users_emb.shape[1] != items_emb.shape[1]:
+        raise ValueError('users_emb / items_emb differ in width')
+    if user_ids is not None:
+        if user_ids.dtype != torch.int64 or not user_ids.is_contiguous() or user_ids.device != dev:
+            raise TypeError('user_ids must be a contiguous int64 tensor on the same device')
+        b = user_ids.numel()
+    else:
+        b = users_emb.shape[0]
+    if mask_rowptr is not None:
+        if mask_rowptr.dtype != torch.int32 or mask_items.dtype != torch.int32 or mask_rowptr.numel() != b + 1:
+            raise TypeError('mask arrays must be int32 with B+1 row pointers')
+    n_items, d = items_emb.shape
+    val = torch.empty((b, k), dtype=torch.float32, device=dev)
+    idx = torch.empty((b, k), dtype=torch.int64, device=dev)
+    lib = _capi.lib()
+    need = lib.tgcn_score_topk_workspace_bytes(b, n_items, d, int(k))
+    ws = _workspace(dev, max(need, 256))
+    rc = lib.tgcn_score_topk_f32(_capi.ptr(users_emb), _capi.ptr(user_ids), b, _capi.ptr(items_emb), n_items, d,
+                                 _capi.ptr(mask_rowptr), _capi.ptr(mask_items), int(k), 1 if round4 else 0, _capi.ptr(val),
+                                 _capi.ptr(idx), _capi.ptr(ws), ws.numel(), _capi.current_stream(dev))
+    _capi.check(rc, 'tgcn_score_topk_f32')
+    return val, idx
+
+
 def score_pairwise(u_table, v_table, users=None, items=None):
     """out[r] = <u_table[users[r]], v_table[items[r]]> (None: row r)."""
     dev = _dev(u_table)
