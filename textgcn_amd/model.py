@@ -322,13 +322,13 @@ class LightGCN(nn.Module):
         for j in range(0, len(users), self.batch_size):
             batch = users[j:j + self.batch_size]
             ids = torch.from_numpy(batch).to(self.device)
+            rp, it = self._batch_mask(batch)
             if custom:   # an override (e.g. LTR) returns the [B, I] matrix; mask + top-k stay on the HIP path
                 rating = self.score_batchwise(users_emb[ids], items_emb, ids).contiguous()
-            else:        # gather fused into the GEMM's operand load (base_model.py:254)
-                rating = scoring.score_dense(users_emb, items_emb, user_ids=ids)
-            rp, it = self._batch_mask(batch)
-            scoring.mask_train(rating, rp, it)                       # base_model.py:257-258
-            v, i = scoring.topk(rating, kmax, round4=True)           # base_model.py:261-263
+                scoring.mask_train(rating, rp, it)                   # base_model.py:257-258
+                v, i = scoring.topk(rating, kmax, round4=True)       # base_model.py:261-263
+            else:        # base_model.py:254-263 in one fused pass: gather + GEMM + mask + top-k + round
+                v, i = scoring.score_topk(users_emb, items_emb, kmax, user_ids=ids, mask_rowptr=rp, mask_items=it, round4=True)
             y_val.append(v)
             y_idx.append(i)
         predictions = torch.cat(y_idx).tolist() if y_idx else []
