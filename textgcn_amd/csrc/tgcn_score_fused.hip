@@ -20,6 +20,8 @@
 //      construction (P ~ 3e-4 per user for step 1's estimate), and it makes the whole path exact.
 // Every score is the k-ordered fp32 fmaf chain (MFMA 32x32x2 f32 or v_fma), so all four steps agree bit for
 // bit with the dense path and with the CPU restatement used in the parity tests.
+#include <cstdlib>
+
 #include "tgcn_internal.h"
 #include "tgcn_topk.h"
 
@@ -45,6 +47,7 @@ struct FilterArgs {
     int S;              // item splits (gridDim.y)
     int items_per_split;  // multiple of kStage
     int cap2;
+    int debug_mode;  // 0 in production (TGCN_DEBUG_FILTER_MODE, dev only)
 };
 
 // stage `rows` rows x 4*DQ columns (zero-filled past n_rows / d) with the (k0,k2,k1,k3) group swizzle
@@ -144,14 +147,40 @@ __global__ __launch_bounds__(256) void k_score_filter(const FilterArgs a)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             acc0[r] = 0.0f, acc1[r] = 0.0f;
+        // A fragments are fetched QB k-groups ahead of the MFMAs that consume them, so the LDS latency sits
+        // under the previous block's matrix work instead of in front of every four MFMAs
+        constexpr int QB = DQ < 8 ? DQ : 8;
+        float2 fa0[2][QB], fa1[2][QB];
 #pragma unroll
-        for (int q = 0; q < DQ; ++q) {
-            const float2 a0 = *reinterpret_cast<const float2 *>(pi + q * 4);
-            const float2 a1 = *reinterpret_cast<const float2 *>(pi + 32 * ROW + q * 4);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, bf[q].x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, bf[q].x, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, bf[q].y, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, bf[q].y, acc1, 0, 0, 0);
+        for (int q = 0; q < QB; ++q) {
+            fa0[0][q] = *reinterpret_cast<const float2 *>(pi + q * 4);
+            fa1[0][q] = *reinterpret_cast<const float2 *>(pi + 32 * ROW + q * 4);
+        }
+#pragma unroll
+        for (int g = 0; g < DQ / QB; ++g) {
+            if (g + 1 < DQ / QB) {
+#pragma unroll
+                for (int q = 0; q < QB; ++q) {
+                    fa0[(g + 1) & 1][q] = *reinterpret_cast<const float2 *>(pi + ((g + 1) * QB + q) * 4);
+                    fa1[(g + 1) & 1][q] = *reinterpret_cast<const float2 *>(pi + 32 * ROW + ((g + 1) * QB + q) * 4);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < QB; ++q) {
+                const float2 b2 = bf[g * QB + q];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[g & 1][q].x, b2.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[g & 1][q].x, b2.x, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[g & 1][q].y, b2.y, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[g & 1][q].y, b2.y, acc1, 0, 0, 0);
+            }
+        }
+        if (a.debug_mode == 1) {  // dev only: time the GEMM loop without the filter epilogue
+            asm volatile("" ::"v"(acc0), "v"(acc1));
+            if (more)
+                store_rows<DQ>(smem + (buf ^ 1) * kStage * ROW, nxt);
+            __syncthreads();
+            buf ^= 1;
+            continue;
         }
         // C/D layout: col (user) = lane & 31, row (item) = (reg & 3) + 8 * (reg >> 2) + 4 * h
 #pragma unroll
@@ -192,11 +221,16 @@ struct SelectArgs {
     int B, S, cap2, k, do_round;
 };
 
-// one wave per user
+constexpr int kMaskCache = 512;  // train items per user cached in LDS for the membership test
+
+// One wave per user.  Lane l walks log segment l (+64, ...): every iteration offers one candidate from each
+// of up to 64 segments, so the loop length is the longest segment, not the number of segments.
 __global__ __launch_bounds__(256) void k_select(const SelectArgs a)
 {
+    __shared__ int smask[4][kMaskCache];
     const int lane = lane_id();
-    const int b = uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int w = threadIdx.x >> 6;
+    const int b = uniform(blockIdx.x * 4 + w);
     if (b >= a.B)
         return;
     int mb = 0, me = 0;
@@ -204,19 +238,26 @@ __global__ __launch_bounds__(256) void k_select(const SelectArgs a)
         mb = a.mask_rowptr[b];
         me = a.mask_rowptr[b + 1];
     }
+    const bool cached = (me - mb) <= kMaskCache;
+    if (cached)
+        for (int j = lane; j < me - mb; j += kWave)
+            smask[w][j] = a.mask_items[mb + j];
     TopList e{-INFINITY, INT_MAX};
     int n_valid = 0;
     bool overflow = false;
     const int n_seg = a.S * 2;
-    for (int seg = 0; seg < n_seg; ++seg) {
-        int cnt = a.counts[(size_t)b * n_seg + seg];
-        if (cnt > a.cap2) {
+    for (int seg0 = 0; seg0 < n_seg; seg0 += kWave) {
+        const int seg = seg0 + lane;
+        int cnt = seg < n_seg ? a.counts[(size_t)b * n_seg + seg] : 0;
+        if (__any(cnt > a.cap2))
             overflow = true;
-            cnt = a.cap2;
-        }
+        cnt = min(cnt, a.cap2);
         const float2 *__restrict__ lg = a.logs + ((size_t)b * n_seg + seg) * a.cap2;
-        for (int j0 = 0; j0 < cnt; j0 += kWave) {
-            const int j = j0 + lane;
+        int longest = cnt;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            longest = max(longest, __shfl_xor(longest, o));
+        for (int j = 0; j < longest; ++j) {
             bool on = j < cnt;
             float sv = -INFINITY;
             int si = INT_MAX;
@@ -224,8 +265,9 @@ __global__ __launch_bounds__(256) void k_select(const SelectArgs a)
                 const float2 t = lg[j];
                 sv = t.x;
                 si = __float_as_int(t.y);
-                if (sorted_contains(a.mask_items, mb, me, si))
-                    on = false;  // a train item of this user: base_model.py:257-258 sets it to -inf
+                // a train item of this user: base_model.py:257-258 sets it to -inf
+                if (cached ? sorted_contains(smask[w], 0, me - mb, si) : sorted_contains(a.mask_items, mb, me, si))
+                    on = false;
             }
             n_valid += __popcll(__ballot(on));
             list_offer(e, sv, si, on, a.k, lane);
@@ -252,16 +294,22 @@ struct BruteArgs {
     int B, I, d, k, do_round;
 };
 
-// exact fallback: one wave per flagged user, lane = item, k-ordered fmaf chain per item
-__global__ __launch_bounds__(64) void k_brute(const BruteArgs a)
+// exact fallback: one 16-wave workgroup per flagged user; each wave scans a contiguous 1/16 of the items
+// (lane = item, k-ordered fmaf chain per item), wave 0 merges the 16 lists
+constexpr int kBruteWaves = 16;
+
+__global__ __launch_bounds__(kBruteWaves * 64) void k_brute(const BruteArgs a)
 {
-    extern __shared__ float su[];  // the user's row
+    extern __shared__ float su[];  // the user's row, then kBruteWaves lists
     const int b = blockIdx.x;
     if (a.flags && !a.flags[b])
         return;
     const int lane = lane_id();
+    const int w = threadIdx.x >> 6;
+    float *lv = su + ((a.d + 63) & ~63);
+    int *li = reinterpret_cast<int *>(lv + kBruteWaves * kWave);
     const float *__restrict__ urow = a.U + (size_t)(a.user_ids ? a.user_ids[b] : b) * a.d;
-    for (int k = lane; k < a.d; k += kWave)
+    for (int k = threadIdx.x; k < a.d; k += blockDim.x)
         su[k] = urow[k];
     __syncthreads();
     int mb = 0, me = 0;
@@ -271,9 +319,11 @@ __global__ __launch_bounds__(64) void k_brute(const BruteArgs a)
     }
     TopList e{-INFINITY, INT_MAX};
     const bool vec = (a.d & 3) == 0;
-    for (int i0 = 0; i0 < a.I; i0 += kWave) {
+    const int per = (((a.I + kBruteWaves - 1) / kBruteWaves + kWave - 1) / kWave) * kWave;
+    const int beg = min(a.I, w * per), end = min(a.I, beg + per);
+    for (int i0 = beg; i0 < end; i0 += kWave) {
         const int item = i0 + lane;
-        const bool on = item < a.I;
+        const bool on = item < end;
         float s = 0.0f;
         if (on) {
             const float *__restrict__ p = a.It + (size_t)item * a.d;
@@ -294,6 +344,13 @@ __global__ __launch_bounds__(64) void k_brute(const BruteArgs a)
         }
         list_offer(e, s, item, on, a.k, lane);
     }
+    lv[w * kWave + lane] = e.v;
+    li[w * kWave + lane] = e.i;
+    __syncthreads();
+    if (w != 0)
+        return;
+    for (int o = 1; o < kBruteWaves; ++o)
+        list_offer(e, lv[o * kWave + lane], li[o * kWave + lane], lane < a.k && li[o * kWave + lane] != INT_MAX, a.k, lane);
     if (lane < a.k) {
         a.out_val[(size_t)b * a.k + lane] = a.do_round ? round4(e.v) : e.v;
         a.out_idx[(size_t)b * a.k + lane] = e.i;
@@ -416,6 +473,10 @@ extern "C" int tgcn_score_topk_f32(const float *U, const int64_t *user_ids, int3
     fa.logs = reinterpret_cast<float2 *>(ws + p.off_logs);
     fa.counts = reinterpret_cast<int *>(ws + p.off_counts);
     fa.B = B, fa.I = I, fa.d = d, fa.S = p.S, fa.items_per_split = p.items_per_split, fa.cap2 = p.cap2;
+    {
+        const char *dbg = getenv("TGCN_DEBUG_FILTER_MODE");
+        fa.debug_mode = dbg ? atoi(dbg) : 0;
+    }
     rc = d <= 64 ? launch_filter<16>(fa, s) : d <= 128 ? launch_filter<32>(fa, s) : launch_filter<64>(fa, s);
     if (rc != TGCN_OK)
         return rc;
@@ -427,6 +488,7 @@ extern "C" int tgcn_score_topk_f32(const float *U, const int64_t *user_ids, int3
     if ((rc = check_launch("k_select")) != TGCN_OK)
         return rc;
     BruteArgs ba{U, user_ids, It, mask_rowptr, mask_items, flags, out_val, out_idx, B, I, d, k, round4};
-    hipLaunchKernelGGL(k_brute, dim3(B), dim3(64), (size_t)d * sizeof(float), s, ba);
+    const size_t brute_lds = ((size_t)((d + 63) & ~63) + 2 * kBruteWaves * kWave) * sizeof(float);
+    hipLaunchKernelGGL(k_brute, dim3(B), dim3(kBruteWaves * 64), brute_lds, s, ba);
     return check_launch("k_brute");
 }
