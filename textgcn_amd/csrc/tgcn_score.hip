@@ -45,38 +45,47 @@ struct DenseArgs {
 
 // stage rows [row0, row0+128) x k [k0, k0+64) of a row-major [n_rows, d] table (optionally gathered
 // through ids) into LDS, zero-filled outside the table
+template <bool FULLK>
 __device__ __forceinline__ void stage_tile(float *__restrict__ dst, const float *__restrict__ src,
                                            const int64_t *__restrict__ ids, int row0, int n_rows, int k0, int d,
                                            int row_mul = 1)
 {
     const int t = threadIdx.x;
-    const bool vec = (d & 3) == 0;
+    constexpr int N = (kTile * kKC / 4) / 256;
+    float4 v[N];
+    // all loads first (one predicated load per element, no early waits), then the LDS writes
 #pragma unroll
-    for (int i = 0; i < (kTile * kKC / 4) / 256; ++i) {
+    for (int i = 0; i < N; ++i) {
         const int f = i * 256 + t;
         const int r = f >> 4;  // 16 float4 per row chunk
         const int q = f & 15;
         const int row = row0 + r;
         const int k = k0 + q * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < n_rows && k < d) {
-            const int64_t srow = ids ? ids[row] : (int64_t)row * row_mul;
-            const float *p = src + (size_t)srow * d + k;
-            if (vec) {
-                v = *reinterpret_cast<const float4 *>(p);
-            } else {
-                v.x = p[0];
-                if (k + 1 < d) v.y = p[1];
-                if (k + 2 < d) v.z = p[2];
-                if (k + 3 < d) v.w = p[3];
-            }
+        // FULLK (d % 64 == 0): rows past the table are clamped, not zero-filled (their products are never stored),
+        // so the loads are unconditional and overlap; other widths need zeros in the K padding (predicated path)
+        const int crow = min(row, n_rows - 1);
+        const int64_t srow = ids ? ids[crow] : (int64_t)crow * row_mul;
+        const float *p = src + (size_t)srow * d;
+        if constexpr (FULLK) {
+            v[i] = *reinterpret_cast<const float4 *>(p + k);
+        } else {
+            const bool ok = row < n_rows;
+            v[i].x = (ok && k + 0 < d) ? p[k + 0] : 0.0f;
+            v[i].y = (ok && k + 1 < d) ? p[k + 1] : 0.0f;
+            v[i].z = (ok && k + 2 < d) ? p[k + 2] : 0.0f;
+            v[i].w = (ok && k + 3 < d) ? p[k + 3] : 0.0f;
         }
-        float *o = dst + r * kLdsRow + q * 4;
-        *reinterpret_cast<float2 *>(o) = make_float2(v.x, v.z);
-        *reinterpret_cast<float2 *>(o + 2) = make_float2(v.y, v.w);
+    }
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int f = i * 256 + t;
+        float *o = dst + (f >> 4) * kLdsRow + (f & 15) * 4;
+        *reinterpret_cast<float2 *>(o) = make_float2(v[i].x, v[i].z);
+        *reinterpret_cast<float2 *>(o + 2) = make_float2(v[i].y, v[i].w);
     }
 }
 
+template <bool FULLK>
 __global__ __launch_bounds__(256) void k_score_dense(const DenseArgs a)
 {
     __shared__ __attribute__((aligned(16))) float smem[2 * kTile * kLdsRow];
@@ -99,8 +108,8 @@ __global__ __launch_bounds__(256) void k_score_dense(const DenseArgs a)
     for (int k0 = 0; k0 < a.d; k0 += kKC) {
         if (k0)
             __syncthreads();
-        stage_tile(ldsU, a.U, a.user_ids, u0, a.B, k0, a.d);
-        stage_tile(ldsI, a.It, nullptr, i0, a.I, k0, a.d, a.item_mul);
+        stage_tile<FULLK>(ldsU, a.U, a.user_ids, u0, a.B, k0, a.d);
+        stage_tile<FULLK>(ldsI, a.It, nullptr, i0, a.I, k0, a.d, a.item_mul);
         __syncthreads();
         const float *pu = ldsU + (w * 32 + r32) * kLdsRow + 2 * h;
         const float *pi = ldsI + r32 * kLdsRow + 2 * h;
@@ -233,7 +242,10 @@ int tgcn::launch_score_dense(const float *U, const int64_t *user_ids, int B, con
     DenseArgs a{U, user_ids, It, S, lds, B, I, d, item_mul};
     const dim3 grid((I + kTile - 1) / kTile, (B + kTile - 1) / kTile);
     TGCN_REQUIRE(grid.y <= 65535, "B too large for one launch (max 65535*128 rows)");
-    hipLaunchKernelGGL(k_score_dense, grid, dim3(256), 0, stream, a);
+    if (d % kKC == 0)
+        hipLaunchKernelGGL(k_score_dense<true>, grid, dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL(k_score_dense<false>, grid, dim3(256), 0, stream, a);
     return check_launch("k_score_dense");
 }
 

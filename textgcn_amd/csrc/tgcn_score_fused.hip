@@ -51,31 +51,33 @@ struct FilterArgs {
 };
 
 // stage `rows` rows x 4*DQ columns (zero-filled past n_rows / d) with the (k0,k2,k1,k3) group swizzle
-template <int DQ>
+// FULLK (d == 4*DQ): rows past the table are clamped to the last valid row instead of zero-filled -- their
+// scores are garbage but never used (the epilogue tests item < i_end, padded users have tau = +inf) -- so every
+// load is unconditional and stays in flight across the MFMA block.  (Any `cond ? load : 0` form makes hipcc
+// branch around the load and wait for it inside the branch.)  Other widths need zeros in the K padding and take
+// the predicated path.
+template <int DQ, bool FULLK>
 __device__ __forceinline__ void load_rows(float4 (&v)[(kStage * DQ) / 256], const float *__restrict__ src,
                                           const int64_t *__restrict__ ids, int row0, int n_rows, int d)
 {
     constexpr int N = (kStage * DQ) / 256;
-    const bool vec = (d & 3) == 0;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         const int f = i * 256 + threadIdx.x;
         const int r = f / DQ, q = f % DQ;
         const int row = row0 + r, k = q * 4;
-        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < n_rows && k < d) {
-            const int64_t srow = ids ? ids[row] : (int64_t)row;
-            const float *p = src + (size_t)srow * d + k;
-            if (vec) {
-                t = *reinterpret_cast<const float4 *>(p);
-            } else {
-                t.x = p[0];
-                if (k + 1 < d) t.y = p[1];
-                if (k + 2 < d) t.z = p[2];
-                if (k + 3 < d) t.w = p[3];
-            }
+        const int crow = min(row, n_rows - 1);
+        const int64_t srow = ids ? ids[crow] : (int64_t)crow;
+        const float *p = src + (size_t)srow * d;
+        if constexpr (FULLK) {
+            v[i] = *reinterpret_cast<const float4 *>(p + k);
+        } else {
+            const bool ok = row < n_rows;
+            v[i].x = (ok && k + 0 < d) ? p[k + 0] : 0.0f;
+            v[i].y = (ok && k + 1 < d) ? p[k + 1] : 0.0f;
+            v[i].z = (ok && k + 2 < d) ? p[k + 2] : 0.0f;
+            v[i].w = (ok && k + 3 < d) ? p[k + 3] : 0.0f;
         }
-        v[i] = t;
     }
 }
 
@@ -95,7 +97,7 @@ __device__ __forceinline__ void store_rows(float *__restrict__ dst, const float4
 }
 
 // DQ = number of 4-wide k groups held per user (d <= 4*DQ).
-template <int DQ>
+template <int DQ, bool FULLK>
 __global__ __launch_bounds__(256) void k_score_filter(const FilterArgs a)
 {
     constexpr int ROW = 4 * DQ + 2;                      // LDS row stride in floats (bank-conflict-free ds_read_b64)
@@ -112,9 +114,9 @@ __global__ __launch_bounds__(256) void k_score_filter(const FilterArgs a)
     // ---- this wave's 32 users as MFMA B fragments, resident in registers for the whole pass
     {
         float4 v[(kStage * DQ) / 256];
-        load_rows<DQ>(v, a.U, a.user_ids, u0, a.B, a.d);
+        load_rows<DQ, FULLK>(v, a.U, a.user_ids, u0, a.B, a.d);
         store_rows<DQ>(smem, v);
-        load_rows<DQ>(v, a.U, a.user_ids, u0 + kStage, a.B, a.d);
+        load_rows<DQ, FULLK>(v, a.U, a.user_ids, u0 + kStage, a.B, a.d);
         store_rows<DQ>(smem + kStage * ROW, v);
     }
     __syncthreads();
@@ -134,14 +136,14 @@ __global__ __launch_bounds__(256) void k_score_filter(const FilterArgs a)
 
     // ---- item stages: global -> registers (issued before the MFMA block) -> LDS (after it), double buffered
     float4 nxt[(kStage * DQ) / 256];
-    load_rows<DQ>(nxt, a.It, nullptr, i_beg, i_end, a.d);
+    load_rows<DQ, FULLK>(nxt, a.It, nullptr, i_beg, i_end, a.d);
     store_rows<DQ>(smem, nxt);
     __syncthreads();
     int buf = 0;
     for (int s0 = i_beg; s0 < i_end; s0 += kStage) {
         const bool more = s0 + kStage < i_end;
         if (more)
-            load_rows<DQ>(nxt, a.It, nullptr, s0 + kStage, i_end, a.d);
+            load_rows<DQ, FULLK>(nxt, a.It, nullptr, s0 + kStage, i_end, a.d);
         const float *pi = smem + buf * kStage * ROW + r32 * ROW + 2 * h;
         f32x16 acc0, acc1;
 #pragma unroll
@@ -386,6 +388,8 @@ Plan make_plan(int B, int I, int d, int k)
     int S = (512 + user_tiles - 1) / user_tiles;  // >= 2 workgroups per CU in flight
     const int max_S = max(1, I / (8 * kStage));   // at least 8 stages per split
     S = max(1, min(min(S, 32), max_S));
+    if (const char *dbg = getenv("TGCN_DEBUG_SPLITS"))  // dev only
+        S = max(1, min(atoi(dbg), max_S));
     p.items_per_split = (((I + S - 1) / S + kStage - 1) / kStage) * kStage;
     p.S = (I + p.items_per_split - 1) / p.items_per_split;
     p.cap2 = max(32, 1024 / (2 * p.S));
@@ -406,7 +410,10 @@ template <int DQ>
 int launch_filter(const FilterArgs &a, hipStream_t s)
 {
     const dim3 grid((a.B + kUsersPerWG - 1) / kUsersPerWG, a.S);
-    hipLaunchKernelGGL((k_score_filter<DQ>), grid, dim3(256), 0, s, a);
+    if (a.d == 4 * DQ)
+        hipLaunchKernelGGL((k_score_filter<DQ, true>), grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((k_score_filter<DQ, false>), grid, dim3(256), 0, s, a);
     return check_launch("k_score_filter");
 }
 
