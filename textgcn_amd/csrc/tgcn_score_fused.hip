@@ -184,23 +184,32 @@ __global__ __launch_bounds__(256) void k_score_filter(const FilterArgs a)
             buf ^= 1;
             continue;
         }
-        // C/D layout: col (user) = lane & 31, row (item) = (reg & 3) + 8 * (reg >> 2) + 4 * h
+        // C/D layout: col (user) = lane & 31, row (item) = (reg & 3) + 8 * (reg >> 2) + 4 * h.
+        // ~0.5 % of the scores pass; the wave-level ballot turns the common "nobody passes" case into one
+        // scalar branch per register instead of an exec-mask save/restore.
+        const int lim = i_end - s0;  // rows >= lim are padding (only in the last stage of the last split)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int item = s0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (acc0[r] > tau && item < i_end) {
-                if (cnt < a.cap2)
-                    log[cnt] = make_float2(acc0[r], __int_as_float(item));
-                ++cnt;
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const bool pass = acc0[r] > tau && row < lim;
+            if (__ballot(pass)) {
+                if (pass) {
+                    if (cnt < a.cap2)
+                        log[cnt] = make_float2(acc0[r], __int_as_float(s0 + row));
+                    ++cnt;
+                }
             }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int item = s0 + 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (acc1[r] > tau && item < i_end) {
-                if (cnt < a.cap2)
-                    log[cnt] = make_float2(acc1[r], __int_as_float(item));
-                ++cnt;
+            const int row = 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const bool pass = acc1[r] > tau && row < lim;
+            if (__ballot(pass)) {
+                if (pass) {
+                    if (cnt < a.cap2)
+                        log[cnt] = make_float2(acc1[r], __int_as_float(s0 + row));
+                    ++cnt;
+                }
             }
         }
         if (more)
