@@ -127,3 +127,25 @@ def test_train_mask_csr_matches_oracle(golden, oracle):
     rp, items = train_mask_csr(g['train_u'], g['train_i'], int(g['n_users']))
     orp, oitems = oracle.train_mask_csr(g['train_u'], g['train_i'], np.arange(int(g['n_users'])))
     assert np.array_equal(rp, orp) and np.array_equal(items, oitems)
+
+
+def test_block_plan_arrays_segments_partition_rows(golden):
+    from textgcn_amd.graph import block_plan_arrays
+    g = golden('g5_medium')
+    gr = NormGraph.from_pairs(g['train_u'], g['train_i'], int(g['n_users']), int(g['n_items']))
+    u, n = gr.n_users, gr.n
+    for (r0, r1, c0, c1) in ((0, u, u, n), (u, n, 0, u)):
+        bp, nb = block_plan_arrays(gr.rowptr, gr.colidx, r0, r1, c0, c1, 100, long_threshold=64)
+        assert bp.shape == (nb + 1, r1 - r0) and nb >= 2
+        lens = np.diff(gr.rowptr[r0:r1 + 1])
+        assert np.all(np.diff(bp.astype(np.int64), axis=0) >= 0)
+        short = lens <= 64
+        assert np.array_equal(bp[0][short], gr.rowptr[r0:r1][short]) and np.array_equal(bp[nb][short], gr.rowptr[r0 + 1:r1 + 1][short])
+        assert np.all(bp[:, ~short] == gr.rowptr[r0:r1][~short])            # long rows: empty segments
+        width = -(-(c1 - c0) // nb)
+        for r in np.nonzero(short)[0][::37]:
+            for b in range(nb):
+                seg = gr.colidx[bp[b, r]:bp[b + 1, r]]
+                assert np.all((seg >= c0 + b * width) & (seg < c0 + (b + 1) * width))
+    with pytest.raises(ValueError):
+        block_plan_arrays(gr.rowptr, gr.colidx, 0, u, 0, u, 100)                # wrong column range

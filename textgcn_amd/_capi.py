@@ -19,11 +19,19 @@ class SplitPlanStruct(Structure):
                 ('long_chunk_ptr', c_void_p), ('workspace', c_void_p)]
 
 
+class BlockPlanStruct(Structure):
+    """mirror of tgcn_block_plan_t"""
+    _fields_ = [('n_blocks', c_int32), ('row_begin', c_int32), ('n_rows', c_int32), ('ld', c_int32), ('blkptr', c_void_p)]
+
+
 _SIGNATURES = {
     'tgcn_abi_version': (ctypes.c_int, []),
     'tgcn_last_error': (c_char_p, []),
     'tgcn_spmm_csr_f32': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p,
                                          c_void_p, c_void_p, c_float, POINTER(SplitPlanStruct), c_uint32, c_void_p]),
+    'tgcn_spmm_blocked_f32': (ctypes.c_int, [POINTER(BlockPlanStruct), c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
+                                             c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_float, POINTER(SplitPlanStruct),
+                                             c_void_p]),
     'tgcn_score_dense_f32': (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_int64,
                                             c_void_p]),
     'tgcn_mask_f32': (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),

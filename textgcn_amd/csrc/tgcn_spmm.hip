@@ -345,6 +345,29 @@ int launch_group(const SpmmArgs &a, int unroll, int grid, hipStream_t s)
 
 using namespace tgcn;
 
+int tgcn::launch_long_rows(const int *rowptr, const int *colidx, const float *vals, int n_rows, const float *X, int d, float *Y,
+                           const float *acc_in, float *acc_out, float acc_div, const tgcn_split_plan_t *plan, hipStream_t s)
+{
+    SpmmArgs a;
+    a.rowptr = rowptr, a.colidx = colidx, a.vals = vals, a.X = X, a.Y = Y;
+    a.acc_in = acc_in, a.acc_out = acc_out, a.acc_div = acc_div;
+    a.n_rows = n_rows, a.d = d, a.row_waves = 0;  // no row waves: every wave of the launch is a chunk wave
+    a.threshold = plan->threshold, a.n_chunks = plan->n_chunks;
+    a.chunk_beg = plan->chunk_beg, a.chunk_end = plan->chunk_end, a.ws = plan->workspace;
+    const int grid = (a.n_chunks + 3) / 4;
+    int rc = d == 64 ? launch_wave<1>(a, 0, grid, s) : d == 128 ? launch_wave<2>(a, 0, grid, s) : launch_wave<4>(a, 0, grid, s);
+    if (rc != TGCN_OK)
+        return rc;
+    const int rgrid = (plan->n_long + 3) / 4;
+    if (d == 64)
+        hipLaunchKernelGGL((k_spmm_long_reduce<1>), dim3(rgrid), dim3(256), 0, s, a, plan->long_rows, plan->long_chunk_ptr, plan->n_long);
+    else if (d == 128)
+        hipLaunchKernelGGL((k_spmm_long_reduce<2>), dim3(rgrid), dim3(256), 0, s, a, plan->long_rows, plan->long_chunk_ptr, plan->n_long);
+    else
+        hipLaunchKernelGGL((k_spmm_long_reduce<4>), dim3(rgrid), dim3(256), 0, s, a, plan->long_rows, plan->long_chunk_ptr, plan->n_long);
+    return check_launch("k_spmm_long_reduce");
+}
+
 extern "C" int tgcn_spmm_csr_f32(const int32_t *rowptr, const int32_t *colidx, const float *vals, int64_t n_rows,
                                  const float *X, int64_t n_src_rows, int32_t d, float *Y, const float *acc_in,
                                  float *acc_out, float acc_div, const tgcn_split_plan_t *plan, uint32_t flags,

@@ -159,6 +159,37 @@ def split_plan_arrays(rowptr, threshold):
     }
 
 
+def block_plan_arrays(rowptr, colidx, row_begin, row_end, col_lo, col_hi, block_width, long_threshold=None, min_segment=4):
+    """Host array of a tgcn_block_plan_t: rows [row_begin, row_end) of a (local) CSR whose entries lie in columns
+    [col_lo, col_hi), cut into column blocks of `block_width` columns.  Returns (blkptr int32 [(n_blocks+1), n_rows],
+    n_blocks).  Rows with more than `long_threshold` entries get empty segments (they go through the split plan).
+    The block count is capped so that a row's mean segment keeps at least `min_segment` entries."""
+    rowptr = np.asarray(rowptr, dtype=np.int64)
+    n_rows = int(row_end - row_begin)
+    a, b = int(rowptr[row_begin]), int(rowptr[row_end])
+    cols = np.asarray(colidx[a:b], dtype=np.int64)
+    if len(cols) and (cols.min() < col_lo or cols.max() >= col_hi):
+        raise ValueError('entries outside the declared column range')
+    n_blocks = max(1, -(-(col_hi - col_lo) // int(block_width)))
+    mean_deg = (b - a) / max(n_rows, 1)
+    n_blocks = int(max(1, min(n_blocks, mean_deg // min_segment if mean_deg >= min_segment else 1)))
+    width = -(-(col_hi - col_lo) // n_blocks)
+    lens = np.diff(rowptr[row_begin:row_end + 1])
+    rows = np.repeat(np.arange(n_rows, dtype=np.int64), lens)
+    span = np.int64(col_hi - col_lo + 1)
+    key = rows * span + (cols - col_lo)                      # ascending: CSR rows ascending, columns ascending inside
+    blkptr = np.empty((n_blocks + 1, n_rows), dtype=np.int64)
+    base = np.arange(n_rows, dtype=np.int64) * span
+    for blk in range(n_blocks + 1):
+        bound = min(blk * width, col_hi - col_lo)
+        blkptr[blk] = a + np.searchsorted(key, base + bound, side='left')
+    blkptr[n_blocks] = rowptr[row_begin + 1:row_end + 1]
+    if long_threshold:
+        is_long = lens > long_threshold
+        blkptr[:, is_long] = rowptr[row_begin:row_end][is_long]
+    return blkptr.astype(np.int32), n_blocks
+
+
 def train_mask_csr(train_u, train_i, n_users):
     """CSR over all users of their train items (ascending): the device form of
     base_model.py:257 `train_user_dict[batch_users].explode()`.  Returns (rowptr int64 [U+1], items int32)."""

@@ -10,15 +10,20 @@ import numpy as np
 import torch
 
 from . import _capi
-from .graph import NormGraph, split_plan_arrays
+from .graph import NormGraph, block_plan_arrays, split_plan_arrays
 
 DEFAULT_SPLIT_THRESHOLD = 1024
+DEFAULT_BLOCK_BYTES = 3 << 20   # of X per column block: fits an XCD's 4 MB L2 next to the streaming CSR traffic
 
 
 class DeviceCSR:
     """CSR of a contiguous block of rows of A on one device (+ optional long-row split plan)."""
 
-    def __init__(self, rowptr, colidx, vals, n_src_rows, device, split_threshold=None):
+    def __init__(self, rowptr, colidx, vals, n_src_rows, device, split_threshold=None, block_specs=None,
+                 block_bytes=DEFAULT_BLOCK_BYTES):
+        """block_specs: optional list of (row_begin, row_end, col_lo, col_hi) covering all rows once -- row ranges
+        whose entries fall in one column range (user rows x item columns, item rows x user columns).  Enables the
+        cache-blocked kernel (tgcn_spmm_blocked_f32) for widths 64/128/256."""
         rowptr = np.asarray(rowptr, dtype=np.int64)
         if rowptr[-1] >= np.iinfo(np.int32).max:
             raise ValueError('row block has >= 2^31 entries')
@@ -35,6 +40,11 @@ class DeviceCSR:
         if self._plan_host is not None:
             self._plan_dev = {k: torch.from_numpy(v).to(self.device) for k, v in self._plan_host.items()
                               if k != 'threshold'}
+        self._block_specs = block_specs
+        self._block_bytes = int(block_bytes)
+        self._split_threshold = split_threshold
+        self._host = (rowptr, colidx) if block_specs else None
+        self._block_plans = {}
 
     @property
     def n_chunks(self):
@@ -54,6 +64,25 @@ class DeviceCSR:
         return ctypes.byref(self._plan_struct[d][0])
 
 
+    def block_plans(self, d):
+        """(ctypes array of tgcn_block_plan_t, count) for width d, or (None, 0) when blocking is not configured."""
+        if not self._block_specs or d not in (64, 128, 256):
+            return None, 0
+        if d not in self._block_plans:
+            rowptr, colidx = self._host
+            width = max(1024, self._block_bytes // (4 * d))
+            structs, keep = [], []
+            for (r0, r1, c0, c1) in self._block_specs:
+                bp, nb = block_plan_arrays(rowptr, colidx, r0, r1, c0, c1, width, self._split_threshold)
+                t = torch.from_numpy(np.ascontiguousarray(bp)).to(self.device)
+                keep.append(t)
+                structs.append(_capi.BlockPlanStruct(nb, int(r0), int(r1 - r0), int(r1 - r0), t.data_ptr()))
+            arr = (_capi.BlockPlanStruct * len(structs))(*structs)
+            self._block_plans[d] = (arr, len(structs), keep)
+        arr, n, _ = self._block_plans[d]
+        return arr, n
+
+
 def _check_dense(t, name, device, rows=None, d=None):
     if not isinstance(t, torch.Tensor) or t.dtype != torch.float32:
         raise TypeError(f'{name} must be a float32 torch tensor')
@@ -66,7 +95,7 @@ def _check_dense(t, name, device, rows=None, d=None):
 
 
 def spmm(csr, x, y=None, acc_in=None, acc_out=None, acc_div=1.0, exact=False, variant=_capi.SPMM_AUTO, unroll=0,
-         vals=None):
+         vals=None, blocked=True):
     """One layer: y = A_block . x, optionally acc_out = (acc_in + y) / acc_div (see tgcn_spmm_csr_f32).
 
     x [n_src_rows, d]; y / acc_in / acc_out [n_rows, d] (y or acc_out may be None).  exact=True ignores the
@@ -87,6 +116,14 @@ def spmm(csr, x, y=None, acc_in=None, acc_out=None, acc_div=1.0, exact=False, va
         vals = csr.vals
     elif vals.dtype != torch.float32 or vals.numel() != csr.nnz or vals.device != dev or not vals.is_contiguous():
         raise ValueError('vals must be a contiguous float32 device tensor with one entry per stored element')
+    plans, n_plans = csr.block_plans(d) if (blocked and not exact and variant == _capi.SPMM_AUTO) else (None, 0)
+    if n_plans:
+        rc = _capi.lib().tgcn_spmm_blocked_f32(
+            plans, n_plans, _capi.ptr(csr.rowptr), _capi.ptr(csr.colidx), _capi.ptr(vals), csr.n_rows, _capi.ptr(x),
+            csr.n_src_rows, d, _capi.ptr(y), _capi.ptr(acc_in), _capi.ptr(acc_out), float(acc_div), plan,
+            _capi.current_stream(dev))
+        _capi.check(rc, 'tgcn_spmm_blocked_f32')
+        return y if y is not None else acc_out
     rc = _capi.lib().tgcn_spmm_csr_f32(
         _capi.ptr(csr.rowptr), _capi.ptr(csr.colidx), _capi.ptr(vals), csr.n_rows, _capi.ptr(x), csr.n_src_rows, d,
         _capi.ptr(y), _capi.ptr(acc_in), _capi.ptr(acc_out), float(acc_div), plan, (variant & 0xff) | (unroll << 8),
@@ -102,10 +139,14 @@ class Propagator:
     E(k+1) = A . E(k).  Buffers are allocated once per embedding width and reused.
     """
 
-    def __init__(self, graph: NormGraph, device, split_threshold=DEFAULT_SPLIT_THRESHOLD):
+    def __init__(self, graph: NormGraph, device, split_threshold=DEFAULT_SPLIT_THRESHOLD, block_bytes=DEFAULT_BLOCK_BYTES):
         self.graph = graph
         self.device = torch.device(device)
-        self.csr = DeviceCSR(graph.rowptr, graph.colidx, graph.vals, graph.n, self.device, split_threshold)
+        u, n = graph.n_users, graph.n
+        # A is bipartite: user rows hold item columns and vice versa
+        specs = [(0, u, u, n), (u, n, 0, u)] if block_bytes else None
+        self.csr = DeviceCSR(graph.rowptr, graph.colidx, graph.vals, graph.n, self.device, split_threshold,
+                             block_specs=specs, block_bytes=block_bytes or DEFAULT_BLOCK_BYTES)
         self._buf = {}
 
     def buffers(self, d):
@@ -115,7 +156,7 @@ class Propagator:
         return self._buf[d]
 
     def forward(self, e0, n_layers, single=False, exact=False, out=None, keep_layers=False, variant=_capi.SPMM_AUTO,
-                unroll=0, vals=None):
+                unroll=0, vals=None, blocked=True):
         n = self.graph.n
         _check_dense(e0, 'e0', self.device, n)
         d = e0.shape[1]
@@ -135,7 +176,7 @@ class Propagator:
                 y = ping if (k & 1) else pong
             if single:
                 spmm(self.csr, x, y=out if (last and not keep_layers) else y, exact=exact, variant=variant, unroll=unroll,
-                     vals=vals)
+                     vals=vals, blocked=blocked)
                 if last and keep_layers:
                     out.copy_(y)
             else:
@@ -143,7 +184,7 @@ class Propagator:
                 # the last layer's own Y is not needed (no store)
                 spmm(self.csr, x, y=None if (last and not keep_layers) else y, acc_in=e0 if k == 1 else acc,
                      acc_out=out if last else acc, acc_div=float(n_layers + 1) if last else 1.0, exact=exact,
-                     variant=variant, unroll=unroll, vals=vals)
+                     variant=variant, unroll=unroll, vals=vals, blocked=blocked)
             if keep_layers:
                 layers.append(y)
             x = y
