@@ -231,7 +231,7 @@ def test_blocked_kernel_bit_identical(cuda, oracle, d, block_bytes):
     ref = oracle.spmm_coo(idx, val, e0)
     short = gr.degrees() <= 200
     assert np.array_equal(bits(layers_b[1].cpu().numpy()[short]), bits(ref[short]))
-    assert normwise(layers_b[1].cpu().numpy(), ref) <= 1e-6
+    assert normwise(layers_b[1].cpu().numpy(), ref) <= 1e-5
 
 
 def test_blocked_kernel_without_split_plan_is_exact(cuda, oracle):

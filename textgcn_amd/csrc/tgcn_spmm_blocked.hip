@@ -14,6 +14,10 @@
 // No inter-workgroup synchronisation: workgroups start together and do statistically equal work per block;
 // drifting apart costs hit rate, never correctness.
 //
+// STATUS (round 1): correct and bit-identical, but NOT faster on MI355X -- config 2 runs 127 us (user rows, L2 hit
+// rate 70 %) + 297 us (item rows, Zipf lengths keep the groups out of step: hit rate 28 %) + 58 us (long rows) per
+// layer against 263 us for the plain kernel (profiles/r01_blocked_experiment.md).  Kept opt-in.
+//
 // Rows longer than the split threshold are not touched here (their block segments are empty in the plan); the
 // chunk waves + k_spmm_long_reduce of tgcn_spmm.hip handle them as before.
 #include <climits>
@@ -44,41 +48,9 @@ __device__ __forceinline__ void fma4(float4 &acc, float v, const float4 &x)
     acc.w = fmaf(v, x.w, acc.w);
 }
 
-// entries [beg, end) of one row, G lanes, float4 per lane; (c0, v0) = the already loaded first G entries
-template <int G, int UNROLL>
-__device__ __forceinline__ void segment(const BlockedArgs &a, const float *__restrict__ Xl, int beg, int end, int gl,
-                                        int c0, float v0, float4 &acc)
-{
-    constexpr int D = 4 * G;
-    int c = c0;
-    float v = v0;
-    for (int base = beg; base < end; base += G) {
-        const int n = min(G, end - base);
-        if (base != beg) {
-            c = 0, v = 0.0f;
-            if (gl < n) {
-                c = a.colidx[base + gl];
-                v = a.vals[base + gl];
-            }
-        }
-        for (int j = 0; j < n; j += UNROLL) {
-            float4 x[UNROLL];
-            float vv[UNROLL];
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                const int jj = min(j + u, n - 1);
-                const int cj = __shfl(c, jj, G);
-                vv[u] = __shfl(v, jj, G);
-                x[u] = *reinterpret_cast<const float4 *>(Xl + (size_t)cj * D);
-            }
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u)
-                if (j + u < n)
-                    fma4(acc, vv[u], x[u]);
-        }
-    }
-}
-
+// A group of G lanes owns NSET rows.  Inside one column block the NSET segments advance TOGETHER: every round
+// issues up to UNROLL row loads for each of them before any is consumed, so a group keeps NSET*UNROLL gathers
+// in flight instead of walking its segments one after the other (which left the kernel latency-bound).
 template <int G, int NSET, int UNROLL>
 __global__ __launch_bounds__(256) void k_spmm_blocked(const BlockedArgs a)
 {
@@ -91,54 +63,79 @@ __global__ __launch_bounds__(256) void k_spmm_blocked(const BlockedArgs a)
     const float *__restrict__ Xl = a.X + gl * 4;
 
     float4 acc[NSET];
-    int pb[NSET], pe[NSET];
+    int pos[NSET], pe[NSET];  // next entry / end of the current block's segment, per owned row
 #pragma unroll
     for (int s = 0; s < NSET; ++s) {
         acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
         const int lr = group + s * n_groups;
-        pb[s] = pe[s] = 0;
+        pos[s] = pe[s] = 0;
         if (lr < a.n_rows) {
-            pb[s] = a.blkptr[lr];
+            pos[s] = a.blkptr[lr];
             pe[s] = a.blkptr[a.ld + lr];
         }
     }
-    // first G entries of the first segment
-    int c_cur = 0;
-    float v_cur = 0.0f;
-    if (gl < pe[0] - pb[0]) {
-        c_cur = a.colidx[pb[0] + gl];
-        v_cur = a.vals[pb[0] + gl];
-    }
     for (int cb = 0; cb < a.n_blocks; ++cb) {
-        // segment bounds of the NEXT column block are fetched now, off the critical path
-        int nb[NSET], ne[NSET];
+        // bounds of the next block: loaded now, needed only after this block is done
+        int ne[NSET];
 #pragma unroll
         for (int s = 0; s < NSET; ++s) {
             const int lr = group + s * n_groups;
-            nb[s] = ne[s] = 0;
-            if (cb + 1 < a.n_blocks && lr < a.n_rows) {
-                nb[s] = pe[s];  // == blkptr[(cb+1)*ld + lr]
+            ne[s] = 0;
+            if (cb + 1 < a.n_blocks && lr < a.n_rows)
                 ne[s] = a.blkptr[(size_t)(cb + 2) * a.ld + lr];
-            }
         }
+        // (col, val) windows: lane gl of the group holds entry pos[s] + gl of segment s
+        int c[NSET], wbase[NSET];
+        float v[NSET];
 #pragma unroll
         for (int s = 0; s < NSET; ++s) {
-            // first entries of the next segment (next set of this block, or set 0 of the next block)
-            const int xb = s + 1 < NSET ? pb[s + 1] : nb[0];
-            const int xe = s + 1 < NSET ? pe[s + 1] : ne[0];
-            int c_nx = 0;
-            float v_nx = 0.0f;
-            if (gl < xe - xb) {
-                c_nx = a.colidx[xb + gl];
-                v_nx = a.vals[xb + gl];
+            wbase[s] = pos[s];
+            c[s] = 0, v[s] = 0.0f;
+            if (pos[s] + gl < pe[s]) {
+                c[s] = a.colidx[pos[s] + gl];
+                v[s] = a.vals[pos[s] + gl];
             }
-            segment<G, UNROLL>(a, Xl, pb[s], pe[s], gl, c_cur, v_cur, acc[s]);
-            c_cur = c_nx;
-            v_cur = v_nx;
+        }
+        bool any = false;
+#pragma unroll
+        for (int s = 0; s < NSET; ++s)
+            any |= pos[s] < pe[s];
+        while (any) {
+            float4 x[NSET][UNROLL];
+            float vv[NSET][UNROLL];
+#pragma unroll
+            for (int s = 0; s < NSET; ++s) {
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    const int e = min(pos[s] + u, pe[s] - 1);       // clamped: a finished segment re-reads a valid row
+                    const int j = max(e - wbase[s], 0);
+                    const int cj = __shfl(c[s], j, G);
+                    vv[s][u] = __shfl(v[s], j, G);
+                    x[s][u] = *reinterpret_cast<const float4 *>(Xl + (size_t)cj * D);
+                }
+            }
+            any = false;
+#pragma unroll
+            for (int s = 0; s < NSET; ++s) {
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u)
+                    if (pos[s] + u < pe[s])
+                        fma4(acc[s], vv[s][u], x[s][u]);
+                pos[s] = min(pos[s] + UNROLL, pe[s]);
+                if (pos[s] < pe[s] && pos[s] + UNROLL > wbase[s] + G) {   // window exhausted: slide it
+                    wbase[s] = pos[s];
+                    c[s] = 0, v[s] = 0.0f;
+                    if (pos[s] + gl < pe[s]) {
+                        c[s] = a.colidx[pos[s] + gl];
+                        v[s] = a.vals[pos[s] + gl];
+                    }
+                }
+                any |= pos[s] < pe[s];
+            }
         }
 #pragma unroll
         for (int s = 0; s < NSET; ++s)
-            pb[s] = nb[s], pe[s] = ne[s];
+            pos[s] = pe[s], pe[s] = ne[s];
     }
 #pragma unroll
     for (int s = 0; s < NSET; ++s) {
@@ -165,7 +162,7 @@ __global__ __launch_bounds__(256) void k_spmm_blocked(const BlockedArgs a)
 template <int G, int NSET>
 void launch_nset(const BlockedArgs &a, int grid, hipStream_t s)
 {
-    hipLaunchKernelGGL((k_spmm_blocked<G, NSET, 4>), dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((k_spmm_blocked<G, NSET, (NSET >= 4 ? 2 : 4)>), dim3(grid), dim3(256), 0, s, a);
 }
 
 template <int G>

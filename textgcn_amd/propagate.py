@@ -95,12 +95,14 @@ def _check_dense(t, name, device, rows=None, d=None):
 
 
 def spmm(csr, x, y=None, acc_in=None, acc_out=None, acc_div=1.0, exact=False, variant=_capi.SPMM_AUTO, unroll=0,
-         vals=None, blocked=True):
+         vals=None, blocked=False):
     """One layer: y = A_block . x, optionally acc_out = (acc_in + y) / acc_div (see tgcn_spmm_csr_f32).
 
     x [n_src_rows, d]; y / acc_in / acc_out [n_rows, d] (y or acc_out may be None).  exact=True ignores the
     long-row plan: every row is one sequential fmaf chain, bit-identical to the reference's CPU kernel.
-    vals: optional replacement of the stored values on the same structure (edge dropout, transposed values)."""
+    vals: optional replacement of the stored values on the same structure (edge dropout, transposed values).
+    blocked: opt into the cache-blocked kernel (tgcn_spmm_blocked_f32).  Bit-identical output; measured SLOWER than
+    the plain kernel on MI355X in round 1, so it is off by default."""
     dev = csr.device
     if dev.type != 'cuda':
         raise RuntimeError('textgcn_amd kernels run on a ROCm GPU only (device is %s)' % dev)
@@ -156,7 +158,7 @@ class Propagator:
         return self._buf[d]
 
     def forward(self, e0, n_layers, single=False, exact=False, out=None, keep_layers=False, variant=_capi.SPMM_AUTO,
-                unroll=0, vals=None, blocked=True):
+                unroll=0, vals=None, blocked=False):
         n = self.graph.n
         _check_dense(e0, 'e0', self.device, n)
         d = e0.shape[1]
