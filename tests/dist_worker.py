@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""One rank of a row-sharded propagation rehearsal (started by tests/test_dist_*.py, never by pytest directly).
+
+  --mode cpu : gloo on CPU tensors; the local SpMM is the CPU oracle (injected stand-in) -- exercises the
+               partitioning / padding / all-gather / layer-sum logic of textgcn_amd.dist without a GPU.
+  --mode gpu : every rank uses cuda:0 (one-GPU box) with the real HIP kernels; gloo staged through the host.
+Writes users_full / items_full of rank 0 (after gathering the user blocks) to --out.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def oracle_spmm(csr, x, y=None, acc_in=None, acc_out=None, acc_div=1.0, exact=False):
+    from oracle import lgcn_oracle as orc
+    out = orc.spmm_csr(csr.rowptr.numpy(), csr.colidx.numpy(), csr.vals.numpy(), x.numpy())
+    if y is not None:
+        y.copy_(torch.from_numpy(out))
+    if acc_out is not None:
+        t = (acc_in.numpy() + out).astype(np.float32)
+        if acc_div != 1.0:
+            t = (t / np.float32(acc_div)).astype(np.float32)
+        acc_out.copy_(torch.from_numpy(t))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--rank', type=int, required=True)
+    ap.add_argument('--world', type=int, required=True)
+    ap.add_argument('--port', type=int, required=True)
+    ap.add_argument('--mode', choices=['cpu', 'gpu'], required=True)
+    ap.add_argument('--out', required=True)
+    ap.add_argument('--n-users', type=int, default=203)
+    ap.add_argument('--n-items', type=int, default=97)
+    ap.add_argument('--nnz', type=int, default=2500)
+    ap.add_argument('--d', type=int, default=64)
+    ap.add_argument('--layers', type=int, default=3)
+    ap.add_argument('--single', action='store_true')
+    args = ap.parse_args()
+
+    from textgcn_amd import synth
+    from textgcn_amd.dist import ShardedPropagator
+    from textgcn_amd.graph import NormGraph
+
+    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{args.port}', rank=args.rank, world_size=args.world)
+    u, i = synth.interactions(args.n_users, args.n_items, args.nnz, seed=1)
+    g = NormGraph.from_pairs(u, i, args.n_users, args.n_items)
+    e0 = synth.embeddings(g.n, args.d, seed=2)
+    if args.mode == 'cpu':
+        sp = ShardedPropagator(g, args.rank, args.world, 'cpu', local_spmm=oracle_spmm, split_threshold=None)
+    else:
+        sp = ShardedPropagator(g, args.rank, args.world, 'cuda:0', split_threshold=64)
+    eu, ei = sp.local_e0(e0)
+    users_local, items_full = sp.forward(eu, ei, args.layers, single=args.single, exact=(args.mode == 'cpu'))
+    users_full = sp.gather_users(users_local)
+    if args.rank == 0:
+        np.savez(args.out, users=users_full[:args.n_users].cpu().numpy(), items=items_full[:args.n_items].cpu().numpy(),
+                 nnz_local=sp.nnz_local)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
