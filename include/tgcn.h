@@ -135,6 +135,21 @@ int tgcn_score_topk_f32(const float *U, const int64_t *user_ids, int32_t B, cons
                         float *out_val, int64_t *out_idx, void *workspace, int64_t workspace_bytes,
                         tgcn_stream_t stream);
 
+/* K11-K13: LTR text-feature head (config 5) folded into one GEMM of width K = tgcn_ltr_folded_width(d, t).
+ *   replaces get_user_vectors / get_item_vectors / get_features_batchwise + nn.Linear(5, 1)
+ *                                                                  TextGCN/ltr_models.py:95-146,181-204
+ *   score = w0 e_u.e_i + w1 r_u.r_i + w2 d_u.d_i + w3 r_u.d_i + w4 d_u.r_i + b
+ *         = [w0 e_u | w1 r_u + w4 d_u | w2 d_u + w3 r_u | b, 0..] . [e_i | r_i | d_i | 1, 0..]
+ * fold_users writes [B, K] rows for users emb_ids[b] (rows of users_emb) / text_ids[b] (rows of the two [U, t]
+ * text tables; either id array may be NULL: row b); pack_items writes [I, K].  `w5_host` is a HOST pointer to the
+ * five effective weights.  Score the folded operands with tgcn_score_dense_f32 / tgcn_score_topk_f32 (d = K). */
+int32_t tgcn_ltr_folded_width(int32_t d, int32_t t);
+int tgcn_ltr_fold_users_f32(const float *users_emb, const float *users_reviews, const float *users_desc,
+                            const int64_t *emb_ids, const int64_t *text_ids, int32_t B, int32_t d, int32_t t,
+                            const float *w5_host, float bias, float *out, tgcn_stream_t stream);
+int tgcn_ltr_pack_items_f32(const float *items_emb, const float *items_reviews, const float *items_desc, int32_t I,
+                            int32_t d, int32_t t, float *out, tgcn_stream_t stream);
+
 /* K9: out[r] = <U[users[r], :], V[items[r], :]>   (users/items may be NULL: row r itself).
  *   replaces torch.sum(users_emb * items_emb, dim=1)               TextGCN/base_model.py:171
  *   and the gathers at base_model.py:189-193 */

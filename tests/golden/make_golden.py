@@ -380,12 +380,72 @@ def g6_builder(work):
     save('g6_builder.npz', **out)
 
 
+# --------------------------------------------------------------------------- G4: LTRLinear on frozen LightGCN
+def g4_ltr(work, data):
+    """ltr_linear on the synth-60x40 data (needs reviews_text.tsv + cached 384-d tensors).
+    The text tensors are synthetic (exact_embedding), written where the reference's cache lookup finds them
+    (reviews_models.py:37-53, kg_models.py:24-31), so no SBERT model is involved."""
+    import pandas as pd
+    train = pd.read_table(os.path.join(data, 'train.tsv'), dtype=str)
+    rng = np.random.default_rng(4)
+    rev = train.copy()
+    rev['review'] = [f'review {k}' for k in range(len(rev))]
+    rev['time'] = rng.integers(0, 1000, size=len(rev))
+    rev.to_csv(os.path.join(data, 'reviews_text.tsv'), sep='\t', index=False)
+    emb_dir = os.path.join(data, 'embeddings')
+    os.makedirs(emb_dir, exist_ok=True)
+    t = 384
+    torch.save(torch.from_numpy(exact_embedding(len(rev), t, 41) * 8), os.path.join(emb_dir, 'item_full_reviews_loss_repr_all-MiniLM-L6-v2_0-seed.torch'))
+    n_items = train.asin.nunique()
+    torch.save(torch.from_numpy(exact_embedding(n_items, t, 42) * 8), os.path.join(emb_dir, 'item_kg_repr_all-MiniLM-L6-v2_0-seed.torch'))
+    # base checkpoint with known weights
+    args = run_args(['--model', 'lgcn', '--no_train', '-k', '5', '10', '--batch_size', '32'], data, work)
+    ds0 = TextGCN.BaseDataset(args)
+    base = TextGCN.BaseModel(args, ds0)
+    set_weights(base, exact_embedding(ds0.n_users, 64, 11), exact_embedding(ds0.n_items, 64, 12))
+    ckpt = os.path.join(work, 'base.pkl')
+    torch.save(base.state_dict(), ckpt)
+    args = run_args(['--model', 'ltr_linear', '--no_train', '-k', '5', '10', '--batch_size', '32', '--load_base', ckpt, '--freeze'], data, work)
+    ds = TextGCN.LTRDataset(args)
+    model = TextGCN.LTRLinear(args, ds)
+    with torch.no_grad():
+        model.layers[0].weight.copy_(torch.tensor([[0.75, -0.5, 0.25, 0.125, -0.375]]))
+        model.layers[0].bias.copy_(torch.tensor([0.0625]))
+    out = {'n_users': np.int64(ds.n_users), 'n_items': np.int64(ds.n_items), 't': np.int64(t),
+           'items_as_desc': ds.items_as_desc.numpy(), 'items_as_avg_reviews': ds.items_as_avg_reviews.numpy(),
+           'users_as_avg_reviews': ds.users_as_avg_reviews.numpy(), 'users_as_avg_desc': ds.users_as_avg_desc.numpy(),
+           'w': model.layers[0].weight.detach().numpy().copy(), 'b': model.layers[0].bias.detach().numpy().copy(),
+           'state_keys': np.array(sorted(model.state_dict().keys()))}
+    with torch.no_grad():
+        ue, ie = model.representation
+        out['users_emb'], out['items_emb'] = ue.numpy().copy(), ie.numpy().copy()
+        users = np.arange(ds.n_users)
+        u_vecs = model.get_user_vectors(ue[users], users)
+        i_vecs = model.get_item_vectors(ie, model.all_items)
+        out['features'] = model.get_features_batchwise(u_vecs, i_vecs).numpy().copy()
+        out['scores'] = model.score_batchwise(ue[users], ie, users).numpy().copy()
+        pairs_u = rng.integers(0, ds.n_users, 200)
+        pairs_i = rng.integers(0, ds.n_items, 200)
+        out['pairs_u'], out['pairs_i'] = pairs_u, pairs_i
+        out['pair_scores'] = model.score_pairwise(ue[pairs_u], ie[pairs_i], torch.from_numpy(pairs_u), torch.from_numpy(pairs_i)).numpy().copy()
+        pred, sc = model.predict(users, with_scores=True)
+        out['topk_idx'], out['topk_val'] = np.asarray(pred, dtype=np.int64), np.asarray(sc, dtype=np.float32)
+    res = model.evaluate()
+    for m, v in res.items():
+        out[f'metric_{m}'] = np.asarray(v, dtype=np.float64)
+    b = dataset_bundle(ds)
+    for k in ('train_u', 'train_i', 'test_u', 'test_i'):
+        out[k] = b[k]
+    save('g4_ltr.npz', **out)
+
+
 def main():
     work = tempfile.mkdtemp(prefix='tgcn_golden_')
     try:
         g1_dummy(work)
         data60 = g2_synth(work)
         g3_dropout(work, data60)
+        g4_ltr(work, data60)
         g5_medium(work)
         g6_builder(work)
     finally:

@@ -1,0 +1,103 @@
+"""ltr_linear (BASELINE config 5): the oracle's LTR restatement against the reference's own outputs (CPU), and
+the folded-GEMM HIP path against both (GPU)."""
+import types
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+from conftest import bits, normwise
+
+
+def test_oracle_ltr_matches_reference(golden, oracle):
+    g = golden('g4_ltr')
+    n_u = int(g['n_users'])
+    users = np.arange(n_u)
+    s = oracle.ltr_score(g['users_emb'], g['users_as_avg_reviews'][users], g['users_as_avg_desc'][users], g['items_emb'],
+                         g['items_as_avg_reviews'], g['items_as_desc'], g['w'], float(g['b'][0]))
+    assert normwise(s, g['scores']) <= 1e-6          # BLAS / addmv order unspecified -> normwise
+    f0 = oracle.score_dense(g['users_emb'], g['items_emb'])
+    assert normwise(f0, g['features'][:, :, 0]) <= 1e-6
+    f3 = oracle.score_dense(g['users_as_avg_reviews'], g['items_as_desc'])
+    assert normwise(f3, g['features'][:, :, 3]) <= 1e-6
+    p = oracle.ltr_pairwise(g['users_emb'][g['pairs_u']], g['users_as_avg_reviews'][g['pairs_u']], g['users_as_avg_desc'][g['pairs_u']],
+                            g['items_emb'][g['pairs_i']], g['items_as_avg_reviews'][g['pairs_i']], g['items_as_desc'][g['pairs_i']],
+                            g['w'], float(g['b'][0]))
+    assert normwise(p, g['pair_scores'].reshape(-1)) <= 1e-6
+    assert list(g['state_keys']) == ['embedding_item.weight', 'embedding_user.weight', 'layers.0.bias', 'layers.0.weight']
+
+
+def _dataset(g):
+    n_u, n_i = int(g['n_users']), int(g['n_items'])
+    from textgcn_amd.graph import NormGraph
+    train = pd.DataFrame({'user_id': g['train_u'], 'asin': g['train_i']})
+    test = pd.DataFrame({'user_id': g['test_u'], 'asin': g['test_i']})
+    return types.SimpleNamespace(
+        n_users=n_u, n_items=n_i, graph=NormGraph.from_pairs(g['train_u'], g['train_i'], n_u, n_i), norm_matrix=None,
+        true_test_lil=test.groupby('user_id')['asin'].aggregate(list).values.tolist(),
+        train_user_dict=train.groupby('user_id')['asin'].aggregate(list), test_df=test,
+        user_mapping=pd.DataFrame({'remap_id': range(n_u), 'org_id': range(n_u)}),
+        item_mapping=pd.DataFrame({'remap_id': range(n_i), 'org_id': range(n_i)}), all_items=range(n_i),
+        items_as_desc=torch.from_numpy(g['items_as_desc']), items_as_avg_reviews=torch.from_numpy(g['items_as_avg_reviews']),
+        users_as_avg_reviews=torch.from_numpy(g['users_as_avg_reviews']), users_as_avg_desc=torch.from_numpy(g['users_as_avg_desc']))
+
+
+@pytest.mark.gpu
+def test_hip_ltr_matches_reference(golden, cuda, oracle, tmp_path):
+    from golden_inputs import exact_embedding
+    from textgcn_amd.ltr import LTRLinear
+    g = golden('g4_ltr')
+    n_u, n_i = int(g['n_users']), int(g['n_items'])
+    p = types.SimpleNamespace(k=[5, 10], emb_size=64, n_layers=3, device='cuda:0', load=None, load_base=None, freeze=True,
+                              batch_size=32, quiet=True, exact=True, ltr_layers=[], save_path=str(tmp_path))
+    m = LTRLinear(p, _dataset(g))
+    with torch.no_grad():
+        m.embedding_user.weight.copy_(torch.from_numpy(exact_embedding(n_u, 64, 11)))
+        m.embedding_item.weight.copy_(torch.from_numpy(exact_embedding(n_i, 64, 12)))
+        m.layers[0].weight.copy_(torch.from_numpy(g['w']))
+        m.layers[0].bias.copy_(torch.from_numpy(g['b']))
+    assert sorted(m.state_dict().keys()) == list(g['state_keys'])
+    assert not m.embedding_user.weight.requires_grad
+    with torch.no_grad():
+        ue, ie = m.representation
+        assert np.array_equal(bits(ue.cpu().numpy()), bits(g['users_emb']))
+        users = torch.arange(n_u, device=cuda)
+        s = m.score_batchwise(ue[users], ie, users)
+        assert normwise(s.cpu().numpy(), g['scores']) <= 1e-5                # fp32 bar of the north star is 1e-4
+        pu, pi = torch.from_numpy(g['pairs_u']).to(cuda), torch.from_numpy(g['pairs_i']).to(cuda)
+        ps = m.score_pairwise(ue[pu], ie[pi], pu, pi)
+        assert ps.shape == (200, 1) and normwise(ps.cpu().numpy(), g['pair_scores']) <= 1e-5
+    pred, sc = m.predict(np.arange(n_u), with_scores=True)
+    pred, sc = np.asarray(pred), np.asarray(sc, dtype=np.float32)
+    # ranked top-10 identical wherever the reference's adjacent scores differ by more than the fp32 noise
+    ref_i, ref_v = g['topk_idx'], g['topk_val']
+    gaps_ok = np.abs(np.diff(ref_v, axis=1)) > 2e-4
+    row_ok = gaps_ok.all(axis=1)
+    assert row_ok.mean() > 0.8
+    assert np.array_equal(pred[row_ok], ref_i[row_ok])
+    assert np.abs(sc - ref_v).max() <= 1.01e-4                                 # both rounded to 4 decimals
+    res = m.evaluate()
+    for met in ('recall', 'precision', 'hit', 'ndcg', 'f1'):
+        assert np.allclose(res[met], g[f'metric_{met}'], atol=0.02), met
+
+
+@pytest.mark.gpu
+def test_hip_ltr_hidden_layers_collapse_to_affine(golden, cuda, tmp_path):
+    """--ltr_layers 4 3: still one affine map (no activation in the reference's Sequential)."""
+    from textgcn_amd.ltr import LTRLinear
+    g = golden('g4_ltr')
+    p = types.SimpleNamespace(k=[5], emb_size=64, n_layers=2, device='cuda:0', load=None, load_base=None, freeze=True,
+                              batch_size=64, quiet=True, ltr_layers=[4, 3], save_path=str(tmp_path))
+    m = LTRLinear(p, _dataset(g))
+    with torch.no_grad():
+        ue, ie = m.representation
+        users = torch.arange(int(g['n_users']), device=cuda)
+        s = m.score_batchwise(ue[users], ie, users)
+        # torch restatement of the reference's formula with the full layer stack
+        uv = {'emb': ue, 'reviews': m.users_as_avg_reviews, 'desc': m.users_as_avg_desc}
+        iv = {'emb': ie, 'reviews': m.items_as_avg_reviews, 'desc': m.items_as_desc}
+        feats = torch.stack([uv['emb'] @ iv['emb'].T, uv['reviews'] @ iv['reviews'].T, uv['desc'] @ iv['desc'].T,
+                             uv['reviews'] @ iv['desc'].T, uv['desc'] @ iv['reviews'].T], dim=-1)
+        ref = m.layers(feats).squeeze(-1)
+    assert normwise(s.cpu().numpy(), ref.cpu().numpy()) <= 1e-5

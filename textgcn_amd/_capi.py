@@ -39,6 +39,10 @@ _SIGNATURES = {
     'tgcn_score_topk_workspace_bytes': (c_int64, [c_int32, c_int32, c_int32, c_int32]),
     'tgcn_score_topk_f32': (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int32,
                                            c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    'tgcn_ltr_folded_width': (c_int32, [c_int32, c_int32]),
+    'tgcn_ltr_fold_users_f32': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
+                                               POINTER(c_float), c_float, c_void_p, c_void_p]),
+    'tgcn_ltr_pack_items_f32': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     'tgcn_score_pairwise_f32': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p,
                                                c_void_p]),
 }

@@ -1,0 +1,97 @@
+// K11-K13: the LTR text-feature head folded into ONE scoring GEMM.
+//
+// Replaces LTRBase.get_user_vectors / get_item_vectors / get_features_batchwise and LTRLinear's nn.Linear over
+// the five features (TextGCN/ltr_models.py:95-146,181-204):
+//   f = [e_u.e_i, r_u.r_i, d_u.d_i, r_u.d_i, d_u.r_i],  s = sum_j w_j f_j + b
+//     = [ w0 e_u | w1 r_u + w4 d_u | w2 d_u + w3 r_u | b ] . [ e_i | r_i | d_i | 1 ]          
+// so the 5 GEMMs + the 2.46 GB [B, I, 5] concat + the strided Linear become a K = d + 2t (+pad) GEMM that the
+// ordinary scoring kernels run (tgcn_score_dense_f32 / tgcn_score_topk_f32).  These two kernels build the folded
+// operands; both are bandwidth-trivial (B x K and I x K floats).
+#include "tgcn_internal.h"
+
+namespace tgcn {
+namespace {
+
+// Ua[b, :] = [ w0 e | w1 r + w4 dsc | w2 dsc + w3 r | bias, 0... ]   (row of user user_ids[b]); K_pad columns
+__global__ void k_ltr_fold_users(const float *__restrict__ e, const float *__restrict__ r, const float *__restrict__ dsc,
+                                 const int64_t *__restrict__ emb_ids, const int64_t *__restrict__ text_ids, int B, int d, int t,
+                                 int k_pad, float w0, float w1, float w2, float w3, float w4, float bias, float *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * k_pad)
+        return;
+    const int b = (int)(i / k_pad), k = (int)(i % k_pad);
+    const int64_t ue = emb_ids ? emb_ids[b] : b;
+    const int64_t ut = text_ids ? text_ids[b] : b;
+    float v = 0.0f;
+    if (k < d)
+        v = w0 * e[ue * d + k];
+    else if (k < d + t)
+        v = fmaf(w4, dsc[ut * t + (k - d)], w1 * r[ut * t + (k - d)]);
+    else if (k < d + 2 * t)
+        v = fmaf(w3, r[ut * t + (k - d - t)], w2 * dsc[ut * t + (k - d - t)]);
+    else if (k == d + 2 * t)
+        v = bias;
+    out[i] = v;
+}
+
+// Ia[i, :] = [ e_i | r_i | d_i | 1, 0... ]
+__global__ void k_ltr_pack_items(const float *__restrict__ e, const float *__restrict__ r, const float *__restrict__ dsc, int I,
+                                 int d, int t, int k_pad, float *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)I * k_pad)
+        return;
+    const int64_t it = i / k_pad;
+    const int k = (int)(i % k_pad);
+    float v = 0.0f;
+    if (k < d)
+        v = e[it * d + k];
+    else if (k < d + t)
+        v = r[it * t + (k - d)];
+    else if (k < d + 2 * t)
+        v = dsc[it * t + (k - d - t)];
+    else if (k == d + 2 * t)
+        v = 1.0f;
+    out[i] = v;
+}
+
+}  // namespace
+}  // namespace tgcn
+
+using namespace tgcn;
+
+extern "C" int32_t tgcn_ltr_folded_width(int32_t d, int32_t t)
+{
+    return ((d + 2 * t + 1 + 63) / 64) * 64;  // multiple of 64: the scoring kernels' full-K fast path
+}
+
+extern "C" int tgcn_ltr_fold_users_f32(const float *users_emb, const float *users_reviews, const float *users_desc,
+                                       const int64_t *emb_ids, const int64_t *text_ids, int32_t B, int32_t d, int32_t t,
+                                       const float *w5_host, float bias, float *out, tgcn_stream_t stream)
+{
+    TGCN_REQUIRE(B >= 0 && d > 0 && t > 0, "bad sizes");
+    if (B == 0)
+        return TGCN_OK;
+    TGCN_REQUIRE(users_emb && users_reviews && users_desc && w5_host && out, "NULL pointer");
+    const int k_pad = tgcn_ltr_folded_width(d, t);
+    const int64_t n = (int64_t)B * k_pad;
+    hipLaunchKernelGGL(k_ltr_fold_users, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       users_emb, users_reviews, users_desc, emb_ids, text_ids, B, d, t, k_pad, w5_host[0], w5_host[1], w5_host[2],
+                       w5_host[3], w5_host[4], bias, out);
+    return check_launch("k_ltr_fold_users");
+}
+
+extern "C" int tgcn_ltr_pack_items_f32(const float *items_emb, const float *items_reviews, const float *items_desc, int32_t I,
+                                       int32_t d, int32_t t, float *out, tgcn_stream_t stream)
+{
+    TGCN_REQUIRE(I >= 0 && d > 0 && t > 0, "bad sizes");
+    if (I == 0)
+        return TGCN_OK;
+    TGCN_REQUIRE(items_emb && items_reviews && items_desc && out, "NULL pointer");
+    const int k_pad = tgcn_ltr_folded_width(d, t);
+    const int64_t n = (int64_t)I * k_pad;
+    hipLaunchKernelGGL(k_ltr_pack_items, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       items_emb, items_reviews, items_desc, I, d, t, k_pad, out);
+    return check_launch("k_ltr_pack_items");
+}

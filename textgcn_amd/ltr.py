@@ -1,0 +1,181 @@
+"""ltr_linear on the HIP path: a linear head over five dot-product features of frozen LightGCN embeddings and
+384-d text vectors (BASELINE config 5).
+
+Drop-in for TextGCN/ltr_models.py `LTRLinear` (member names, rebinding order and state_dict keys kept).  The
+reference evaluates 5 GEMMs, concatenates a [B, I, 5] tensor and applies nn.Linear over its last dimension
+(ltr_models.py:131-146,200-204); the layers carry no activation (ltr_models.py:186-190), so any depth is one affine
+map and the whole batchwise score is ONE GEMM of width d + 2t + 1: tgcn_ltr_fold_users_f32 /
+tgcn_ltr_pack_items_f32 build its operands, the ordinary scoring kernels run it.
+"""
+import ctypes
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _capi, scoring
+from .interactions import InteractionData
+from .model import LightGCN
+
+FEATURE_NAMES = ['lightgcn score', 'reviews', 'desc', 'reviews-description', 'description-reviews']   # ltr_models.py:71-77
+
+
+class LTRData(InteractionData):
+    """InteractionData + the four text tables LTRBase reads from its dataset (ltr_models.py:49-55).
+
+    The reference derives them with SBERT + pandas (reviews_models.py, kg_models.py, ltr_models.py:19-35) -- one-off
+    host preprocessing that is out of this path's scope -- so they are taken as given: tensors passed in, or a
+    `ltr_tables.pt` dict in the data folder with keys items_as_desc, items_as_avg_reviews [I, t],
+    users_as_avg_reviews, users_as_avg_desc [U, t]."""
+    TABLES = ('items_as_desc', 'items_as_avg_reviews', 'users_as_avg_reviews', 'users_as_avg_desc')
+
+    def __init__(self, params=None, tables=None, **kw):
+        super().__init__(params, **kw)
+        if tables is None:
+            import os
+            path = os.path.join(self.path, 'ltr_tables.pt')
+            if not os.path.exists(path):
+                raise FileNotFoundError(f'{path}: LTRData needs the four precomputed text tables {self.TABLES}')
+            tables = torch.load(path, map_location='cpu')
+        for name in self.TABLES:
+            t = torch.as_tensor(tables[name], dtype=torch.float32)
+            want = self.n_items if name.startswith('items') else self.n_users
+            if t.dim() != 2 or t.shape[0] != want:
+                raise ValueError(f'{name} must be [{want}, t], got {tuple(t.shape)}')
+            setattr(self, name, t)
+
+
+class LTRLinear(LightGCN):
+    """reference: TextGCN/ltr_models.py:38-210 (LTRBase + LTRLinear)."""
+
+    def __init__(self, params, dataset):
+        super().__init__(params, dataset)
+        # the reference rebinds on the INSTANCE after construction so that the base model loaded inside
+        # __init__ is evaluated with the plain LightGCN scoring (ltr_models.py:175-179)
+        self.evaluate = self.evaluate_ltr
+        self.score_pairwise = self.score_pairwise_ltr
+        self.score_batchwise = self.score_batchwise_ltr
+
+    def _copy_params(self, params):
+        super()._copy_params(params)
+        self.load_base = getattr(params, 'load_base', None)
+        self.freeze = getattr(params, 'freeze', False)
+        self._ltr_layers = list(getattr(params, 'ltr_layers', []) or [])
+
+    def _copy_dataset_params(self, dataset):
+        super()._copy_dataset_params(dataset)
+        to = lambda t: torch.as_tensor(t, dtype=torch.float32).to(self.device).contiguous()  # noqa: E731
+        self.items_as_avg_reviews = to(dataset.items_as_avg_reviews)
+        self.users_as_avg_reviews = to(dataset.users_as_avg_reviews)
+        self.users_as_avg_desc = to(dataset.users_as_avg_desc)
+        self.items_as_desc = to(dataset.items_as_desc)
+        self.all_items = dataset.all_items
+        self.text_dim = self.items_as_desc.shape[1]
+
+    def _init_embeddings(self, emb_size):
+        super()._init_embeddings(emb_size)
+        if self.freeze:   # ltr_models.py:57-61
+            self.embedding_user.requires_grad_(False)
+            self.embedding_item.requires_grad_(False)
+
+    def _add_vars(self, params):
+        super()._add_vars(params)
+        if self.load_base:   # ltr_models.py:66-68: before the scoring functions are rebound
+            self.load_model(self.load_base)
+        self.feature_names = list(FEATURE_NAMES)
+        self._setup_layers(params)
+        self._packed = None
+
+    def _setup_layers(self, params):
+        sizes = [len(self.feature_names)] + self._ltr_layers + [1]   # ltr_models.py:186-190
+        self.layers = nn.Sequential(*[nn.Linear(i, j) for i, j in zip(sizes, sizes[1:])]).to(self.device)
+
+    # ------------------------------------------------------------------ the affine map the layers amount to
+    def effective_weights(self):
+        """(w [5], b) with layers(f) == f . w + b.  Composes the activation-free Linear stack exactly as the
+        forward pass would (W_n ... W_1, biases pushed through)."""
+        w = None
+        b = None
+        for lin in self.layers:
+            wt, bs = lin.weight.detach().double(), lin.bias.detach().double()
+            if w is None:
+                w, b = wt, bs
+            else:
+                w, b = wt @ w, wt @ b + bs
+        return w.reshape(-1).float().cpu().numpy(), float(b.reshape(-1)[0])
+
+    # ------------------------------------------------------------------ folded operands
+    def _k(self):
+        return _capi.lib().tgcn_ltr_folded_width(self.emb_size, self.text_dim)
+
+    def _fold_users(self, users_emb, emb_ids, text_ids):
+        w, b = self.effective_weights()
+        n = emb_ids.numel() if emb_ids is not None else users_emb.shape[0]
+        out = torch.empty((n, self._k()), dtype=torch.float32, device=self.device)
+        w5 = (ctypes.c_float * 5)(*[float(x) for x in w])
+        rc = _capi.lib().tgcn_ltr_fold_users_f32(_capi.ptr(users_emb), _capi.ptr(self.users_as_avg_reviews),
+                                                 _capi.ptr(self.users_as_avg_desc), _capi.ptr(emb_ids), _capi.ptr(text_ids), n,
+                                                 self.emb_size, self.text_dim, w5, b, _capi.ptr(out), _capi.current_stream(self.device))
+        _capi.check(rc, 'tgcn_ltr_fold_users_f32')
+        return out
+
+    def _pack_items(self, items_emb):
+        key = (items_emb.data_ptr(), items_emb._version)
+        if self._packed is None or self._packed[0] != key:
+            out = torch.empty((self.n_items, self._k()), dtype=torch.float32, device=self.device)
+            rc = _capi.lib().tgcn_ltr_pack_items_f32(_capi.ptr(items_emb), _capi.ptr(self.items_as_avg_reviews),
+                                                     _capi.ptr(self.items_as_desc), self.n_items, self.emb_size, self.text_dim,
+                                                     _capi.ptr(out), _capi.current_stream(self.device))
+            _capi.check(rc, 'tgcn_ltr_pack_items_f32')
+            self._packed = (key, out)
+        return self._packed[1]
+
+    # ------------------------------------------------------------------ scoring (ltr_models.py:200-210)
+    def score_batchwise_ltr(self, users_emb, items_emb, users):
+        """[B, I] scores.  users_emb are the already gathered rows (reference calling convention)."""
+        users = torch.as_tensor(users, dtype=torch.int64, device=self.device).contiguous()
+        ua = self._fold_users(users_emb.contiguous(), None, users)
+        return scoring.score_dense(ua, self._pack_items(items_emb.contiguous()))
+
+    def score_pairwise_ltr(self, users_emb, items_emb, users, items):
+        """[n, 1] scores of gathered (user, item) rows -- small, differentiable torch ops (training batches)."""
+        users = torch.as_tensor(users, dtype=torch.int64, device=self.device)
+        items = torch.as_tensor(items, dtype=torch.int64, device=self.device)
+        ru, du = self.users_as_avg_reviews[users], self.users_as_avg_desc[users]
+        ri, di = self.items_as_avg_reviews[items], self.items_as_desc[items]
+        dot = lambda a, c: (a * c).sum(dim=1, keepdim=True)  # noqa: E731
+        feats = torch.cat([dot(users_emb, items_emb), dot(ru, ri), dot(du, di), dot(ru, di), dot(du, ri)], dim=1)   # :148-166
+        return self.layers(feats)
+
+    def evaluate_ltr(self, *args, **kwargs):
+        if len(self.layers) == 1:   # ltr_models.py:192-198
+            self.logger.info('Feature weights from the top layer:')
+            for f, w in zip(self.feature_names, self.layers[0].weight.tolist()[0]):
+                self.logger.info(f'{f:<20} {w:.4}')
+        return LightGCN.evaluate(self, *args, **kwargs)
+
+    @torch.no_grad()
+    def predict(self, users, save: bool = False, with_scores: bool = False):
+        self._packed = None   # item operand is rebuilt once per predict call
+        self.training = False
+        users_np = np.asarray(list(users) if not isinstance(users, np.ndarray) else users, dtype=np.int64)
+        if 'score_batchwise' not in self.__dict__:   # still inside __init__ (base model evaluation)
+            return LightGCN.predict(self, users_np, save, with_scores)
+        kmax = max(self.k)
+        users_emb, items_emb = self.representation
+        users_emb, items_emb = users_emb.contiguous(), items_emb.contiguous()
+        ia = self._pack_items(items_emb)
+        y_val, y_idx = [], []
+        for j in range(0, len(users_np), self.batch_size):
+            batch = users_np[j:j + self.batch_size]
+            ids = torch.from_numpy(batch).to(self.device)
+            ua = self._fold_users(users_emb, ids, ids)
+            rp, it = self._batch_mask(batch)
+            v, i = scoring.score_topk(ua, ia, kmax, mask_rowptr=rp, mask_items=it, round4=True)
+            y_val.append(v)
+            y_idx.append(i)
+        predictions = torch.cat(y_idx).tolist() if y_idx else []
+        scores = torch.cat(y_val).tolist() if y_val else []
+        if save:
+            self._save_predictions(users_np, predictions, scores)
+        return (predictions, scores) if with_scores else predictions
