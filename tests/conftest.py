@@ -8,6 +8,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+if GOLDEN not in sys.path:
+    sys.path.insert(0, GOLDEN)   # golden_inputs.py (recomputable inputs of the fixtures)
 
 
 def pytest_configure(config):
