@@ -105,6 +105,7 @@ def main():
     ap.add_argument('--exact', action='store_true', help='no long-row split: bit-identical to the CPU reference')
     ap.add_argument('--split-threshold', type=int, default=None)
     ap.add_argument('--score-batches', type=int, default=20)
+    ap.add_argument('--score-batch-size', type=int, default=2048, help='users per scoring call (reference batch_size = 2048)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-scoring', action='store_true')
     args = ap.parse_args()
@@ -207,7 +208,7 @@ def main():
     # ---------------- second metric: scored pairs/s (rank 0's users; every rank scores its own users)
     if not args.no_scoring:
         k_top = 40
-        bsz = 2048
+        bsz = args.score_batch_size
         if world == 1:
             ue, ie = out[:n_u], out[n_u:]
             users_all = np.arange(n_u)
@@ -250,7 +251,7 @@ def main():
             ts, pairs = float(mx[0].item()), float(tt[1].item())
         flops = 2.0 * d * pairs
         result['scoring'] = {
-            'metric': 'scored user-item pairs/sec (scores + train mask + top-40 fused, B=2048 per call)', 'value': pairs / ts,
+            'metric': f'scored user-item pairs/sec (scores + train mask + top-40 fused, B={bsz} per call)', 'value': pairs / ts,
             'unit': 'pairs/s', 'batches': n_batches, 'ms_per_batch': ts / n_batches * 1e3,
             'roofline': {'bound': 'mfma', 'achieved': round(flops / ts / 1e12 / max(world, 1), 2), 'peak': MFMA_F32_PEAK_TF,
                          'unit': 'TFLOP/s', 'frac': round(flops / ts / 1e12 / max(world, 1) / MFMA_F32_PEAK_TF, 4), 'traffic': None},

@@ -214,6 +214,39 @@ __global__ __launch_bounds__(256) void k_topk(const float *__restrict__ S, int64
     }
 }
 
+// narrow rows (I <= 4096): one wave per row, no LDS merge
+__global__ __launch_bounds__(256) void k_topk_wave(const float *__restrict__ S, int64_t lds, int B, int I, int k, int do_round,
+                                                   float *__restrict__ out_val, int64_t *__restrict__ out_idx)
+{
+    const int b = uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (b >= B)
+        return;
+    const int lane = lane_id();
+    const float *__restrict__ row = S + (size_t)b * lds;
+    TopList e{-INFINITY, INT_MAX};
+    const bool vec_ok = (lds & 3) == 0 && ((size_t)row & 15) == 0;
+    for (int base = 0; base < I; base += kWave * 4) {
+        const int i0 = base + lane * 4;
+        float x[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        if (vec_ok && i0 + 3 < I) {
+            const float4 t = *reinterpret_cast<const float4 *>(row + i0);
+            x[0] = t.x, x[1] = t.y, x[2] = t.z, x[3] = t.w;
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + u < I)
+                    x[u] = row[i0 + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            list_offer(e, x[u], i0 + u, i0 + u < I, k, lane);
+    }
+    if (lane < k) {
+        out_val[(size_t)b * k + lane] = do_round ? round4(e.v) : e.v;
+        out_idx[(size_t)b * k + lane] = e.i;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // pairwise dots: one lane per pair, k-ordered chain (tiny workloads: a training batch)
 __global__ __launch_bounds__(256) void k_score_pairwise(const float *__restrict__ U, const int64_t *__restrict__ users,
@@ -252,7 +285,10 @@ int tgcn::launch_score_dense(const float *U, const int64_t *user_ids, int B, con
 int tgcn::launch_topk(const float *S, int64_t lds, int B, int I, int k, int do_round, float *out_val, int64_t *out_idx,
                       hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_topk, dim3(B), dim3(256), 0, stream, S, lds, B, I, k, do_round, out_val, out_idx);
+    if (I <= 4096)
+        hipLaunchKernelGGL(k_topk_wave, dim3((B + 3) / 4), dim3(256), 0, stream, S, lds, B, I, k, do_round, out_val, out_idx);
+    else
+        hipLaunchKernelGGL(k_topk, dim3(B), dim3(256), 0, stream, S, lds, B, I, k, do_round, out_val, out_idx);
     return check_launch("k_topk");
 }
 
