@@ -256,6 +256,29 @@ def main():
             'roofline': {'bound': 'mfma', 'achieved': round(flops / ts / 1e12 / max(world, 1), 2), 'peak': MFMA_F32_PEAK_TF,
                          'unit': 'TFLOP/s', 'frac': round(flops / ts / 1e12 / max(world, 1) / MFMA_F32_PEAK_TF, 4), 'traffic': None},
         }
+        # the model class scores 16384 users per call (LightGCN.predict_chunk); same kernels, fewer launches
+        big = min(16384, len(users_all))
+        if world == 1 and big > bsz:
+            n_big = max(1, min(4, len(users_all) // big))
+            bb = []
+            for bidx in range(n_big):
+                bu_ = users_all[bidx * big:(bidx + 1) * big]
+                rowptr = np.zeros(len(bu_) + 1, dtype=np.int32)
+                np.cumsum(mrp[bu_ + 1] - mrp[bu_], out=rowptr[1:])
+                items = mit[mrp[bu_[0]]:mrp[bu_[-1] + 1]]
+                bb.append((torch.from_numpy(bu_).to(dev), torch.from_numpy(rowptr).to(dev), torch.from_numpy(np.ascontiguousarray(items)).to(dev)))
+            score_batch(bb[0])
+            barrier()
+            ev0.record()
+            for bt in bb:
+                score_batch(bt)
+            ev1.record()
+            barrier()
+            tb = ev0.elapsed_time(ev1) / 1e3
+            pb = sum(int(bt[0].numel()) for bt in bb) * n_i
+            result['scoring']['large_batch'] = {'users_per_call': big, 'value': pb / tb, 'unit': 'pairs/s',
+                                                'ms_per_call': tb / n_big * 1e3,
+                                                'mfma_frac': round(2.0 * d * pb / tb / 1e12 / MFMA_F32_PEAK_TF, 4)}
 
     # ---------------- CPU baseline beside it (rank 0, N = 1 only)
     if world == 1 and not args.no_cpu_baseline:

@@ -6,8 +6,9 @@
 // Plan (all launches on one stream, no host round trip):
 //   1. threshold estimate.  Score every user against a strided sample of the items (every `kSampleStride`-th
 //      item, same MFMA kernel as the dense path), mask the sampled train items, take the r-th largest sample
-//      score as tau_u.  With r = 8 and stride 48 the true rank of tau_u among all items is ~384 +- 135, and the
-//      chance that it falls below k = 40 (8 of a user's true top-40 inside the 1/48 sample) is ~2e-6.
+//      score as tau_u.  With r = 8 and stride 32 the true rank of tau_u among all items is ~256 +- 90, and the
+//      chance that it falls below k = 40 (8 of a user's true top-40 inside the 1/32 sample) is ~7e-5.  (Stride 48
+//      makes that 2e-6 but lets 50 % more candidates through: measured slower end to end.)
 //   2. k_score_filter: the fp32 MFMA GEMM over ALL items; the 32x32 accumulators are compared against tau_u in
 //      registers and only scores > tau_u are written, as (score, item) pairs, to a log private to the lane that
 //      owns that (user, row-half) -- no atomics, no [B, I] traffic.  Items on MFMA rows (A operand, staged
@@ -31,7 +32,7 @@ namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int kSampleStride = 48;  // items per sampled item
+constexpr int kSampleStride = 32;  // items per sampled item
 constexpr int kTauRank = 8;        // tau = kTauRank-th largest masked sample score
 constexpr int kUsersPerWG = 128;   // 4 waves x 32 users
 constexpr int kStage = 64;         // items per LDS stage (2 MFMA sub-tiles of 32)
@@ -230,7 +231,7 @@ struct SelectArgs {
     const int *__restrict__ mask_items;
     float *__restrict__ out_val;
     int64_t *__restrict__ out_idx;
-    int *__restrict__ flags;
+    int *__restrict__ flagged;  // [1 + B]: count, then the flagged user rows (count zeroed by the caller each call)
     int B, S, cap2, k, do_round;
 };
 
@@ -303,8 +304,8 @@ __global__ __launch_bounds__(256) void k_select(const SelectArgs a)
         }
     }
     const bool ok = !overflow && n_valid >= a.k;
-    if (lane == 0)
-        a.flags[b] = ok ? 0 : 1;
+    if (!ok && lane == 0)
+        a.flagged[1 + atomicAdd(a.flagged, 1)] = b;
     if (ok && lane < a.k) {
         a.out_val[(size_t)b * a.k + lane] = a.do_round ? round4(e.v) : e.v;
         a.out_idx[(size_t)b * a.k + lane] = e.i;
@@ -317,7 +318,7 @@ struct BruteArgs {
     const float *__restrict__ It;
     const int *__restrict__ mask_rowptr;
     const int *__restrict__ mask_items;
-    const int *__restrict__ flags;  // NULL: every user
+    const int *__restrict__ flagged;  // [1 + B]: count, rows
     float *__restrict__ out_val;
     int64_t *__restrict__ out_idx;
     int B, I, d, k, do_round;
@@ -330,9 +331,10 @@ constexpr int kBruteWaves = 16;
 __global__ __launch_bounds__(kBruteWaves * 64) void k_brute(const BruteArgs a)
 {
     extern __shared__ float su[];  // the user's row, then kBruteWaves lists
-    const int b = blockIdx.x;
-    if (a.flags && !a.flags[b])
-        return;
+    const int n_flagged = a.flagged[0];
+    for (int f = blockIdx.x; f < n_flagged; f += gridDim.x) {
+    const int b = a.flagged[1 + f];
+    __syncthreads();  // su / lv reused across iterations
     const int lane = lane_id();
     const int w = threadIdx.x >> 6;
     float *lv = su + ((a.d + 63) & ~63);
@@ -390,14 +392,15 @@ __global__ __launch_bounds__(kBruteWaves * 64) void k_brute(const BruteArgs a)
     lv[w * kWave + lane] = e.v;
     li[w * kWave + lane] = e.i;
     __syncthreads();
-    if (w != 0)
-        return;
-    for (int o = 1; o < kBruteWaves; ++o)
-        list_offer(e, lv[o * kWave + lane], li[o * kWave + lane], lane < a.k && li[o * kWave + lane] != INT_MAX, a.k, lane);
-    if (lane < a.k) {
-        a.out_val[(size_t)b * a.k + lane] = a.do_round ? round4(e.v) : e.v;
-        a.out_idx[(size_t)b * a.k + lane] = e.i;
+    if (w == 0) {
+        for (int o = 1; o < kBruteWaves; ++o)
+            list_offer(e, lv[o * kWave + lane], li[o * kWave + lane], lane < a.k && li[o * kWave + lane] != INT_MAX, a.k, lane);
+        if (lane < a.k) {
+            a.out_val[(size_t)b * a.k + lane] = a.do_round ? round4(e.v) : e.v;
+            a.out_idx[(size_t)b * a.k + lane] = e.i;
+        }
     }
+    }  // flagged users
 }
 
 struct Plan {
@@ -419,9 +422,9 @@ Plan make_plan(int B, int I, int d, int k)
         return p;
     }
     const int user_tiles = (B + kUsersPerWG - 1) / kUsersPerWG;
-    int S = (512 + user_tiles - 1) / user_tiles;  // >= 2 workgroups per CU in flight
+    int S = (768 + user_tiles - 1) / user_tiles;  // 3 workgroups per CU (the register budget's occupancy) in flight
     const int max_S = max(1, I / (8 * kStage));   // at least 8 stages per split
-    S = max(1, min(min(S, 32), max_S));
+    S = max(1, min(min(S, 48), max_S));
     if (const char *dbg = getenv("TGCN_DEBUG_SPLITS"))  // dev only
         S = max(1, min(atoi(dbg), max_S));
     p.items_per_split = (((I + S - 1) / S + kStage - 1) / kStage) * kStage;
@@ -436,7 +439,7 @@ Plan make_plan(int B, int I, int d, int k)
     p.off_tau = o, o += align256((size_t)B * sizeof(float));
     p.off_logs = o, o += align256((size_t)B * p.S * 2 * p.cap2 * sizeof(float2));
     p.off_counts = o, o += align256((size_t)B * p.S * 2 * sizeof(int));
-    p.off_flags = o, o += align256((size_t)B * sizeof(int));
+    p.off_flags = o, o += align256((size_t)(B + 1) * sizeof(int));
     p.total = o;
     return p;
 }
@@ -519,13 +522,15 @@ extern "C" int tgcn_score_topk_f32(const float *U, const int64_t *user_ids, int3
         return rc;
 
     // 3. exact selection from the logs; 4. exact rescoring of flagged users
-    int *flags = reinterpret_cast<int *>(ws + p.off_flags);
-    SelectArgs sa{fa.logs, fa.counts, mask_rowptr, mask_items, out_val, out_idx, flags, B, p.S, p.cap2, k, round4};
+    int *flagged = reinterpret_cast<int *>(ws + p.off_flags);
+    if (hipMemsetAsync(flagged, 0, sizeof(int), s) != hipSuccess)
+        return check_launch("hipMemsetAsync(flagged)");
+    SelectArgs sa{fa.logs, fa.counts, mask_rowptr, mask_items, out_val, out_idx, flagged, B, p.S, p.cap2, k, round4};
     hipLaunchKernelGGL(k_select, dim3((B + 3) / 4), dim3(256), 0, s, sa);
     if ((rc = check_launch("k_select")) != TGCN_OK)
         return rc;
-    BruteArgs ba{U, user_ids, It, mask_rowptr, mask_items, flags, out_val, out_idx, B, I, d, k, round4};
+    BruteArgs ba{U, user_ids, It, mask_rowptr, mask_items, flagged, out_val, out_idx, B, I, d, k, round4};
     const size_t brute_lds = ((size_t)((d + 63) & ~63) + 2 * kBruteWaves * kWave) * sizeof(float);
-    hipLaunchKernelGGL(k_brute, dim3(B), dim3(kBruteWaves * 64), brute_lds, s, ba);
+    hipLaunchKernelGGL(k_brute, dim3(min(B, 256)), dim3(kBruteWaves * 64), brute_lds, s, ba);  // loops over the flagged list
     return check_launch("k_brute");
 }

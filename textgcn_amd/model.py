@@ -70,6 +70,7 @@ class _Propagate(torch.autograd.Function):
 class LightGCN(nn.Module):
     """reference: TextGCN/base_model.py:17-299 (class BaseModel)."""
 
+    predict_chunk = 16384   # users per fused scoring call
     exact = False   # True: no long-row split -> every row is one fmaf chain (bit-identical to the CPU reference)
 
     def __init__(self, params, dataset):
@@ -319,8 +320,11 @@ class LightGCN(nn.Module):
         users_emb, items_emb = self.representation
         users_emb, items_emb = users_emb.contiguous(), items_emb.contiguous()
         custom = 'score_batchwise' in self.__dict__ or type(self).score_batchwise is not LightGCN.score_batchwise
-        for j in range(0, len(users), self.batch_size):
-            batch = users[j:j + self.batch_size]
+        # the reference scores `batch_size` users per step (base_model.py:245) to bound its [B, I] matrix; the
+        # fused path has no such matrix, so it takes larger chunks (same results, fewer launches)
+        step = self.batch_size if custom else max(self.batch_size, self.predict_chunk)
+        for j in range(0, len(users), step):
+            batch = users[j:j + step]
             ids = torch.from_numpy(batch).to(self.device)
             rp, it = self._batch_mask(batch)
             if custom:   # an override (e.g. LTR) returns the [B, I] matrix; mask + top-k stay on the HIP path
