@@ -422,9 +422,9 @@ Plan make_plan(int B, int I, int d, int k)
         return p;
     }
     const int user_tiles = (B + kUsersPerWG - 1) / kUsersPerWG;
-    int S = (768 + user_tiles - 1) / user_tiles;  // 3 workgroups per CU (the register budget's occupancy) in flight
+    int S = (512 + user_tiles - 1) / user_tiles;  // >= 2 workgroups per CU in flight (48 was not reliably better)
     const int max_S = max(1, I / (8 * kStage));   // at least 8 stages per split
-    S = max(1, min(min(S, 48), max_S));
+    S = max(1, min(min(S, 32), max_S));
     if (const char *dbg = getenv("TGCN_DEBUG_SPLITS"))  // dev only
         S = max(1, min(atoi(dbg), max_S));
     p.items_per_split = (((I + S - 1) / S + kStage - 1) / kStage) * kStage;
