@@ -119,11 +119,18 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a ROCm GPU: the HIP path has no CPU fallback')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # rehearsal switch for the one-GPU box: every rank on cuda:0, gloo staged through the host (tests only; the
+    # driver's multi-GPU runs use RCCL, one GPU per rank)
+    rehearsal = os.environ.get('TGCN_BENCH_REHEARSAL') == '1'
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend='nccl', device_id=dev)
+        if rehearsal:
+            dist.init_process_group(backend='gloo')
+        else:
+            dist.init_process_group(backend='nccl', device_id=dev)
 
     from textgcn_amd import propagate, scoring, synth
     from textgcn_amd.graph import NormGraph, train_mask_csr
@@ -160,9 +167,18 @@ def main():
         n_rows_local, n_src, nnz_local = sp.bu + sp.bi, sp.n_pad, sp.nnz_local
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
+
+    def reduce_max_sum(vals):
+        """(max over ranks, sum over ranks) of a small list of floats"""
+        t = torch.tensor(vals, dtype=torch.float64, device='cpu' if rehearsal else dev)
+        mx, sm = t.clone(), t.clone()
+        torch.distributed.all_reduce(mx, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(sm, op=torch.distributed.ReduceOp.SUM)
+        return mx.tolist(), sm.tolist()
 
     for _ in range(args.warmup):
         step()
@@ -178,9 +194,7 @@ def main():
     t_dev = ev0.elapsed_time(ev1) / 1e3
     t = max(t_wall, t_dev)
     if world > 1:
-        tt = torch.tensor([t], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        t = float(tt.item())
+        t = reduce_max_sum([t])[0][0]
     edges = args.steps * K * graph.nnz
     value = edges / t
 
@@ -244,11 +258,8 @@ def main():
         ts = ev0.elapsed_time(ev1) / 1e3
         pairs = sum(int(bt[0].numel()) for bt in batches) * n_i
         if world > 1:
-            tt = torch.tensor([ts, float(pairs)], device=dev, dtype=torch.float64)
-            mx = tt.clone()
-            torch.distributed.all_reduce(mx, op=torch.distributed.ReduceOp.MAX)
-            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.SUM)
-            ts, pairs = float(mx[0].item()), float(tt[1].item())
+            mx, sm = reduce_max_sum([ts, float(pairs)])
+            ts, pairs = mx[0], sm[1]
         flops = 2.0 * d * pairs
         result['scoring'] = {
             'metric': f'scored user-item pairs/sec (scores + train mask + top-40 fused, B={bsz} per call)', 'value': pairs / ts,

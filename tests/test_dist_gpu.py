@@ -26,3 +26,25 @@ def test_sharded_hip_forward_equals_single_gpu(cuda, tmp_path, world):
     ref = Propagator(g, cuda, split_threshold=64).forward(e0, K).cpu().numpy()
     assert np.array_equal(bits(got['users']), bits(ref[:n_u]))
     assert np.array_equal(bits(got['items']), bits(ref[n_u:]))
+
+
+def test_bench_two_rank_rehearsal(cuda, tmp_path):
+    """bench.py's N > 1 code path (sharded propagation, per-rank scoring, max-over-ranks timing, one JSON line from
+    rank 0) on the one-GPU box: two ranks on cuda:0 over gloo (TGCN_BENCH_REHEARSAL=1).  The driver's real runs use
+    RCCL with one GPU per rank; everything else is the same code."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    from test_dist_cpu import free_port
+    env = dict(os.environ, TGCN_BENCH_REHEARSAL='1', OMP_NUM_THREADS='4')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+           '--workload', 'small', '--score-batches', '1', '--no-cpu-baseline']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r['n_gpus'] == 2 and r['value'] > 0 and r['scaling'] == 'weak' and 'roofline' in r and r['scoring']['value'] > 0
