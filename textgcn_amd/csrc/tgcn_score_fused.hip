@@ -6,9 +6,9 @@
 // Plan (all launches on one stream, no host round trip):
 //   1. threshold estimate.  Score every user against a strided sample of the items (every `kSampleStride`-th
 //      item, same MFMA kernel as the dense path), mask the sampled train items, take the r-th largest sample
-//      score as tau_u.  With r = 8 and stride 32 the true rank of tau_u among all items is ~256 +- 90, and the
-//      chance that it falls below k = 40 (8 of a user's true top-40 inside the 1/32 sample) is ~7e-5.  (Stride 48
-//      makes that 2e-6 but lets 50 % more candidates through: measured slower end to end.)
+//      score as tau_u.  With r = 10 and stride 32 the true rank of tau_u among all items is ~320 +- 100, and the
+//      chance that it falls below k = 40 (10 of a user's true top-40 inside the 1/32 sample) is ~7e-7 (r = 8: 7e-5,
+//      which at 16384 users per call meant a fallback launch with real work in two calls out of three).
 //   2. k_score_filter: the fp32 MFMA GEMM over ALL items; the 32x32 accumulators are compared against tau_u in
 //      registers and only scores > tau_u are written, as (score, item) pairs, to a log private to the lane that
 //      owns that (user, row-half) -- no atomics, no [B, I] traffic.  Items on MFMA rows (A operand, staged
@@ -33,7 +33,7 @@ namespace {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
 constexpr int kSampleStride = 32;  // items per sampled item
-constexpr int kTauRank = 8;        // tau = kTauRank-th largest masked sample score
+constexpr int kTauRank = 10;       // tau = kTauRank-th largest masked sample score
 constexpr int kUsersPerWG = 128;   // 4 waves x 32 users
 constexpr int kStage = 64;         // items per LDS stage (2 MFMA sub-tiles of 32)
 constexpr int kSmallI = 8192;      // below this the dense path (score -> mask -> top-k) is used
@@ -324,83 +324,83 @@ struct BruteArgs {
     int B, I, d, k, do_round;
 };
 
-// exact fallback: one 16-wave workgroup per flagged user; each wave scans a contiguous 1/16 of the items
-// (lane = item, k-ordered fmaf chain per item), wave 0 merges the 16 lists
-constexpr int kBruteWaves = 16;
+// exact fallback: one workgroup (8 waves at d = 64, fewer for wider rows: LDS) per flagged user.  Each wave walks a
+// contiguous share of the items in tiles
+// of 64 rows: the tile is loaded with coalesced 16-byte reads into a padded LDS buffer (row stride d+1 floats:
+// lane = row reads are conflict-free), then lane l chains row l in ascending k -- the same fmaf chain as the MFMA.
+constexpr int kBruteMaxWaves = 8;
+constexpr int kBruteMaxD = 256;   // wider embeddings take the direct-read path
+constexpr size_t kBruteLdsBudget = 150 << 10;
 
-__global__ __launch_bounds__(kBruteWaves * 64) void k_brute(const BruteArgs a)
+__global__ __launch_bounds__(kBruteMaxWaves * 64) void k_brute(const BruteArgs a)
 {
-    extern __shared__ float su[];  // the user's row, then kBruteWaves lists
-    const int n_flagged = a.flagged[0];
-    for (int f = blockIdx.x; f < n_flagged; f += gridDim.x) {
-    const int b = a.flagged[1 + f];
-    __syncthreads();  // su / lv reused across iterations
+    extern __shared__ float su[];  // user row [d_pad] | lists 2 x [waves x 64] | tiles [waves][64][d+1]
     const int lane = lane_id();
     const int w = threadIdx.x >> 6;
-    float *lv = su + ((a.d + 63) & ~63);
-    int *li = reinterpret_cast<int *>(lv + kBruteWaves * kWave);
-    const float *__restrict__ urow = a.U + (size_t)(a.user_ids ? a.user_ids[b] : b) * a.d;
-    for (int k = threadIdx.x; k < a.d; k += blockDim.x)
-        su[k] = urow[k];
-    __syncthreads();
-    int mb = 0, me = 0;
-    if (a.mask_rowptr) {
-        mb = a.mask_rowptr[b];
-        me = a.mask_rowptr[b + 1];
-    }
-    TopList e{-INFINITY, INT_MAX};
-    const bool vec = (a.d & 3) == 0;
-    const int per = (((a.I + kBruteWaves - 1) / kBruteWaves + kWave - 1) / kWave) * kWave;
-    const int beg = min(a.I, w * per), end = min(a.I, beg + per);
-    for (int i0 = beg; i0 < end; i0 += kWave) {
-        const int item = i0 + lane;
-        const bool on = item < end;
-        float s = 0.0f;
-        if (on) {
-            const float *__restrict__ p = a.It + (size_t)item * a.d;
-            if (vec) {
-                int k = 0;
-                for (; k + 64 <= a.d; k += 64) {   // 16 independent 16-byte loads in flight, then the ordered chain
-                    float4 t[16];
-#pragma unroll
-                    for (int q = 0; q < 16; ++q)
-                        t[q] = *reinterpret_cast<const float4 *>(p + k + 4 * q);
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        s = fmaf(su[k + 4 * q], t[q].x, s);
-                        s = fmaf(su[k + 4 * q + 1], t[q].y, s);
-                        s = fmaf(su[k + 4 * q + 2], t[q].z, s);
-                        s = fmaf(su[k + 4 * q + 3], t[q].w, s);
-                    }
+    const int n_waves = blockDim.x >> 6;
+    const int d_pad = (a.d + 63) & ~63;
+    float *lv = su + d_pad;
+    int *li = reinterpret_cast<int *>(lv + n_waves * kWave);
+    const bool tiled = a.d <= kBruteMaxD && (a.d & 3) == 0;
+    const int trow = a.d + 1;
+    float *tile = reinterpret_cast<float *>(li + n_waves * kWave) + (size_t)w * kWave * trow;
+    const int n_flagged = a.flagged[0];
+    for (int f = blockIdx.x; f < n_flagged; f += gridDim.x) {
+        const int b = a.flagged[1 + f];
+        __syncthreads();  // su / lists reused across iterations
+        const float *__restrict__ urow = a.U + (size_t)(a.user_ids ? a.user_ids[b] : b) * a.d;
+        for (int k = threadIdx.x; k < a.d; k += blockDim.x)
+            su[k] = urow[k];
+        __syncthreads();
+        int mb = 0, me = 0;
+        if (a.mask_rowptr) {
+            mb = a.mask_rowptr[b];
+            me = a.mask_rowptr[b + 1];
+        }
+        TopList e{-INFINITY, INT_MAX};
+        const int per = (((a.I + n_waves - 1) / n_waves + kWave - 1) / kWave) * kWave;
+        const int beg = min(a.I, w * per), end = min(a.I, beg + per);
+        const int q_per_row = a.d >> 2;
+        for (int i0 = beg; i0 < end; i0 += kWave) {
+            const int item = i0 + lane;
+            const bool on = item < end;
+            float s = 0.0f;
+            if (tiled) {
+                // coalesced: consecutive lanes read consecutive 16-byte pieces of the 64 x d tile
+                const int n_rows = min(kWave, end - i0);
+                const float *__restrict__ src = a.It + (size_t)i0 * a.d;
+                for (int p = lane; p < n_rows * q_per_row; p += kWave) {
+                    const float4 t = *reinterpret_cast<const float4 *>(src + (size_t)p * 4);
+                    const int r = p / q_per_row, k = (p % q_per_row) * 4;
+                    float *o = tile + r * trow + k;
+                    o[0] = t.x, o[1] = t.y, o[2] = t.z, o[3] = t.w;
                 }
-                for (; k < a.d; k += 4) {
-                    const float4 t = *reinterpret_cast<const float4 *>(p + k);
-                    s = fmaf(su[k], t.x, s);
-                    s = fmaf(su[k + 1], t.y, s);
-                    s = fmaf(su[k + 2], t.z, s);
-                    s = fmaf(su[k + 3], t.w, s);
-                }
-            } else {
+                __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes before its reads
+                const float *__restrict__ row = tile + lane * trow;
+                if (on)
+                    for (int k = 0; k < a.d; ++k)
+                        s = fmaf(su[k], row[k], s);
+            } else if (on) {
+                const float *__restrict__ p = a.It + (size_t)item * a.d;
                 for (int k = 0; k < a.d; ++k)
                     s = fmaf(su[k], p[k], s);
             }
-            if (sorted_contains(a.mask_items, mb, me, item))
+            if (on && sorted_contains(a.mask_items, mb, me, item))
                 s = -INFINITY;
+            list_offer(e, s, item, on, a.k, lane);
         }
-        list_offer(e, s, item, on, a.k, lane);
-    }
-    lv[w * kWave + lane] = e.v;
-    li[w * kWave + lane] = e.i;
-    __syncthreads();
-    if (w == 0) {
-        for (int o = 1; o < kBruteWaves; ++o)
-            list_offer(e, lv[o * kWave + lane], li[o * kWave + lane], lane < a.k && li[o * kWave + lane] != INT_MAX, a.k, lane);
-        if (lane < a.k) {
-            a.out_val[(size_t)b * a.k + lane] = a.do_round ? round4(e.v) : e.v;
-            a.out_idx[(size_t)b * a.k + lane] = e.i;
+        lv[w * kWave + lane] = e.v;
+        li[w * kWave + lane] = e.i;
+        __syncthreads();
+        if (w == 0) {
+            for (int o = 1; o < n_waves; ++o)
+                list_offer(e, lv[o * kWave + lane], li[o * kWave + lane], lane < a.k && li[o * kWave + lane] != INT_MAX, a.k, lane);
+            if (lane < a.k) {
+                a.out_val[(size_t)b * a.k + lane] = a.do_round ? round4(e.v) : e.v;
+                a.out_idx[(size_t)b * a.k + lane] = e.i;
+            }
         }
     }
-    }  // flagged users
 }
 
 struct Plan {
@@ -530,7 +530,18 @@ extern "C" int tgcn_score_topk_f32(const float *U, const int64_t *user_ids, int3
     if ((rc = check_launch("k_select")) != TGCN_OK)
         return rc;
     BruteArgs ba{U, user_ids, It, mask_rowptr, mask_items, flagged, out_val, out_idx, B, I, d, k, round4};
-    const size_t brute_lds = ((size_t)((d + 63) & ~63) + 2 * kBruteWaves * kWave) * sizeof(float);
-    hipLaunchKernelGGL(k_brute, dim3(min(B, 256)), dim3(kBruteWaves * 64), brute_lds, s, ba);  // loops over the flagged list
+    int brute_waves = kBruteMaxWaves;
+    const bool brute_tiled = d <= kBruteMaxD && (d & 3) == 0;
+    if (brute_tiled)
+        brute_waves = max(1, min(kBruteMaxWaves, (int)(kBruteLdsBudget / ((size_t)kWave * (d + 1) * sizeof(float)))));
+    size_t brute_lds = ((size_t)((d + 63) & ~63) + 2 * brute_waves * kWave) * sizeof(float);
+    if (brute_tiled)
+        brute_lds += (size_t)brute_waves * kWave * (d + 1) * sizeof(float);
+    static bool lds_opt_in = false;   // > 64 KB of dynamic LDS needs the attribute once per process
+    if (!lds_opt_in) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_brute), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
+        lds_opt_in = true;
+    }
+    hipLaunchKernelGGL(k_brute, dim3(min(B, 256)), dim3(brute_waves * 64), brute_lds, s, ba);  // loops over the flagged list
     return check_launch("k_brute");
 }
