@@ -107,7 +107,7 @@ def test_training_mode_dropout_forward_matches_reference(golden, cuda):
                                train_user_dict=train.groupby('user_id')['asin'].aggregate(list), test_df=test,
                                user_mapping=pd.DataFrame({'remap_id': range(n_u), 'org_id': range(n_u)}),
                                item_mapping=pd.DataFrame({'remap_id': range(n_i), 'org_id': range(n_i)}), norm_matrix=None)
-    m = LightGCN(_params(k=[5], dropout=float(g3['p'])), ds)
+    m = LightGCN(_params(k=[5], dropout=float(g3['p']), dropout_rng='cpu'), ds)
     _set_weights(m, g['a_layer0'][:n_u], g['a_layer0'][n_u:])
     m.training = True
     torch.manual_seed(123)
@@ -134,7 +134,7 @@ def test_backward_matches_fp64_autograd(golden, cuda, single):
                                train_user_dict=train.groupby('user_id')['asin'].aggregate(list), test_df=test,
                                user_mapping=pd.DataFrame({'remap_id': range(n_u), 'org_id': range(n_u)}),
                                item_mapping=pd.DataFrame({'remap_id': range(n_i), 'org_id': range(n_i)}), norm_matrix=None)
-    m = LightGCN(_params(k=[5], dropout=0.4, single=single), ds)
+    m = LightGCN(_params(k=[5], dropout=0.4, single=single, dropout_rng='cpu'), ds)
     m.training = True
     torch.manual_seed(7)
     keep = (torch.rand(gr.nnz) < 0.6)

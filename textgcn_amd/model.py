@@ -108,6 +108,9 @@ class LightGCN(nn.Module):
         if g('exact') is not None:
             self.exact = bool(g('exact'))
         self._split_threshold = g('split_threshold', DEFAULT_SPLIT_THRESHOLD)
+        # 'cpu': torch.rand(nnz) on the CPU generator, the reference's exact stream (base_model.py:82) -- 10 M draws
+        # + a host-to-device copy per training step on config 2; 'device': same Bernoulli(1-p) law drawn on the GPU
+        self.dropout_rng = g('dropout_rng', 'device')
 
     def _copy_dataset_params(self, dataset):
         self.n_users = dataset.n_users
@@ -184,14 +187,18 @@ class LightGCN(nn.Module):
     # ------------------------------------------------------------------ dropout (base_model.py:77-86)
     def _dropout_values(self):
         """Edge dropout as value masking on the fixed CSR: keep entry e iff rand[e] < 1 - p, kept values scaled
-        by 1/(1-p).  The uniform draw is torch.rand(nnz) on the CPU generator exactly as base_model.py:82, so a
-        seeded run drops the same edges as the reference.  Returns (vals, vals_transposed) device tensors."""
+        by 1/(1-p).  With dropout_rng='cpu' the uniform draw is torch.rand(nnz) on the CPU generator exactly as
+        base_model.py:82, so a seeded run drops the same edges as the reference (tests); the default draws on
+        the device.  Returns (vals, vals_transposed) device tensors."""
         g = self.graph
         if self._drop is None:
             scaled = (g.vals / np.float32(1 - self.dropout)).astype(np.float32)
             self._drop = (torch.from_numpy(scaled).to(self.device), torch.from_numpy(g.transpose_perm()).to(self.device))
         scaled, perm = self._drop
-        keep = (torch.rand(g.nnz) < (1 - self.dropout)).to(self.device)
+        if self.dropout_rng == 'cpu':
+            keep = (torch.rand(g.nnz) < (1 - self.dropout)).to(self.device)
+        else:
+            keep = torch.rand(g.nnz, device=self.device) < (1 - self.dropout)
         vals = torch.where(keep, scaled, torch.zeros_like(scaled))
         return vals, vals[perm]
 
