@@ -319,33 +319,43 @@ struct BruteArgs {
     const int *__restrict__ mask_rowptr;
     const int *__restrict__ mask_items;
     const int *__restrict__ flagged;  // [1 + B]: count, rows
+    float2 *__restrict__ parts;      // [flag_cap][kBruteSplits][64] partial lists
+    int flag_cap;
     float *__restrict__ out_val;
     int64_t *__restrict__ out_idx;
     int B, I, d, k, do_round;
 };
 
-// exact fallback: one workgroup (8 waves at d = 64, fewer for wider rows: LDS) per flagged user.  Each wave walks a
-// contiguous share of the items in tiles
-// of 64 rows: the tile is loaded with coalesced 16-byte reads into a padded LDS buffer (row stride d+1 floats:
-// lane = row reads are conflict-free), then lane l chains row l in ascending k -- the same fmaf chain as the MFMA.
-constexpr int kBruteMaxWaves = 8;
-constexpr int kBruteMaxD = 256;   // wider embeddings take the direct-read path
-constexpr size_t kBruteLdsBudget = 150 << 10;
+// Exact fallback for flagged users, spread over the chip: kBruteSplits workgroups per user, each scanning a
+// contiguous 1/kBruteSplits of the items.  A wave walks its share in tiles of 64 rows: the tile is loaded with
+// coalesced 16-byte reads into a padded LDS buffer (row stride d+1 floats: lane = row reads are conflict-free),
+// then lane l chains row l in ascending k -- the same fmaf chain as the MFMA.  The workgroup's waves merge their
+// lists through LDS and write one 64-entry partial list per (user, split); k_brute_merge finishes the job.
+// A flagged user costs ~25 us of latency instead of ~1 ms in a single workgroup.
+constexpr int kBruteSplits = 32;
+constexpr int kBruteWaves = 4;
+constexpr int kBruteTileMaxD = 128;   // LDS tile: 4 waves x 64 rows x (d+1) floats <= 132 KB
 
-__global__ __launch_bounds__(kBruteMaxWaves * 64) void k_brute(const BruteArgs a)
+__global__ __launch_bounds__(kBruteWaves * 64) void k_brute_part(const BruteArgs a)
 {
     extern __shared__ float su[];  // user row [d_pad] | lists 2 x [waves x 64] | tiles [waves][64][d+1]
     const int lane = lane_id();
     const int w = threadIdx.x >> 6;
-    const int n_waves = blockDim.x >> 6;
     const int d_pad = (a.d + 63) & ~63;
     float *lv = su + d_pad;
-    int *li = reinterpret_cast<int *>(lv + n_waves * kWave);
-    const bool tiled = a.d <= kBruteMaxD && (a.d & 3) == 0;
+    int *li = reinterpret_cast<int *>(lv + kBruteWaves * kWave);
+    const bool tiled = a.d <= kBruteTileMaxD && (a.d & 3) == 0;
     const int trow = a.d + 1;
-    float *tile = reinterpret_cast<float *>(li + n_waves * kWave) + (size_t)w * kWave * trow;
-    const int n_flagged = a.flagged[0];
-    for (int f = blockIdx.x; f < n_flagged; f += gridDim.x) {
+    float *tile = reinterpret_cast<float *>(li + kBruteWaves * kWave) + (size_t)w * kWave * trow;
+    const int split = blockIdx.x;
+    const int n_flagged = min(a.flagged[0], a.flag_cap);
+    // this workgroup's item range, then this wave's share of it (multiples of 64)
+    const int per_split = (((a.I + kBruteSplits - 1) / kBruteSplits + kWave - 1) / kWave) * kWave;
+    const int s_beg = min(a.I, split * per_split), s_end = min(a.I, s_beg + per_split);
+    const int per = ((((s_end - s_beg) + kBruteWaves - 1) / kBruteWaves + kWave - 1) / kWave) * kWave;
+    const int beg = min(s_end, s_beg + w * per), end = min(s_end, beg + per);
+    const int q_per_row = a.d >> 2;
+    for (int f = blockIdx.y; f < n_flagged; f += gridDim.y) {
         const int b = a.flagged[1 + f];
         __syncthreads();  // su / lists reused across iterations
         const float *__restrict__ urow = a.U + (size_t)(a.user_ids ? a.user_ids[b] : b) * a.d;
@@ -358,9 +368,6 @@ __global__ __launch_bounds__(kBruteMaxWaves * 64) void k_brute(const BruteArgs a
             me = a.mask_rowptr[b + 1];
         }
         TopList e{-INFINITY, INT_MAX};
-        const int per = (((a.I + n_waves - 1) / n_waves + kWave - 1) / kWave) * kWave;
-        const int beg = min(a.I, w * per), end = min(a.I, beg + per);
-        const int q_per_row = a.d >> 2;
         for (int i0 = beg; i0 < end; i0 += kWave) {
             const int item = i0 + lane;
             const bool on = item < end;
@@ -393,19 +400,37 @@ __global__ __launch_bounds__(kBruteMaxWaves * 64) void k_brute(const BruteArgs a
         li[w * kWave + lane] = e.i;
         __syncthreads();
         if (w == 0) {
-            for (int o = 1; o < n_waves; ++o)
+            for (int o = 1; o < kBruteWaves; ++o)
                 list_offer(e, lv[o * kWave + lane], li[o * kWave + lane], lane < a.k && li[o * kWave + lane] != INT_MAX, a.k, lane);
-            if (lane < a.k) {
-                a.out_val[(size_t)b * a.k + lane] = a.do_round ? round4(e.v) : e.v;
-                a.out_idx[(size_t)b * a.k + lane] = e.i;
-            }
+            a.parts[((size_t)f * kBruteSplits + split) * kWave + lane] = make_float2(e.v, __int_as_float(e.i));
+        }
+    }
+}
+
+// one wave per flagged user: merge the kBruteSplits partial lists and write the result
+__global__ __launch_bounds__(64) void k_brute_merge(const BruteArgs a)
+{
+    const int lane = lane_id();
+    const int n_flagged = min(a.flagged[0], a.flag_cap);
+    for (int f = blockIdx.x; f < n_flagged; f += gridDim.x) {
+        const int b = a.flagged[1 + f];
+        TopList e{-INFINITY, INT_MAX};
+        for (int sidx = 0; sidx < kBruteSplits; ++sidx) {
+            const float2 t = a.parts[((size_t)f * kBruteSplits + sidx) * kWave + lane];
+            const int ti = __float_as_int(t.y);
+            list_offer(e, t.x, ti, lane < a.k && ti != INT_MAX, a.k, lane);
+        }
+        if (lane < a.k) {
+            a.out_val[(size_t)b * a.k + lane] = a.do_round ? round4(e.v) : e.v;
+            a.out_idx[(size_t)b * a.k + lane] = e.i;
         }
     }
 }
 
 struct Plan {
     int S, items_per_split, cap2, m, m_ld;  // m = sampled items
-    size_t off_sample, off_tauv, off_taui, off_tau, off_logs, off_counts, off_flags, total;
+    size_t off_sample, off_tauv, off_taui, off_tau, off_logs, off_counts, off_parts, off_flags, total;
+    int flag_cap;
     bool small;
 };
 
@@ -439,6 +464,8 @@ Plan make_plan(int B, int I, int d, int k)
     p.off_tau = o, o += align256((size_t)B * sizeof(float));
     p.off_logs = o, o += align256((size_t)B * p.S * 2 * p.cap2 * sizeof(float2));
     p.off_counts = o, o += align256((size_t)B * p.S * 2 * sizeof(int));
+    p.flag_cap = B;   // every user may need the fallback (e.g. fully tied scores): 16 KB of partial lists each
+    p.off_parts = o, o += align256((size_t)p.flag_cap * kBruteSplits * kWave * sizeof(float2));
     p.off_flags = o, o += align256((size_t)(B + 1) * sizeof(int));
     p.total = o;
     return p;
@@ -529,19 +556,19 @@ extern "C" int tgcn_score_topk_f32(const float *U, const int64_t *user_ids, int3
     hipLaunchKernelGGL(k_select, dim3((B + 3) / 4), dim3(256), 0, s, sa);
     if ((rc = check_launch("k_select")) != TGCN_OK)
         return rc;
-    BruteArgs ba{U, user_ids, It, mask_rowptr, mask_items, flagged, out_val, out_idx, B, I, d, k, round4};
-    int brute_waves = kBruteMaxWaves;
-    const bool brute_tiled = d <= kBruteMaxD && (d & 3) == 0;
-    if (brute_tiled)
-        brute_waves = max(1, min(kBruteMaxWaves, (int)(kBruteLdsBudget / ((size_t)kWave * (d + 1) * sizeof(float)))));
-    size_t brute_lds = ((size_t)((d + 63) & ~63) + 2 * brute_waves * kWave) * sizeof(float);
-    if (brute_tiled)
-        brute_lds += (size_t)brute_waves * kWave * (d + 1) * sizeof(float);
+    BruteArgs ba{U, user_ids, It, mask_rowptr, mask_items, flagged, reinterpret_cast<float2 *>(ws + p.off_parts), p.flag_cap,
+                 out_val, out_idx, B, I, d, k, round4};
+    size_t brute_lds = ((size_t)((d + 63) & ~63) + 2 * kBruteWaves * kWave) * sizeof(float);
+    if (d <= kBruteTileMaxD && (d & 3) == 0)
+        brute_lds += (size_t)kBruteWaves * kWave * (d + 1) * sizeof(float);
     static bool lds_opt_in = false;   // > 64 KB of dynamic LDS needs the attribute once per process
     if (!lds_opt_in) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_brute), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_brute_part), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
         lds_opt_in = true;
     }
-    hipLaunchKernelGGL(k_brute, dim3(min(B, 256)), dim3(brute_waves * 64), brute_lds, s, ba);  // loops over the flagged list
-    return check_launch("k_brute");
+    hipLaunchKernelGGL(k_brute_part, dim3(kBruteSplits, 8), dim3(kBruteWaves * 64), brute_lds, s, ba);
+    if ((rc = check_launch("k_brute_part")) != TGCN_OK)
+        return rc;
+    hipLaunchKernelGGL(k_brute_merge, dim3(64), dim3(64), 0, s, ba);
+    return check_launch("k_brute_merge");
 }
