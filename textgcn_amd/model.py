@@ -246,51 +246,60 @@ class LightGCN(nn.Module):
 
     # ------------------------------------------------------------------ losses (base_model.py:181-210)
     def get_loss(self, data):
-        users, pos, *negs = data.to(self.device).t()
+        """data: [batch, 2 + n_neg] rows (user, positive, negatives...) -> BPR + L2 terms."""
+        cols = data.to(self.device).t()
+        users, pos, negs = cols[0], cols[1], list(cols[2:])
         return self.bpr_loss(users, pos, negs) + self.reg_loss(users, pos, negs)
 
     def bpr_loss(self, users, pos, negs):
-        users_emb, items_emb = self.representation
-        users_emb = users_emb[users]
-        pos_scores = self.score_pairwise(users_emb, items_emb[pos], users, pos)
-        loss = 0
-        for neg in negs:
-            neg_scores = self.score_pairwise(users_emb, items_emb[neg], users, neg)
-            loss += torch.mean(F.selu(neg_scores - pos_scores))
-        loss /= len(negs)
+        """mean over negatives of mean_b selu(s(u, neg) - s(u, pos))  (base_model.py:186-198)"""
+        all_users, all_items = self.representation
+        u = all_users[users]
+        s_pos = self.score_pairwise(u, all_items[pos], users, pos)
+        terms = [F.selu(self.score_pairwise(u, all_items[n], users, n) - s_pos).mean() for n in negs]
+        loss = torch.stack(terms).sum() / len(terms)
         self._loss_values['bpr'] += loss
         return loss
 
     def reg_loss(self, users, pos, negs):
-        loss = (self.embedding_user(users).norm(2).pow(2)
-                + self.embedding_item(pos).norm(2).pow(2)
-                + self.embedding_item(torch.stack(negs)).norm(2).pow(2).mean())
-        res = self.reg_lambda * loss / len(users) / 2
+        """lambda / (2 b) * (|E_u[users]|^2 + |E_i[pos]|^2 + mean_neg-free |E_i[negs]|^2)  (base_model.py:200-210):
+        the negatives' squared norm is that of the stacked [n_neg, b, d] block (one number), as in the reference."""
+        sq = lambda t: t.norm(2).pow(2)  # noqa: E731
+        total = sq(self.embedding_user(users)) + sq(self.embedding_item(pos)) + sq(self.embedding_item(torch.stack(negs))).mean()
+        res = total * (self.reg_lambda / (2 * len(users)))
         self._loss_values['reg'] += res
         return res
 
     # ------------------------------------------------------------------ training loop (base_model.py:108-139)
+    def _train_epoch(self, batches, epoch):
+        self.train()
+        self.training = True
+        self._loss_values = defaultdict(float)
+        for data in batches:
+            self.optimizer.zero_grad()
+            loss = self.get_loss(data)
+            if bool(loss.isnan()):
+                raise AssertionError(f'loss is NA at epoch {epoch}')   # base_model.py:123
+            loss.backward()
+            self.optimizer.step()
+
     def fit(self, batches):
+        """Adam over all parameters; every `evaluate_every` epochs: log losses, evaluate, checkpoint, early stop.
+        A run that is never stopped early writes a final checkpoint (the reference's for/else)."""
         self.optimizer = torch.optim.Adam(self.parameters(), lr=self.lr)
+        stopped = False
         for epoch in range(1, self.epochs + 1):
-            self.train()
-            self.training = True
-            self._loss_values = defaultdict(float)
-            for data in batches:
-                self.optimizer.zero_grad()
-                batch_loss = self.get_loss(data)
-                assert not batch_loss.isnan(), f'loss is NA at epoch {epoch}'
-                batch_loss.backward()
-                self.optimizer.step()
-            if epoch % self.evaluate_every:
+            self._train_epoch(batches, epoch)
+            if epoch % self.evaluate_every != 0:
                 continue
-            self.logger.info(f"Epoch {epoch}: {' '.join([f'{k} = {v:.4f}' for k, v in self._loss_values.items()])}")
+            self.logger.info(f'Epoch {epoch}: ' + ' '.join(f'{name} = {float(val):.4f}' for name, val in self._loss_values.items()))
             self.evaluate(epoch)
             self.checkpoint(epoch)
             if early_stop(self.metrics_logger):
                 self.logger.warning(f'Early stopping triggerred at epoch {epoch}')
+                stopped = True
                 break
-        else:
+        if not stopped:
             self.checkpoint(self.epochs)
 
     # ------------------------------------------------------------------ evaluate / predict (base_model.py:212-276)
@@ -361,24 +370,26 @@ class LightGCN(nn.Module):
 
     # ------------------------------------------------------------------ checkpoints (base_model.py:278-299)
     def load_model(self, load_path):
+        """`load_path`: a state_dict file, or a run directory (then its best.pkl).  The loaded model is evaluated
+        once and the metric history reset, as the reference does."""
         if load_path is None:
             self.logger.info(f'Created model {self.uid}')
             return
-        if os.path.isdir(load_path):
-            load_path = os.path.join(load_path, 'best.pkl')
-        self.logger.info(f'Loading model {load_path}')
-        self.load_state_dict(torch.load(load_path, map_location=self.device))
+        path = os.path.join(load_path, 'best.pkl') if os.path.isdir(load_path) else load_path
+        self.logger.info(f'Loading model {path}')
+        self.load_state_dict(torch.load(path, map_location=self.device))
         self.logger.info('Performance of the loaded model:')
         self.evaluate()
         self.metrics_logger = {m: np.zeros((0, len(self.k))) for m in self.metrics}
 
     def checkpoint(self, epoch):
+        """latest_checkpoint.pkl every time; best.pkl when the newest recall@k[0] is the best seen so far."""
         if not self.save:
             return
         latest = os.path.join(self.save_path, 'latest_checkpoint.pkl')
         torch.save(self.state_dict(), latest)
-        rec = self.metrics_logger[self.metrics[0]]
-        if len(rec) and rec[:, 0].max() == rec[-1][0]:
+        history = self.metrics_logger[self.metrics[0]]
+        if len(history) and history[-1][0] >= history[:, 0].max():
             self.logger.info(f'Updating best model at epoch {epoch}')
             shutil.copyfile(latest, os.path.join(self.save_path, 'best.pkl'))
 
