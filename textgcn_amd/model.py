@@ -292,7 +292,7 @@ class LightGCN(nn.Module):
             self._train_epoch(batches, epoch)
             if epoch % self.evaluate_every != 0:
                 continue
-            self.logger.info(f'Epoch {epoch}: ' + ' '.join(f'{name} = {float(val):.4f}' for name, val in self._loss_values.items()))
+            self.logger.info(f'Epoch {epoch}: ' + ' '.join(f'{name} = {float(val.detach() if torch.is_tensor(val) else val):.4f}' for name, val in self._loss_values.items()))
             self.evaluate(epoch)
             self.checkpoint(epoch)
             if early_stop(self.metrics_logger):

@@ -28,6 +28,7 @@ def short(name):
 def pmc_table(d):
     out = collections.defaultdict(lambda: collections.defaultdict(list))
     files = glob.glob(os.path.join(d, '*', '*counter_collection.csv')) + glob.glob(os.path.join(d, '*counter_collection.csv'))
+    files = [max(files, key=os.path.getmtime)] if files else []   # gpurun merges successive runs into one directory: newest only
     for f in files:
         for r in csv.DictReader(open(f)):
             if 'tgcn' in r['Kernel_Name']:
@@ -46,7 +47,7 @@ def main():
     prof = os.path.join(ROOT, 'profiles')
     os.makedirs(prof, exist_ok=True)
     if args.kt:
-        f = glob.glob(os.path.join(args.kt, '*', '*kernel_stats.csv'))[0]
+        f = max(glob.glob(os.path.join(args.kt, '*', '*kernel_stats.csv')), key=os.path.getmtime)   # newest run
         shutil.copyfile(f, os.path.join(prof, f'{args.round}_kernel_stats.csv'))
         print('kernel stats ->', f'profiles/{args.round}_kernel_stats.csv')
     if not args.pmc:
