@@ -156,6 +156,16 @@ int tgcn_ltr_pack_items_f32(const float *items_emb, const float *items_reviews, 
 int tgcn_score_pairwise_f32(const float *U, const int64_t *users, const float *V, const int64_t *items,
                             int64_t n, int32_t d, float *out, tgcn_stream_t stream);
 
+/* N4 (dynamic negative sampling): out[b, j] = <U[users[b], :], It[cand[b, j], :]> for per-user candidate lists
+ * cand [B, m] (int64 item ids); with a mask CSR over ALL users (mask_rowptr indexed by user id) a candidate that
+ * is a train item of its user scores -inf.
+ *   replaces torch.matmul(users_emb.unsqueeze(1), items_emb.transpose(1, 2)).squeeze()
+ *                                                                  TextGCN/advanced_sampling.py:37-44
+ *   and the positives filter subtract_tensor_as_set               advanced_sampling.py:64, utils.py:121-128 */
+int tgcn_score_candidates_f32(const float *U, const int64_t *users, const float *It, const int64_t *cand, int32_t B,
+                              int32_t m, int32_t d, const int32_t *mask_rowptr, const int32_t *mask_items, float *out,
+                              tgcn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,3 +54,25 @@ def test_product_fails_loudly_without_gpu():
         pytest.skip('GPU present')
     with pytest.raises(RuntimeError):
         scoring.score_dense(torch.zeros(2, 4), torch.zeros(3, 4))
+
+
+def test_c_abi_rejects_bad_arguments_with_message(built_lib):
+    """Argument validation happens before any launch, so it can be exercised without a GPU: error code + message."""
+    from textgcn_amd import _capi
+    lib = _capi.lib()
+    rc = lib.tgcn_spmm_csr_f32(None, None, None, 5, None, 5, 64, None, None, None, 1.0, None, 0, None)
+    assert rc == -1 and b'NULL' in lib.tgcn_last_error()
+    rc = lib.tgcn_spmm_csr_f32(None, None, None, 5, None, 5, 0, None, None, None, 1.0, None, 0, None)
+    assert rc == -1 and b'd out of range' in lib.tgcn_last_error()
+    assert lib.tgcn_spmm_csr_f32(None, None, None, 0, None, 0, 64, None, None, None, 1.0, None, 0, None) == 0   # empty: no-op
+    rc = lib.tgcn_topk_f32(None, 10, 2, 10, 65, 0, None, None, None)
+    assert rc == -1 and b'k must be in [1, 64]' in lib.tgcn_last_error()
+    rc = lib.tgcn_topk_f32(None, 10, 2, 10, 11, 0, None, None, None)
+    assert rc == -1 and b'exceeds the number of items' in lib.tgcn_last_error()
+    rc = lib.tgcn_score_dense_f32(None, None, 4, None, 4, 8, None, 2, None)
+    assert rc == -1
+    assert lib.tgcn_score_topk_workspace_bytes(2048, 50000, 64, 40) > 0
+    assert lib.tgcn_score_topk_workspace_bytes(0, 50000, 64, 40) == 0
+    rc = lib.tgcn_score_topk_f32(None, None, 4, None, 100, 64, None, None, 10, 0, None, None, None, 0, None)
+    assert rc == -1
+    assert lib.tgcn_ltr_folded_width(128, 384) == 960 and lib.tgcn_ltr_folded_width(64, 384) == 896

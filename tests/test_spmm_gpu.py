@@ -243,3 +243,36 @@ def test_blocked_kernel_without_split_plan_is_exact(cuda, oracle):
     idx, val = gr.to_coo()
     ref, _ = oracle.propagate(idx, val, e0, 2)
     assert np.array_equal(bits(out.cpu().numpy()), bits(ref))
+
+
+def test_full_size_c3_properties(cuda, oracle):
+    """BASELINE config 3 shape (U=180k, I=60k, nnz=1.6M, d=128, K=4): sampled rows of every layer against the
+    oracle chain, exact == split on short rows of layer 1, linearity, layer mean identity."""
+    from textgcn_amd import synth
+    from textgcn_amd.graph import NormGraph
+    from textgcn_amd.propagate import Propagator
+    n_u, n_i, nnz, d, K = synth.CONFIGS['c3']
+    u, i = synth.interactions(n_u, n_i, nnz, seed=0)
+    gr = NormGraph.from_pairs(u, i, n_u, n_i)
+    e0 = synth.embeddings(gr.n, d, seed=0)
+    prop = Propagator(gr, cuda)
+    e0d = e0.to(cuda)
+    out, layers = prop.forward(e0d, K, exact=True, keep_layers=True)
+    rng = np.random.default_rng(3)
+    rows = np.unique(np.concatenate([rng.integers(0, gr.n, 200), np.argsort(-gr.degrees())[:3]]))
+    for k in range(1, K + 1):
+        src = layers[k - 1].cpu().numpy()
+        got = layers[k].cpu().numpy()
+        for r in rows:
+            a, b = gr.rowptr[r], gr.rowptr[r + 1]
+            sub = oracle.spmm_csr(np.array([0, b - a]), gr.colidx[a:b], gr.vals[a:b], src)
+            assert np.array_equal(bits(got[r]), bits(sub[0])), (k, r)
+    s = layers[0].clone()
+    for k in range(1, K + 1):
+        s = s + layers[k]
+    assert torch.equal(out, s / torch.tensor(float(K + 1), device=cuda))      # /5: a true division
+    out_split, layers_split = prop.forward(e0d, K, exact=False, keep_layers=True)
+    short = torch.from_numpy(gr.degrees() <= 1024).to(cuda)
+    assert torch.equal(layers_split[1][short], layers[1][short])
+    assert normwise(out_split.cpu().numpy(), out.cpu().numpy()) <= 1e-5
+    assert torch.equal(prop.forward(e0d * 4.0, K, exact=True), out * 4.0)

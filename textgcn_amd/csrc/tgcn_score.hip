@@ -264,6 +264,37 @@ __global__ __launch_bounds__(256) void k_score_pairwise(const float *__restrict_
     out[r] = s;
 }
 
+// ------------------------------------------------------------------------------------------------
+// per-user candidate scores (dynamic negative sampling): out[b, j] = <U[users[b]], It[cand[b, j]]>, train items
+// of the user masked to -inf.  One wave per (user, 64 candidates); lane = candidate, k-ordered chain.
+__global__ __launch_bounds__(256) void k_score_candidates(const float *__restrict__ U, const int64_t *__restrict__ users,
+                                                          const float *__restrict__ It, const int64_t *__restrict__ cand,
+                                                          int B, int m, int d, const int *__restrict__ mask_rowptr,
+                                                          const int *__restrict__ mask_items, float *__restrict__ out)
+{
+    extern __shared__ float su[];   // 4 user rows
+    const int w = threadIdx.x >> 6;
+    const int lane = lane_id();
+    const int b = blockIdx.y * 4 + w;
+    const bool row_ok = b < B;
+    const int64_t u = row_ok ? users[b] : 0;
+    float *urow = su + w * d;
+    for (int k = lane; k < d; k += kWave)
+        urow[k] = row_ok ? U[(size_t)u * d + k] : 0.0f;
+    __syncthreads();
+    const int j = blockIdx.x * kWave + lane;
+    if (!row_ok || j >= m)
+        return;
+    const int64_t item = cand[(size_t)b * m + j];
+    const float *__restrict__ p = It + (size_t)item * d;
+    float s = 0.0f;
+    for (int k = 0; k < d; ++k)
+        s = fmaf(urow[k], p[k], s);
+    if (mask_rowptr && sorted_contains(mask_items, mask_rowptr[u], mask_rowptr[u + 1], (int)item))
+        s = -INFINITY;
+    out[(size_t)b * m + j] = s;
+}
+
 }  // namespace
 }  // namespace tgcn
 
@@ -346,4 +377,21 @@ extern "C" int tgcn_score_pairwise_f32(const float *U, const int64_t *users, con
     hipLaunchKernelGGL(k_score_pairwise, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), U, users, V, items, n, d, out);
     return check_launch("k_score_pairwise");
+}
+
+extern "C" int tgcn_score_candidates_f32(const float *U, const int64_t *users, const float *It, const int64_t *cand,
+                                         int32_t B, int32_t m, int32_t d, const int32_t *mask_rowptr,
+                                         const int32_t *mask_items, float *out, tgcn_stream_t stream)
+{
+    TGCN_REQUIRE(B >= 0 && m >= 0, "negative size");
+    TGCN_REQUIRE(d > 0 && d <= 4096, "d out of range");
+    if (B == 0 || m == 0)
+        return TGCN_OK;
+    TGCN_REQUIRE(U && users && It && cand && out, "NULL pointer");
+    TGCN_REQUIRE(!mask_rowptr || mask_items, "mask_rowptr without mask_items");
+    const dim3 grid((m + kWave - 1) / kWave, (B + 3) / 4);
+    TGCN_REQUIRE(grid.y <= 65535, "B too large for one launch");
+    hipLaunchKernelGGL(k_score_candidates, grid, dim3(256), (size_t)4 * d * sizeof(float), static_cast<hipStream_t>(stream), U,
+                       users, It, cand, B, m, d, mask_rowptr, mask_items, out);
+    return check_launch("k_score_candidates");
 }

@@ -126,3 +126,21 @@ def score_pairwise(u_table, v_table, users=None, items=None):
                                              u_table.shape[1], _capi.ptr(out), _capi.current_stream(dev))
     _capi.check(rc, 'tgcn_score_pairwise_f32')
     return out
+
+
+def score_candidates(u_table, users, items_table, cand, mask_rowptr=None, mask_items=None):
+    """out[b, j] = <u_table[users[b]], items_table[cand[b, j]]>; train items of the user (mask CSR over ALL users)
+    score -inf.  cand: int64 [B, m]."""
+    dev = _dev(u_table)
+    _f32c(u_table, 'u_table'), _f32c(items_table, 'items_table')
+    if users.dtype != torch.int64 or cand.dtype != torch.int64 or not cand.is_contiguous() or cand.dim() != 2:
+        raise TypeError('users / cand must be int64 (cand contiguous [B, m])')
+    b, m = cand.shape
+    if users.numel() != b:
+        raise ValueError('users and cand differ in length')
+    out = torch.empty((b, m), dtype=torch.float32, device=dev)
+    rc = _capi.lib().tgcn_score_candidates_f32(_capi.ptr(u_table), _capi.ptr(users.contiguous()), _capi.ptr(items_table),
+                                               _capi.ptr(cand), b, m, u_table.shape[1], _capi.ptr(mask_rowptr),
+                                               _capi.ptr(mask_items), _capi.ptr(out), _capi.current_stream(dev))
+    _capi.check(rc, 'tgcn_score_candidates_f32')
+    return out
