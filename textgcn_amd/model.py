@@ -398,9 +398,8 @@ def get_class(name):
     """Registry in the shape of the reference's main.get_class (main.py:16-22): name -> [DatasetCls, ModelCls]."""
     from .interactions import InteractionData
     table = {'lgcn': [InteractionData, LightGCN]}
-    try:
-        from .ltr import LTRData, LTRLinear
-        table['ltr_linear'] = [LTRData, LTRLinear]
-    except ImportError:
-        pass
+    from .adv_sampling import AdvSamplData, AdvSamplModel
+    from .ltr import LTRData, LTRLinear
+    table['adv_sampling'] = [AdvSamplData, AdvSamplModel]
+    table['ltr_linear'] = [LTRData, LTRLinear]
     return table[name]
