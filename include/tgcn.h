@@ -75,11 +75,14 @@ typedef struct tgcn_split_plan {
  *   acc_out[r,:]  = (acc_in[r,:] + y) / acc_div         if acc_out != NULL  (acc_div == 1: no division)
  * acc_in may alias acc_out.  Layer k of K:  acc_in = E0 rows (k = 1) or the running sum, acc_div =
  * K+1 on the last layer -- exactly the reference's sequential sum then one division.
- * `plan` may be NULL (every row summed by one wave: bit-identical to the reference's CPU result). */
+ * `plan` may be NULL (every row summed by one wave: bit-identical to the reference's CPU result).
+ * `row_order` (optional, [n_rows], a permutation of the row ids): the order in which rows are handed to
+ * wavefronts.  Results do not depend on it; descending row length (longest work first) shortens the launch's
+ * tail -- 6 % on BASELINE config 2.  Honoured by the wave-per-row kernel. */
 int tgcn_spmm_csr_f32(const int32_t *rowptr, const int32_t *colidx, const float *vals, int64_t n_rows,
                       const float *X, int64_t n_src_rows, int32_t d, float *Y, const float *acc_in,
-                      float *acc_out, float acc_div, const tgcn_split_plan_t *plan, uint32_t flags,
-                      tgcn_stream_t stream);
+                      float *acc_out, float acc_div, const tgcn_split_plan_t *plan, const int32_t *row_order,
+                      uint32_t flags, tgcn_stream_t stream);
 
 /* Cache-blocked form of the same product (bit-identical results; faster when X does not fit an XCD's 4 MB L2).
  * A block plan covers local rows [row_begin, row_begin + n_rows) whose entries all fall in one column range

@@ -60,11 +60,11 @@ def test_c_abi_rejects_bad_arguments_with_message(built_lib):
     """Argument validation happens before any launch, so it can be exercised without a GPU: error code + message."""
     from textgcn_amd import _capi
     lib = _capi.lib()
-    rc = lib.tgcn_spmm_csr_f32(None, None, None, 5, None, 5, 64, None, None, None, 1.0, None, 0, None)
+    rc = lib.tgcn_spmm_csr_f32(None, None, None, 5, None, 5, 64, None, None, None, 1.0, None, None, 0, None)
     assert rc == -1 and b'NULL' in lib.tgcn_last_error()
-    rc = lib.tgcn_spmm_csr_f32(None, None, None, 5, None, 5, 0, None, None, None, 1.0, None, 0, None)
+    rc = lib.tgcn_spmm_csr_f32(None, None, None, 5, None, 5, 0, None, None, None, 1.0, None, None, 0, None)
     assert rc == -1 and b'd out of range' in lib.tgcn_last_error()
-    assert lib.tgcn_spmm_csr_f32(None, None, None, 0, None, 0, 64, None, None, None, 1.0, None, 0, None) == 0   # empty: no-op
+    assert lib.tgcn_spmm_csr_f32(None, None, None, 0, None, 0, 64, None, None, None, 1.0, None, None, 0, None) == 0   # empty: no-op
     rc = lib.tgcn_topk_f32(None, 10, 2, 10, 65, 0, None, None, None)
     assert rc == -1 and b'k must be in [1, 64]' in lib.tgcn_last_error()
     rc = lib.tgcn_topk_f32(None, 10, 2, 10, 11, 0, None, None, None)

@@ -28,7 +28,7 @@ _SIGNATURES = {
     'tgcn_abi_version': (ctypes.c_int, []),
     'tgcn_last_error': (c_char_p, []),
     'tgcn_spmm_csr_f32': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p,
-                                         c_void_p, c_void_p, c_float, POINTER(SplitPlanStruct), c_uint32, c_void_p]),
+                                         c_void_p, c_void_p, c_float, POINTER(SplitPlanStruct), c_void_p, c_uint32, c_void_p]),
     'tgcn_spmm_blocked_f32': (ctypes.c_int, [POINTER(BlockPlanStruct), c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
                                              c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_float, POINTER(SplitPlanStruct),
                                              c_void_p]),

@@ -41,7 +41,9 @@ struct SpmmArgs {
     float acc_div;
     int n_rows;
     int d;
-    int row_waves;  // waves [0,row_waves) own rows, waves [row_waves, row_waves+n_chunks) own chunks
+    int row_waves;  // waves [0, n_chunks) own chunks of long rows -- dispatched FIRST, they are the longest work items
+                    // (up to `threshold` entries each) -- and waves [n_chunks, n_chunks + row_waves) own rows
+    const int *__restrict__ row_order;  // optional: wave w (after the chunk waves) owns row row_order[w]
     int threshold;  // rows with more entries than this are left to the chunk waves
     int n_chunks;
     const int *__restrict__ chunk_beg;
@@ -165,12 +167,13 @@ __global__ __launch_bounds__(256) void k_spmm_wave(const SpmmArgs a)
 {
     const int lane = lane_id();
     const int wave = uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (wave >= a.row_waves) {
-        if (wave - a.row_waves < a.n_chunks)
-            chunk_wave<VEC, UNROLL>(a, wave - a.row_waves, lane);
+    if (wave < a.n_chunks) {
+        chunk_wave<VEC, UNROLL>(a, wave, lane);
         return;
     }
-    const int row = wave;
+    if (wave - a.n_chunks >= a.row_waves)
+        return;
+    const int row = a.row_order ? a.row_order[wave - a.n_chunks] : wave - a.n_chunks;
     const int beg = a.rowptr[row];
     const int end = a.rowptr[row + 1];
     if (end - beg > a.threshold)
@@ -192,13 +195,14 @@ __global__ __launch_bounds__(256) void k_spmm_group(const SpmmArgs a)
     constexpr int VEC = D / kWave;  // for the chunk waves (wave-per-chunk layout)
     const int lane = lane_id();
     const int wave = uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (wave >= a.row_waves) {
-        if (wave - a.row_waves < a.n_chunks)
-            chunk_wave<VEC, 8>(a, wave - a.row_waves, lane);
+    if (wave < a.n_chunks) {
+        chunk_wave<VEC, 8>(a, wave, lane);
         return;
     }
+    if (wave - a.n_chunks >= a.row_waves)
+        return;
     const int gl = lane & (G - 1);
-    const int row = wave * R + lane / G;
+    const int row = (wave - a.n_chunks) * R + lane / G;
     const bool valid = row < a.n_rows;
     int beg = 0, end = 0;
     if (valid) {
@@ -351,7 +355,7 @@ int tgcn::launch_long_rows(const int *rowptr, const int *colidx, const float *va
     SpmmArgs a;
     a.rowptr = rowptr, a.colidx = colidx, a.vals = vals, a.X = X, a.Y = Y;
     a.acc_in = acc_in, a.acc_out = acc_out, a.acc_div = acc_div;
-    a.n_rows = n_rows, a.d = d, a.row_waves = 0;  // no row waves: every wave of the launch is a chunk wave
+    a.n_rows = n_rows, a.d = d, a.row_waves = 0, a.row_order = nullptr;  // no row waves: every wave of the launch is a chunk wave
     a.threshold = plan->threshold, a.n_chunks = plan->n_chunks;
     a.chunk_beg = plan->chunk_beg, a.chunk_end = plan->chunk_end, a.ws = plan->workspace;
     const int grid = (a.n_chunks + 3) / 4;
@@ -370,8 +374,8 @@ int tgcn::launch_long_rows(const int *rowptr, const int *colidx, const float *va
 
 extern "C" int tgcn_spmm_csr_f32(const int32_t *rowptr, const int32_t *colidx, const float *vals, int64_t n_rows,
                                  const float *X, int64_t n_src_rows, int32_t d, float *Y, const float *acc_in,
-                                 float *acc_out, float acc_div, const tgcn_split_plan_t *plan, uint32_t flags,
-                                 tgcn_stream_t stream)
+                                 float *acc_out, float acc_div, const tgcn_split_plan_t *plan, const int32_t *row_order,
+                                 uint32_t flags, tgcn_stream_t stream)
 {
     TGCN_REQUIRE(n_rows >= 0 && n_rows < INT_MAX - 256, "n_rows out of range");
     TGCN_REQUIRE(d > 0 && d <= 4096, "d out of range");
@@ -401,6 +405,7 @@ extern "C" int tgcn_spmm_csr_f32(const int32_t *rowptr, const int32_t *colidx, c
     a.acc_in = acc_in, a.acc_out = acc_out, a.acc_div = acc_div;
     a.n_rows = (int)n_rows, a.d = d;
     a.threshold = INT_MAX, a.n_chunks = 0, a.chunk_beg = nullptr, a.chunk_end = nullptr, a.ws = nullptr;
+    a.row_order = row_order;
     const bool split = plan && plan->n_chunks > 0 && vec_ok;
     if (split) {
         TGCN_REQUIRE(plan->threshold > 0, "plan->threshold must be positive");

@@ -20,7 +20,7 @@ class DeviceCSR:
     """CSR of a contiguous block of rows of A on one device (+ optional long-row split plan)."""
 
     def __init__(self, rowptr, colidx, vals, n_src_rows, device, split_threshold=None, block_specs=None,
-                 block_bytes=DEFAULT_BLOCK_BYTES):
+                 block_bytes=DEFAULT_BLOCK_BYTES, order_rows=True):
         """block_specs: optional list of (row_begin, row_end, col_lo, col_hi) covering all rows once -- row ranges
         whose entries fall in one column range (user rows x item columns, item rows x user columns).  Enables the
         cache-blocked kernel (tgcn_spmm_blocked_f32) for widths 64/128/256."""
@@ -34,6 +34,9 @@ class DeviceCSR:
         self.rowptr = torch.from_numpy(rowptr.astype(np.int32)).to(self.device)
         self.colidx = torch.from_numpy(np.ascontiguousarray(colidx, dtype=np.int32)).to(self.device)
         self.vals = torch.from_numpy(np.ascontiguousarray(vals, dtype=np.float32)).to(self.device)
+        # longest rows first: the launch's tail is its last long row (scheduling only; results do not depend on it)
+        lens = np.diff(rowptr)
+        self.row_order = torch.from_numpy(np.argsort(-lens, kind='stable').astype(np.int32)).to(self.device) if order_rows else None
         self._plan_host = split_plan_arrays(rowptr, split_threshold) if split_threshold else None
         self._plan_dev = None
         self._plan_struct = {}
@@ -128,7 +131,8 @@ def spmm(csr, x, y=None, acc_in=None, acc_out=None, acc_div=1.0, exact=False, va
         return y if y is not None else acc_out
     rc = _capi.lib().tgcn_spmm_csr_f32(
         _capi.ptr(csr.rowptr), _capi.ptr(csr.colidx), _capi.ptr(vals), csr.n_rows, _capi.ptr(x), csr.n_src_rows, d,
-        _capi.ptr(y), _capi.ptr(acc_in), _capi.ptr(acc_out), float(acc_div), plan, (variant & 0xff) | (unroll << 8),
+        _capi.ptr(y), _capi.ptr(acc_in), _capi.ptr(acc_out), float(acc_div), plan, _capi.ptr(csr.row_order),
+        (variant & 0xff) | ((unroll & 0xff) << 8),
         _capi.current_stream(dev))
     _capi.check(rc, 'tgcn_spmm_csr_f32')
     return y if y is not None else acc_out
