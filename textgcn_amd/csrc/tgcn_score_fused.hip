@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void k_score_filter(const FilterArgs a)
             acc0[r] = 0.0f, acc1[r] = 0.0f;
         // A fragments are fetched QB k-groups ahead of the MFMAs that consume them, so the LDS latency sits
         // under the previous block's matrix work instead of in front of every four MFMAs
-        constexpr int QB = DQ < 8 ? DQ : 8;
+        constexpr int QB = 4;   // 16 MFMAs (~1000 cycles) per block: ample cover for the next block's LDS reads
         float2 fa0[2][QB], fa1[2][QB];
 #pragma unroll
         for (int q = 0; q < QB; ++q) {
@@ -170,6 +170,9 @@ __global__ __launch_bounds__(256) void k_score_filter(const FilterArgs a)
                     fa1[(g + 1) & 1][q] = *reinterpret_cast<const float2 *>(pi + 32 * ROW + ((g + 1) * QB + q) * 4);
                 }
             }
+            // pin the order: hipcc otherwise sinks the reads to just in front of their first use and the wave
+            // stalls on lgkmcnt once per four MFMAs
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < QB; ++q) {
                 const float2 b2 = bf[g * QB + q];
@@ -178,6 +181,7 @@ __global__ __launch_bounds__(256) void k_score_filter(const FilterArgs a)
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[g & 1][q].y, b2.y, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[g & 1][q].y, b2.y, acc1, 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (a.debug_mode == 1) {  // dev only: time the GEMM loop without the filter epilogue
             asm volatile("" ::"v"(acc0), "v"(acc1));
@@ -187,28 +191,39 @@ __global__ __launch_bounds__(256) void k_score_filter(const FilterArgs a)
             buf ^= 1;
             continue;
         }
-        // C/D layout: col (user) = lane & 31, row (item) = (reg & 3) + 8 * (reg >> 2) + 4 * h.
-        // ~0.5 % of the scores pass; the wave-level ballot turns the common "nobody passes" case into one
-        // scalar branch per register instead of an exec-mask save/restore.
-        const int lim = i_end - s0;  // rows >= lim are padding (only in the last stage of the last split)
+        // C/D layout: col (user) = lane & 31, row (item) = (reg & 3) + 8 * (reg >> 2) + 4 * h.  ~0.6 % of the scores
+        // pass.  Rows past i_end exist only in the last stage of the last split: handled by a uniform branch so that
+        // the common path is one compare + one exec-masked block per register.
+        const int lim = i_end - s0;
+        if (lim >= kStage) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const bool pass = acc0[r] > tau && row < lim;
-            if (__ballot(pass)) {
-                if (pass) {
+            for (int r = 0; r < 16; ++r)
+                if (acc0[r] > tau) {
+                    if (cnt < a.cap2)
+                        log[cnt] = make_float2(acc0[r], __int_as_float(s0 + (r & 3) + 8 * (r >> 2) + 4 * h));
+                    ++cnt;
+                }
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (acc1[r] > tau) {
+                    if (cnt < a.cap2)
+                        log[cnt] = make_float2(acc1[r], __int_as_float(s0 + 32 + (r & 3) + 8 * (r >> 2) + 4 * h));
+                    ++cnt;
+                }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (acc0[r] > tau && row < lim) {
                     if (cnt < a.cap2)
                         log[cnt] = make_float2(acc0[r], __int_as_float(s0 + row));
                     ++cnt;
                 }
             }
-        }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            const bool pass = acc1[r] > tau && row < lim;
-            if (__ballot(pass)) {
-                if (pass) {
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (acc1[r] > tau && row < lim) {
                     if (cnt < a.cap2)
                         log[cnt] = make_float2(acc1[r], __int_as_float(s0 + row));
                     ++cnt;
