@@ -132,28 +132,44 @@ class ShardedPropagator:
             b['out_i'].copy_(xi)
             return b['out_u'], b['out_i']
         acc_u, acc_i = b['acc_u'], b['acc_i']
+        # Pending gathers of the table being READ (x): users feed the item half-step, items feed the user half-step.
+        wait_users = wait_items = None
         for k in range(1, n_layers + 1):
             last = k == n_layers
             yu, yi = y[:self.u_pad], y[self.u_pad:]
             div = float(n_layers + 1) if last else 1.0
-            # --- user half-step (reads the item rows of x)
-            if single:
-                self._spmm(self.csr_u, x, y=b['out_u'] if last else yu[my_u], exact=exact)
+
+            def user_half():   # reads the item rows of x
+                self._wait(wait_items)
+                if single:
+                    self._spmm(self.csr_u, x, y=b['out_u'] if last else yu[my_u], exact=exact)
+                else:
+                    self._spmm(self.csr_u, x, y=None if last else yu[my_u], acc_in=e0_u if k == 1 else acc_u,
+                               acc_out=b['out_u'] if last else acc_u, acc_div=div, exact=exact)
+                return None if last else self._all_gather(yu, yu[my_u], True)
+
+            def item_half():   # reads the user rows of x
+                self._wait(wait_users)
+                if single:
+                    self._spmm(self.csr_i, x, y=yi[my_i], exact=exact)
+                else:
+                    # on the last layer the item block of the *mean* is what gets gathered: write it into yi
+                    self._spmm(self.csr_i, x, y=None if last else yi[my_i], acc_in=e0_i if k == 1 else acc_i,
+                               acc_out=yi[my_i] if last else acc_i, acc_div=div, exact=exact)
+                return self._all_gather(yi, yi[my_i], True)
+
+            # Alternate the order so that EVERY all-gather overlaps a half-step: the block gathered last in layer
+            # k-1 is consumed last in layer k (odd layers: users then items; even layers: items then users).
+            if k & 1:
+                nu = user_half()
+                ni = item_half()
             else:
-                self._spmm(self.csr_u, x, y=None if last else yu[my_u], acc_in=e0_u if k == 1 else acc_u,
-                           acc_out=b['out_u'] if last else acc_u, acc_div=div, exact=exact)
-            wu = None if last else self._all_gather(yu, yu[my_u], True)   # overlaps the item half-step
-            # --- item half-step (reads the user rows of x)
-            if single:
-                self._spmm(self.csr_i, x, y=yi[my_i], exact=exact)
-            else:
-                # on the last layer the item block of the *mean* is what gets gathered: write it into yi
-                self._spmm(self.csr_i, x, y=None if last else yi[my_i], acc_in=e0_i if k == 1 else acc_i,
-                           acc_out=yi[my_i] if last else acc_i, acc_div=div, exact=exact)
-            wi = self._all_gather(yi, yi[my_i], True)
-            self._wait(wu)
-            self._wait(wi)
+                ni = item_half()
+                nu = user_half()
+            wait_users, wait_items = nu, ni
             x, y = y, x
+        self._wait(wait_users)
+        self._wait(wait_items)
         # after the swap, x holds the last layer: its item part is the gathered item table
         b['out_i'].copy_(x[self.u_pad:])
         return b['out_u'], b['out_i']
