@@ -43,24 +43,26 @@ struct DenseArgs {
     int item_mul;  // item row i lives at It[i * item_mul, :] (strided item sample; 1 = every item)
 };
 
-constexpr int kStageVec = (kTile * kKC / 4) / 256;   // float4 per thread per operand tile
-
-// global -> registers: rows [row0, row0+128) x k [k0, k0+64) of a row-major [n_rows, d] table (optionally gathered
-// through ids).  FULLK (d % 64 == 0): rows past the table are clamped, not zero-filled (their products are never
-// stored), so every load is unconditional and stays in flight; other widths need zeros in the K padding and take
-// the predicated path (any `cond ? load : 0` form makes hipcc branch around the load and wait inside the branch).
+// stage rows [row0, row0+128) x k [k0, k0+64) of a row-major [n_rows, d] table (optionally gathered
+// through ids) into LDS, zero-filled outside the table
 template <bool FULLK>
-__device__ __forceinline__ void tile_load(float4 (&v)[kStageVec], const float *__restrict__ src, const int64_t *__restrict__ ids,
-                                          int row0, int n_rows, int k0, int d, int row_mul = 1)
+__device__ __forceinline__ void stage_tile(float *__restrict__ dst, const float *__restrict__ src,
+                                           const int64_t *__restrict__ ids, int row0, int n_rows, int k0, int d,
+                                           int row_mul = 1)
 {
     const int t = threadIdx.x;
+    constexpr int N = (kTile * kKC / 4) / 256;
+    float4 v[N];
+    // all loads first (one predicated load per element, no early waits), then the LDS writes
 #pragma unroll
-    for (int i = 0; i < kStageVec; ++i) {
+    for (int i = 0; i < N; ++i) {
         const int f = i * 256 + t;
         const int r = f >> 4;  // 16 float4 per row chunk
         const int q = f & 15;
         const int row = row0 + r;
         const int k = k0 + q * 4;
+        // FULLK (d % 64 == 0): rows past the table are clamped, not zero-filled (their products are never stored),
+        // so the loads are unconditional and overlap; other widths need zeros in the K padding (predicated path)
         const int crow = min(row, n_rows - 1);
         const int64_t srow = ids ? ids[crow] : (int64_t)crow * row_mul;
         const float *p = src + (size_t)srow * d;
@@ -74,14 +76,8 @@ __device__ __forceinline__ void tile_load(float4 (&v)[kStageVec], const float *_
             v[i].w = (ok && k + 3 < d) ? p[k + 3] : 0.0f;
         }
     }
-}
-
-// registers -> LDS with the (k0,k2,k1,k3) group swizzle
-__device__ __forceinline__ void tile_store(float *__restrict__ dst, const float4 (&v)[kStageVec])
-{
-    const int t = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < kStageVec; ++i) {
+    for (int i = 0; i < N; ++i) {
         const int f = i * 256 + t;
         float *o = dst + (f >> 4) * kLdsRow + (f & 15) * 4;
         *reinterpret_cast<float2 *>(o) = make_float2(v[i].x, v[i].z);
@@ -109,20 +105,12 @@ __global__ __launch_bounds__(256) void k_score_dense(const DenseArgs a)
         for (int r = 0; r < 16; ++r)
             acc[n][r] = 0.0f;
 
-    // K chunks of 64: the next chunk's global loads are issued before this chunk's 128 MFMAs and land in LDS after
-    // them (one LDS buffer, two barriers per chunk) -- with K = 960 (folded LTR operands) the loop is the kernel
-    float4 vu[kStageVec], vi[kStageVec];
-    tile_load<FULLK>(vu, a.U, a.user_ids, u0, a.B, 0, a.d);
-    tile_load<FULLK>(vi, a.It, nullptr, i0, a.I, 0, a.d, a.item_mul);
-    tile_store(ldsU, vu);
-    tile_store(ldsI, vi);
-    __syncthreads();
     for (int k0 = 0; k0 < a.d; k0 += kKC) {
-        const bool more = k0 + kKC < a.d;
-        if (more) {
-            tile_load<FULLK>(vu, a.U, a.user_ids, u0, a.B, k0 + kKC, a.d);
-            tile_load<FULLK>(vi, a.It, nullptr, i0, a.I, k0 + kKC, a.d, a.item_mul);
-        }
+        if (k0)
+            __syncthreads();
+        stage_tile<FULLK>(ldsU, a.U, a.user_ids, u0, a.B, k0, a.d);
+        stage_tile<FULLK>(ldsI, a.It, nullptr, i0, a.I, k0, a.d, a.item_mul);
+        __syncthreads();
         const float *pu = ldsU + (w * 32 + r32) * kLdsRow + 2 * h;
         const float *pi = ldsI + r32 * kLdsRow + 2 * h;
 #pragma unroll 4
@@ -138,12 +126,6 @@ __global__ __launch_bounds__(256) void k_score_dense(const DenseArgs a)
 #pragma unroll
             for (int n = 0; n < 4; ++n)
                 acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.y, b2[n].y, acc[n], 0, 0, 0);
-        }
-        if (more) {
-            __syncthreads();   // every wave is done reading this chunk
-            tile_store(ldsU, vu);
-            tile_store(ldsI, vi);
-            __syncthreads();
         }
     }
 
