@@ -202,8 +202,11 @@ def main():
     layer_bytes = [algorithmic_bytes_per_layer(nnz_local, n_rows_local, n_src, d, k, K, False) for k in range(1, K + 1)]
     mean_layer_s = t_dev / (args.steps * K)
     achieved = float(np.mean(layer_bytes)) / mean_layer_s / 1e9
+    traffic = load_traffic(wl if world == 1 else None)
     roofline = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': load_traffic(wl if world == 1 else None),
+                'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                # measured memory-side bytes (PMC pass, profiles/) over the live launch time: what the fabric moves
+                'traffic_GBs': round(traffic / mean_layer_s / 1e9, 1) if traffic else None,
                 'kernel': 'k_spmm (one layer launch, incl. long-row reduce)',
                 'algorithmic_bytes_per_launch': int(np.mean(layer_bytes)), 'launch_us': round(mean_layer_s * 1e6, 2),
                 'gather_model_GBs': round((nnz_local * (8 + 4 * d) + n_rows_local * d * 4) / mean_layer_s / 1e9, 1)}

@@ -194,3 +194,16 @@ def test_fit_runs_and_checkpoint_roundtrip(cuda, tmp_path):
     p2 = _params(k=[5, 10], batch_size=256, load=str(tmp_path), save_path=str(tmp_path), exact=False, data=str(folder))
     m2 = LightGCN(p2, ds)
     assert m2.predict(np.arange(ds.n_users)) == pred
+
+
+def test_predict_edge_cases(golden, cuda, tmp_path):
+    """empty user list, a single user, users in arbitrary order with repeats, batch size 1."""
+    from textgcn_amd.interactions import InteractionData
+    from textgcn_amd.model import LightGCN
+    ds = InteractionData(folder=os.path.join(GOLDEN, 'dummy'), k=[1, 2, 3])
+    m = LightGCN(_params(save_path=str(tmp_path), batch_size=1), ds)
+    assert m.predict([]) == []
+    assert m.predict([], with_scores=True) == ([], [])
+    full = m.predict(range(ds.n_users))
+    assert m.predict([3]) == [full[3]]
+    assert m.predict(np.array([4, 0, 4, 2])) == [full[4], full[0], full[4], full[2]]

@@ -292,3 +292,20 @@ def test_hip_graph_replay_matches_eager(cuda):
     out2 = prop.forward_graphed(e0, 3)
     assert torch.equal(out2, ref * 2.0)
     assert len(prop._graphs) == 1
+
+
+def test_edge_cases_empty_and_isolated(cuda, oracle):
+    """No interactions at all, isolated nodes, a single edge, n_layers = 0."""
+    from textgcn_amd.graph import NormGraph
+    from textgcn_amd.propagate import Propagator
+    e = np.zeros(0, dtype=np.int64)
+    g0 = NormGraph.from_pairs(e, e, 7, 5)                      # 12 isolated nodes, nnz = 0
+    x = torch.randn((12, 64), device=cuda)
+    out = Propagator(g0, cuda).forward(x, 3)
+    assert torch.equal(out, x / 4.0)                            # every layer is zero: mean = E0 / (K+1)
+    g1 = NormGraph.from_pairs(np.array([2]), np.array([3]), 7, 5)
+    out1 = Propagator(g1, cuda).forward(x, 2, exact=True).cpu().numpy()
+    idx, val = g1.to_coo()
+    ref, _ = oracle.propagate(idx, val, x.cpu().numpy(), 2)
+    assert np.array_equal(bits(out1), bits(ref))
+    assert torch.equal(Propagator(g1, cuda).forward(x, 0), x)   # K = 0: representation is E0
