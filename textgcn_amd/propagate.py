@@ -32,6 +32,8 @@ class DeviceCSR:
         self.nnz = int(rowptr[-1])
         self.device = torch.device(device)
         self.rowptr = torch.from_numpy(rowptr.astype(np.int32)).to(self.device)
+        if self.nnz == 0:   # a graph without interactions: keep non-NULL device arrays for the ABI's pointer checks
+            colidx, vals = np.zeros(1, dtype=np.int32), np.zeros(1, dtype=np.float32)
         self.colidx = torch.from_numpy(np.ascontiguousarray(colidx, dtype=np.int32)).to(self.device)
         self.vals = torch.from_numpy(np.ascontiguousarray(vals, dtype=np.float32)).to(self.device)
         # longest rows first: the launch's tail is its last long row (scheduling only; results do not depend on it)
@@ -119,7 +121,7 @@ def spmm(csr, x, y=None, acc_in=None, acc_out=None, acc_div=1.0, exact=False, va
     plan = None if exact else csr.plan(d)
     if vals is None:
         vals = csr.vals
-    elif vals.dtype != torch.float32 or vals.numel() != csr.nnz or vals.device != dev or not vals.is_contiguous():
+    elif vals.dtype != torch.float32 or vals.numel() != max(csr.nnz, 1) or vals.device != dev or not vals.is_contiguous():
         raise ValueError('vals must be a contiguous float32 device tensor with one entry per stored element')
     plans, n_plans = csr.block_plans(d) if (blocked and not exact and variant == _capi.SPMM_AUTO) else (None, 0)
     if n_plans:
