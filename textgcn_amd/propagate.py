@@ -38,7 +38,17 @@ class DeviceCSR:
         self.vals = torch.from_numpy(np.ascontiguousarray(vals, dtype=np.float32)).to(self.device)
         # longest rows first: the launch's tail is its last long row (scheduling only; results do not depend on it)
         lens = np.diff(rowptr)
-        self.row_order = torch.from_numpy(np.argsort(-lens, kind='stable').astype(np.int32)).to(self.device) if order_rows else None
+        self.row_order = None
+        if order_rows:
+            order = np.argsort(-lens, kind='stable')
+            if block_specs:
+                # one phase per row block that shares a gather table (item rows, then user rows), longest first inside
+                # a phase: the rows in flight then gather from ONE table, not from both
+                parts = []
+                for (r0, r1, _c0, _c1) in sorted(block_specs, key=lambda sp: -sp[0]):
+                    parts.append(r0 + np.argsort(-lens[r0:r1], kind='stable'))
+                order = np.concatenate(parts)
+            self.row_order = torch.from_numpy(order.astype(np.int32)).to(self.device)
         self._plan_host = split_plan_arrays(rowptr, split_threshold) if split_threshold else None
         self._plan_dev = None
         self._plan_struct = {}
