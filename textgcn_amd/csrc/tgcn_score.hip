@@ -225,21 +225,33 @@ __global__ __launch_bounds__(256) void k_topk_wave(const float *__restrict__ S, 
     const float *__restrict__ row = S + (size_t)b * lds;
     TopList e{-INFINITY, INT_MAX};
     const bool vec_ok = (lds & 3) == 0 && ((size_t)row & 15) == 0;
-    for (int base = 0; base < I; base += kWave * 4) {
-        const int i0 = base + lane * 4;
-        float x[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        if (vec_ok && i0 + 3 < I) {
-            const float4 t = *reinterpret_cast<const float4 *>(row + i0);
-            x[0] = t.x, x[1] = t.y, x[2] = t.z, x[3] = t.w;
-        } else {
+    // rows of <= 4096 floats: 16 sweeps of 256 at most; all loads of 8 sweeps are issued before the first offer
+    constexpr int kSweeps = 8;
+    for (int base = 0; base < I; base += kWave * 4 * kSweeps) {
+        float x[kSweeps][4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                if (i0 + u < I)
-                    x[u] = row[i0 + u];
+        for (int sw = 0; sw < kSweeps; ++sw) {
+            const int i0 = base + sw * kWave * 4 + lane * 4;
+            x[sw][0] = x[sw][1] = x[sw][2] = x[sw][3] = -INFINITY;
+            if (vec_ok && i0 + 3 < I) {
+                const float4 t = *reinterpret_cast<const float4 *>(row + i0);
+                x[sw][0] = t.x, x[sw][1] = t.y, x[sw][2] = t.z, x[sw][3] = t.w;
+            } else {
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (i0 + u < I)
+                        x[sw][u] = row[i0 + u];
+            }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            list_offer(e, x[u], i0 + u, i0 + u < I, k, lane);
+        for (int sw = 0; sw < kSweeps; ++sw) {
+            const int i0 = base + sw * kWave * 4 + lane * 4;
+            if (base + sw * kWave * 4 >= I)
+                break;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                list_offer(e, x[sw][u], i0 + u, i0 + u < I, k, lane);
+        }
     }
     if (lane < k) {
         out_val[(size_t)b * k + lane] = do_round ? round4(e.v) : e.v;

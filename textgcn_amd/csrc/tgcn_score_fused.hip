@@ -290,19 +290,37 @@ __global__ __launch_bounds__(256) void k_select(const SelectArgs a)
         list_offer(e, sv, si, on, a.k, lane);
     };
     if (n_seg >= 32) {
-        // many short segments: lane = segment, all segments advance together
+        // many short segments: lane = segment, all segments advance together.  The first kPre candidates of every
+        // segment are fetched in one go (independent loads, one memory latency) before any is offered.
+        constexpr int kPre = 8;
         for (int seg0 = 0; seg0 < n_seg; seg0 += kWave) {
             const int seg = seg0 + lane;
             int cnt = seg < n_seg ? a.counts[(size_t)b * n_seg + seg] : 0;
             if (__any(cnt > a.cap2))
                 overflow = true;
             cnt = min(cnt, a.cap2);
-            const float2 *__restrict__ lg = a.logs + ((size_t)b * n_seg + seg) * a.cap2;
+            const float2 *__restrict__ lg = a.logs + ((size_t)b * n_seg + min(seg, n_seg - 1)) * a.cap2;
+            float2 pre[kPre];
+#pragma unroll
+            for (int j = 0; j < kPre; ++j)
+                pre[j] = lg[min(j, a.cap2 - 1)];   // always in bounds; entries past cnt are ignored below
             int longest = cnt;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1)
                 longest = max(longest, __shfl_xor(longest, o));
-            for (int j = 0; j < longest; ++j)
+#pragma unroll
+            for (int j = 0; j < kPre; ++j) {
+                if (j >= longest)
+                    break;
+                bool on = j < cnt;
+                const float sv = pre[j].x;
+                const int si = __float_as_int(pre[j].y);
+                if (on && (cached ? sorted_contains(smask[w], 0, me - mb, si) : sorted_contains(a.mask_items, mb, me, si)))
+                    on = false;
+                n_valid += __popcll(__ballot(on));
+                list_offer(e, sv, si, on, a.k, lane);
+            }
+            for (int j = kPre; j < longest; ++j)
                 offer(j < cnt, lg, j);
         }
     } else {
