@@ -17,13 +17,21 @@ __device__ __forceinline__ bool better(float av, int ai, float bv, int bi)
     return av > bv || (av == bv && ai < bi);
 }
 
+// lane i <- lane i-1 across the whole wave as ONE VALU instruction (DPP wave_shr:1, GFX9 family incl. gfx950);
+// __shfl_up would go through the LDS crossbar (ds_bpermute, ~100 cycles) -- the insert below is a serial chain, so
+// that latency was most of the selection kernels' time.  Lane 0 keeps its own value (it is never read: pos >= 0).
+__device__ __forceinline__ int wave_shr1(int v)
+{
+    return __builtin_amdgcn_update_dpp(v, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+
 // insert (cv, ci) (wave-uniform) into the sorted 64-entry list; entries past the end fall off
 __device__ __forceinline__ void list_insert(TopList &e, float cv, int ci, int lane)
 {
     const bool beats = better(e.v, e.i, cv, ci);
     const int pos = __popcll(__ballot(beats));  // sorted list: `beats` is a prefix of lanes
-    const float uv = __shfl_up(e.v, 1);
-    const int ui = __shfl_up(e.i, 1);
+    const float uv = __int_as_float(wave_shr1(__float_as_int(e.v)));
+    const int ui = wave_shr1(e.i);
     if (lane == pos) {
         e.v = cv;
         e.i = ci;
