@@ -2,7 +2,6 @@
 the sharded result must be bit-identical to the single-GPU result."""
 import numpy as np
 import pytest
-import torch
 
 from conftest import bits
 from test_dist_cpu import run_ranks

@@ -19,7 +19,6 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from . import _capi
 from .graph import NormGraph
 from .propagate import DEFAULT_SPLIT_THRESHOLD, DeviceCSR, spmm
 
