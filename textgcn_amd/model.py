@@ -335,8 +335,22 @@ class LightGCN(nn.Module):
 
     @torch.no_grad()
     def predict(self, users, save: bool = False, with_scores: bool = False):
-        self.training = False
         users = np.asarray(list(users) if not isinstance(users, np.ndarray) else users, dtype=np.int64)
+        val, idx = self.predict_tensors(users)
+        predictions = idx.tolist() if idx is not None else []
+        scores = val.tolist() if val is not None else []
+        if save:
+            self._save_predictions(users, predictions, scores)
+        if with_scores:
+            return predictions, scores
+        return predictions
+
+    @torch.no_grad()
+    def predict_tensors(self, users):
+        """The device part of `predict`: (scores [n, kmax] fp32, items [n, kmax] int64) on the GPU, or (None, None)
+        for an empty user list.  `predict` adds the reference's list conversion (base_model.py:265-266)."""
+        self.training = False
+        users = np.asarray(users, dtype=np.int64)
         kmax = max(self.k)
         y_val, y_idx = [], []
         users_emb, items_emb = self.representation
@@ -370,13 +384,9 @@ class LightGCN(nn.Module):
             y_idx.append(i)
         for side in streams:
             main.wait_stream(side)
-        predictions = torch.cat(y_idx).tolist() if y_idx else []
-        scores = torch.cat(y_val).tolist() if y_val else []
-        if save:
-            self._save_predictions(users, predictions, scores)
-        if with_scores:
-            return predictions, scores
-        return predictions
+        if not y_idx:
+            return None, None
+        return torch.cat(y_val), torch.cat(y_idx)
 
     def _save_predictions(self, users, predictions, scores):
         """predictions.tsv in the reference's format (base_model.py:268-273): original ids, python-list cells."""
