@@ -155,27 +155,36 @@ class LTRLinear(LightGCN):
         return LightGCN.evaluate(self, *args, **kwargs)
 
     @torch.no_grad()
-    def predict(self, users, save: bool = False, with_scores: bool = False):
+    def predict_tensors(self, users):
+        """Device part of predict (see LightGCN.predict_tensors) with the folded LTR score."""
+        users_np = np.asarray(users, dtype=np.int64)
+        if 'score_batchwise' not in self.__dict__:   # still inside __init__: the loaded base model is evaluated as LightGCN
+            return LightGCN.predict_tensors(self, users_np)
         self._packed = None   # item operand is rebuilt once per predict call
         self.training = False
-        users_np = np.asarray(list(users) if not isinstance(users, np.ndarray) else users, dtype=np.int64)
-        if 'score_batchwise' not in self.__dict__:   # still inside __init__ (base model evaluation)
-            return LightGCN.predict(self, users_np, save, with_scores)
         kmax = max(self.k)
         users_emb, items_emb = self.representation
         users_emb, items_emb = users_emb.contiguous(), items_emb.contiguous()
         ia = self._pack_items(items_emb)
         y_val, y_idx = [], []
-        for j in range(0, len(users_np), self.batch_size):
+        main = torch.cuda.current_stream(self.device)
+        streams = self._predict_streams()       # chunks round-robin on a few streams, as in LightGCN.predict_tensors
+        for n, j in enumerate(range(0, len(users_np), self.batch_size)):
             batch = users_np[j:j + self.batch_size]
             ids = torch.from_numpy(batch).to(self.device)
-            ua = self._fold_users(users_emb, ids, ids)
             rp, it = self._batch_mask(batch)
-            v, i = scoring.score_topk(ua, ia, kmax, mask_rowptr=rp, mask_items=it, round4=True)
+            slot = n % len(streams)
+            side = streams[slot]
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                ua = self._fold_users(users_emb, ids, ids)
+                v, i = scoring.score_topk(ua, ia, kmax, mask_rowptr=rp, mask_items=it, round4=True, slot=slot)
+            for t in (ids, rp, it, ua, v, i):
+                t.record_stream(side)
             y_val.append(v)
             y_idx.append(i)
-        predictions = torch.cat(y_idx).tolist() if y_idx else []
-        scores = torch.cat(y_val).tolist() if y_val else []
-        if save:
-            self._save_predictions(users_np, predictions, scores)
-        return (predictions, scores) if with_scores else predictions
+        for side in streams:
+            main.wait_stream(side)
+        if not y_idx:
+            return None, None
+        return torch.cat(y_val), torch.cat(y_idx)
