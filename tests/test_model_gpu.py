@@ -207,3 +207,38 @@ def test_predict_edge_cases(golden, cuda, tmp_path):
     full = m.predict(range(ds.n_users))
     assert m.predict([3]) == [full[3]]
     assert m.predict(np.array([4, 0, 4, 2])) == [full[4], full[0], full[4], full[2]]
+
+
+def test_predict_streams_do_not_change_results(cuda, tmp_path):
+    """Many small chunks round-robin on three streams (shared inputs, per-stream scratch) vs one stream, and vs the
+    unfused dense -> mask -> top-k path: identical lists."""
+    import pandas as pd
+    from textgcn_amd import scoring, synth
+    from textgcn_amd.graph import NormGraph, train_mask_csr
+    from textgcn_amd.model import LightGCN
+    n_u, n_i = 3000, 9000
+    u, i = synth.interactions(n_u, n_i, 60000, seed=8)
+    g = NormGraph.from_pairs(u, i, n_u, n_i)
+    rp, items = train_mask_csr(u, i, n_u)
+    ds = types.SimpleNamespace(n_users=n_u, n_items=n_i, graph=g, norm_matrix=None, mask_rowptr=rp, mask_items=items,
+                               true_test_lil=[[0]], train_user_dict=None, test_df=pd.DataFrame({'user_id': [0], 'asin': [0]}),
+                               user_mapping=pd.DataFrame({'remap_id': [0], 'org_id': ['u']}),
+                               item_mapping=pd.DataFrame({'remap_id': [0], 'org_id': ['i']}))
+    m = LightGCN(_params(k=[20, 40], batch_size=64, save_path=str(tmp_path), exact=False), ds)
+    m.predict_chunk = 128
+    users = np.random.default_rng(0).permutation(n_u)
+    m.predict_streams, m._streams = 3, None
+    v3, i3 = m.predict_tensors(users)
+    m.predict_streams, m._streams = 1, None
+    v1, i1 = m.predict_tensors(users)
+    assert torch.equal(i3, i1) and torch.equal(v3, v1)
+    with torch.no_grad():
+        ue, ie = m.representation
+    s = scoring.score_dense(ue.contiguous(), ie.contiguous(), user_ids=torch.from_numpy(users).to(cuda))
+    cnt = rp[users + 1] - rp[users]
+    brp = np.zeros(len(users) + 1, dtype=np.int32)
+    np.cumsum(cnt, out=brp[1:])
+    bit = np.concatenate([items[rp[x]:rp[x + 1]] for x in users])
+    scoring.mask_train(s, torch.from_numpy(brp).to(cuda), torch.from_numpy(bit).to(cuda))
+    rv, ri = scoring.topk(s, 40, round4=True)
+    assert torch.equal(i3, ri) and torch.equal(v3, rv)
