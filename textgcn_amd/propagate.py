@@ -39,7 +39,11 @@ class DeviceCSR:
         # longest rows first: the launch's tail is its last long row (scheduling only; results do not depend on it)
         lens = np.diff(rowptr)
         self.row_order = None
-        if order_rows:
+        # Longest-first hand-out pays when the launch's tail -- one wave finishing its longest row -- is a visible
+        # share of the launch: (longest work item) x (waves the chip runs at once) vs total entries.  On huge graphs
+        # (config 4: 0.04) it only scatters the CSR reads (measured 5 % slower), so rows keep their natural order.
+        longest = min(int(lens.max()) if len(lens) else 0, split_threshold or (1 << 30))
+        if order_rows and self.nnz and longest * 8192 > 0.1 * self.nnz:
             order = np.argsort(-lens, kind='stable')
             if block_specs:
                 # one phase per row block that shares a gather table (item rows, then user rows), longest first inside
