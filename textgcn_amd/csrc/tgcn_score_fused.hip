@@ -480,7 +480,9 @@ Plan make_plan(int B, int I, int d, int k)
         return p;
     }
     const int user_tiles = (B + kUsersPerWG - 1) / kUsersPerWG;
-    int S = (512 + user_tiles - 1) / user_tiles;  // >= 2 workgroups per CU in flight (48 was not reliably better)
+    // 3 workgroups per CU (what registers + LDS admit) when the user tiles alone give >= 1 per CU, else 2 per CU:
+    // with few user tiles more splits mean more prologues for no reliable gain (48 splits: 142 us on one box, 218 on another)
+    int S = ((user_tiles >= 64 ? 768 : 512) + user_tiles - 1) / user_tiles;
     const int max_S = max(1, I / (8 * kStage));   // at least 8 stages per split
     S = max(1, min(min(S, 32), max_S));
     if (const char *dbg = getenv("TGCN_DEBUG_SPLITS"))  // dev only
