@@ -104,6 +104,35 @@ int tgcn_spmm_blocked_f32(const tgcn_block_plan_t *plans, int32_t n_plans, const
                           int64_t n_src_rows, int32_t d, float *Y, const float *acc_in, float *acc_out,
                           float acc_div, const tgcn_split_plan_t *split, tgcn_stream_t stream);
 
+/* XCD-affine segmented form of the same product (d in {64, 128, 256}).  Rows are cut at column-block boundaries
+ * into segments; every segment position is summed (sequential fmaf chain from +0) by one d/4-lane group into
+ * workspace[slot, 0:d]; a second launch adds the slots [seg_row_ptr[i], seg_row_ptr[i+1])
+ * of row seg_rows[i] in slot order and applies the Y / acc epilogue.  The host lays positions out so that all
+ * segments met by one workgroup (tgcn_segment_positions_per_workgroup(d) consecutive positions) belong to column
+ * blocks of one class, and
+ * workgroups g, g+8, g+16 ... share a class: workgroups are dealt round-robin over the 8 XCDs, so every XCD's 4 MB
+ * L2 serves 1/8 of the gathered table instead of missing to the Infinity Cache.  Placement is a speed matter only.
+ * `direct_rows` are summed by one wavefront each exactly as in tgcn_spmm_csr_f32.  n_segments must be a multiple of
+ * the per-workgroup count; empty positions (begin == end) are padding.  Deterministic; differs from the one-chain-per-row
+ * result in rounding only (same contract as the long-row split).  Built by textgcn_amd.graph.segment_plan_arrays. */
+typedef struct tgcn_segment_plan {
+    int32_t n_segments;
+    int32_t n_seg_rows;
+    int32_t n_direct_rows;
+    int32_t n_slots;
+    const int32_t *seg_meta;    /* [n_segments][4]: {begin, end (offsets into colidx/vals), workspace slot, 0}; 16-B aligned */
+    const int32_t *seg_rows;    /* [n_seg_rows] local row ids */
+    const int32_t *seg_row_ptr; /* [n_seg_rows + 1] slot ranges */
+    const int32_t *direct_rows; /* [n_direct_rows] local row ids */
+    float *workspace;           /* [n_slots, d] fp32 scratch */
+} tgcn_segment_plan_t;
+
+int32_t tgcn_segment_positions_per_workgroup(int32_t d); /* 0 for unsupported d */
+int tgcn_spmm_segmented_f32(const tgcn_segment_plan_t *plan, const int32_t *rowptr, const int32_t *colidx,
+                            const float *vals, int64_t n_rows, const float *X, int64_t n_src_rows, int32_t d,
+                            float *Y, const float *acc_in, float *acc_out, float acc_div, uint32_t flags,
+                            tgcn_stream_t stream);
+
 /* K5: S[b, i] = <U[user_ids[b], :], It[i, :]>  (user_ids == NULL: U rows 0..B-1), S row stride lds.
  *   replaces torch.matmul(users_emb, items_emb.t())                TextGCN/base_model.py:179
  *   (+ the users_emb[batch_users] gather at base_model.py:254)

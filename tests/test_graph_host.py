@@ -149,3 +149,47 @@ def test_block_plan_arrays_segments_partition_rows(golden):
                 assert np.all((seg >= c0 + b * width) & (seg < c0 + (b + 1) * width))
     with pytest.raises(ValueError):
         block_plan_arrays(gr.rowptr, gr.colidx, 0, u, 0, u, 100)                # wrong column range
+
+
+def test_segment_plan_covers_every_entry_once_in_order():
+    """XCD-affine segment plan (graph.segment_plan_arrays): every stored entry of a phase row lies in exactly one
+    segment, a row's slots follow its entry order, positions of one workgroup share a column-block class."""
+    from textgcn_amd.graph import NormGraph, segment_plan_arrays
+    from textgcn_amd import synth
+    u, i = synth.interactions(300, 170, 6000, seed=3)
+    g = NormGraph.from_pairs(u, i, 300, 170)
+    U, N = g.n_users, g.n
+    for nb_items, nb_users, S, max_len in ((8, 4, 16, 128), (16, 0, 8, 5), (2, 8, 4, 7)):
+        phases = [(U, N, 0, U, nb_items)] + ([(0, U, U, N, nb_users)] if nb_users else [])
+        p = segment_plan_arrays(g.rowptr, g.colidx, phases, S, max_len)
+        assert len(p['seg_beg']) % S == 0
+        live = p['seg_end'] > p['seg_beg']
+        assert (p['seg_end'] - p['seg_beg'])[live].max() <= max_len
+        # coverage: entries of segment rows exactly once
+        mark = np.zeros(g.nnz, dtype=np.int32)
+        for b, e in zip(p['seg_beg'][live], p['seg_end'][live]):
+            mark[b:e] += 1
+        seg_row_mask = np.zeros(N, dtype=bool)
+        seg_row_mask[p['seg_rows']] = True
+        ent_row = np.repeat(np.arange(N), np.diff(g.rowptr))
+        assert np.array_equal(mark == 1, seg_row_mask[ent_row]) and mark.max() <= 1
+        assert sorted(np.concatenate([p['seg_rows'], p['direct_rows']]).tolist()) == list(range(N))
+        # slots: unique, a row's slots ascending with the entry offset
+        slots = p['seg_slot'][live]
+        assert len(np.unique(slots)) == len(slots) == p['n_slots']
+        beg_of_slot = np.empty(p['n_slots'], dtype=np.int64)
+        beg_of_slot[slots] = p['seg_beg'][live]
+        for k, r in enumerate(p['seg_rows']):
+            s0, s1 = p['seg_row_ptr'][k], p['seg_row_ptr'][k + 1]
+            b = beg_of_slot[s0:s1]
+            assert s1 > s0 and np.all(np.diff(b) > 0) and g.rowptr[r] <= b[0] and b[-1] < g.rowptr[r + 1]
+        # class affinity: all live segments of a workgroup read columns of one block class
+        first_col = g.colidx[np.minimum(p['seg_beg'], g.nnz - 1)]
+        for (r0, r1, c0, c1, nb) in phases:
+            width = -(-(c1 - c0) // nb)
+            in_phase = live & (first_col >= c0) & (first_col < c1)
+            blk = (first_col - c0) // width
+            wg = np.arange(len(live)) // S
+            for w in np.unique(wg[in_phase]):
+                cls = np.unique(blk[in_phase & (wg == w)] % 8) if nb >= 8 else np.unique(blk[in_phase & (wg == w)])
+                assert len(cls) == 1

@@ -309,3 +309,45 @@ def test_edge_cases_empty_and_isolated(cuda, oracle):
     ref, _ = oracle.propagate(idx, val, x.cpu().numpy(), 2)
     assert np.array_equal(bits(out1), bits(ref))
     assert torch.equal(Propagator(g1, cuda).forward(x, 0), x)   # K = 0: representation is E0
+
+
+@pytest.mark.parametrize('d', [64, 128, 256])
+@pytest.mark.parametrize('blocks', [(8, 0), (4, 8), (16, 2)])
+@pytest.mark.parametrize('max_len', [128, 6])
+def test_segmented_xcd_affine_kernel(cuda, oracle, d, blocks, max_len):
+    """tgcn_spmm_segmented_f32: rows cut at column-block boundaries, segment sums added in slot order.  Direct rows
+    are bit-exact, segmented rows agree with the one-chain result to rounding, runs are identical (no atomics), and the
+    fused epilogue (acc_in/acc_out/acc_div, Y optional) matches the oracle's layer sum."""
+    from textgcn_amd.propagate import Propagator, spmm
+    gr = _random_graph(1500, 700, 30000, seed=5, zipf=1.0)
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((gr.n, d)).astype(np.float32)
+    e0 = rng.standard_normal((gr.n, d)).astype(np.float32)
+    idx, val = gr.to_coo()
+    ref = oracle.spmm_coo(idx, val, x)
+    prop = Propagator(gr, cuda)
+    prop.csr.configure_segments(list(blocks), max_len=max_len)    # specs: (user rows, item rows)
+    xd, e0d = torch.from_numpy(x).to(cuda), torch.from_numpy(e0).to(cuda)
+    outs = []
+    for unroll in (0, 4, 16):
+        y = torch.full((gr.n, d), float('nan'), device=cuda)
+        spmm(prop.csr, xd, y=y, segmented=True, unroll=unroll)
+        outs.append(y.cpu().numpy())
+    assert normwise(outs[0], ref) <= 5e-6    # rounding only (the path's tolerance is 1e-4)
+    assert np.array_equal(bits(outs[0]), bits(outs[1])) and np.array_equal(bits(outs[0]), bits(outs[2]))
+    direct = np.zeros(gr.n, dtype=bool)
+    if blocks[0] == 0:
+        direct[:gr.n_users] = True
+    if blocks[1] == 0:
+        direct[gr.n_users:] = True
+    direct |= gr.degrees() == 0
+    assert np.array_equal(bits(outs[0][direct]), bits(ref[direct]))
+    # fused epilogue on top of the segmented sums
+    acc = torch.full((gr.n, d), float('nan'), device=cuda)
+    spmm(prop.csr, xd, y=None, acc_in=e0d, acc_out=acc, acc_div=4.0, segmented=True)
+    want = (e0 + outs[0]) / np.float32(4.0)
+    assert np.array_equal(bits(acc.cpu().numpy()), bits(want.astype(np.float32)))
+    # whole forward through the segmented path
+    full = prop.forward(e0d, 3, segmented=True).cpu().numpy()
+    exact = prop.forward(e0d, 3, exact=True).cpu().numpy()
+    assert normwise(full, exact) <= 5e-6

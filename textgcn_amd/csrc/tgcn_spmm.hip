@@ -249,6 +249,175 @@ __global__ __launch_bounds__(256) void k_spmm_group(const SpmmArgs a)
     }
 }
 
+// XCD-affine segmented launch (tgcn_spmm_segmented_f32).  Workgroups [0, n_seg_wgs) walk kSegIters x 4 waves x R
+// segment positions each (R = 64/G segments per wave, one per G-lane group, float4 per lane): a wave's next segment
+// descriptor is loaded two steps ahead and its first G (col, val) pairs one step ahead, issued AFTER the current
+// step's row gathers so that waiting for the gathers does not wait for them -- a segment holds ~10 entries, so an
+// unpipelined wave would spend its time in the descriptor -> (col, val) -> gather -> store latency chain.  The
+// remaining workgroups own one direct row per wave.
+constexpr int kSegIters = 8;
+
+struct SegArgs {
+    const int4 *__restrict__ seg_meta;  // {beg, end, slot, 0} per position
+    const int *__restrict__ direct_rows;
+    int n_seg_wgs;
+    int n_direct;
+};
+
+template <int G, int UNROLL>
+__global__ __launch_bounds__(256) void k_spmm_seg(const SpmmArgs a, const SegArgs g)
+{
+    constexpr int R = kWave / G;
+    constexpr int D = 4 * G;
+    constexpr int VEC = D / kWave;
+    const int lane = lane_id();
+    const int wg = blockIdx.x;
+    const int wv = threadIdx.x >> 6;
+    if (wg >= g.n_seg_wgs) {
+        const int w = uniform((wg - g.n_seg_wgs) * 4 + wv);
+        if (w >= g.n_direct)
+            return;
+        const int row = g.direct_rows[w];
+        float acc[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k)
+            acc[k] = 0.0f;
+        accumulate_wave<VEC, VEC == 4 ? 8 : 16>(a, a.rowptr[row], a.rowptr[row + 1], lane, acc);
+        epilogue<VEC>(a, (size_t)row * a.d + lane * VEC, acc);
+        return;
+    }
+    const int gl = lane & (G - 1);
+    // position of step t: ((wg * kSegIters + t) * 4 + wv) * R + lane / G
+    const int4 *meta = g.seg_meta + ((size_t)wg * kSegIters * 4 + wv) * R + lane / G;
+    constexpr int kStep = 4 * R;
+    const float *__restrict__ Xl = a.X + gl * 4;
+    int4 m_cur = meta[0];
+    int4 m_nxt = meta[kStep];
+    int c_cur, c_nxt = 0;
+    float v_cur, v_nxt = 0.0f;
+    {
+        const int idx = max(min(m_cur.x + gl, m_cur.y - 1), 0);
+        c_cur = a.colidx[idx];
+        v_cur = a.vals[idx];
+    }
+    for (int t = 0; t < kSegIters; ++t) {
+        const int beg = m_cur.x, end = m_cur.y;
+        const int n = min(G, end - beg);  // uniform inside a group; 0 for padding
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 x[UNROLL];
+        float vv[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const int jj = max(min(u, n - 1), 0);
+            const int cj = __shfl(c_cur, jj, G);
+            vv[u] = __shfl(v_cur, jj, G);
+            x[u] = *reinterpret_cast<const float4 *>(Xl + (size_t)cj * D);
+        }
+        // prefetch: descriptor of step t+2, (col, val) of step t+1 (clamped, unconditional loads)
+        int4 m_n2 = m_nxt;
+        if (t + 2 < kSegIters)
+            m_n2 = meta[(t + 2) * kStep];
+        if (t + 1 < kSegIters) {
+            const int idx = max(min(m_nxt.x + gl, m_nxt.y - 1), 0);
+            c_nxt = a.colidx[idx];
+            v_nxt = a.vals[idx];
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            if (u < n) {
+                acc.x = fmaf(vv[u], x[u].x, acc.x);
+                acc.y = fmaf(vv[u], x[u].y, acc.y);
+                acc.z = fmaf(vv[u], x[u].z, acc.z);
+                acc.w = fmaf(vv[u], x[u].w, acc.w);
+            }
+        }
+        // the rest of the segment (entries UNROLL.. of the first G, then further G-entry slabs): not pipelined
+        int c = c_cur;
+        float v = v_cur;
+        for (int base = beg, j0 = UNROLL; base < end; base += G, j0 = 0) {
+            const int nn = min(G, end - base);
+            if (base != beg) {
+                const int idx = min(base + gl, end - 1);
+                c = a.colidx[idx];
+                v = a.vals[idx];
+            }
+            for (int j = j0; j < nn; j += UNROLL) {
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    const int jj = min(j + u, nn - 1);
+                    const int cj = __shfl(c, jj, G);
+                    vv[u] = __shfl(v, jj, G);
+                    x[u] = *reinterpret_cast<const float4 *>(Xl + (size_t)cj * D);
+                }
+#pragma unroll
+                for (int u = 0; u < UNROLL; ++u) {
+                    if (j + u < nn) {
+                        acc.x = fmaf(vv[u], x[u].x, acc.x);
+                        acc.y = fmaf(vv[u], x[u].y, acc.y);
+                        acc.z = fmaf(vv[u], x[u].z, acc.z);
+                        acc.w = fmaf(vv[u], x[u].w, acc.w);
+                    }
+                }
+            }
+        }
+        if (end > beg)
+            *reinterpret_cast<float4 *>(a.ws + (size_t)m_cur.z * D + gl * 4) = acc;
+        m_cur = m_nxt, m_nxt = m_n2;
+        c_cur = c_nxt, v_cur = v_nxt;
+    }
+}
+
+template <int G>
+int launch_seg(const SpmmArgs &a, const SegArgs &g, int unroll, int grid, hipStream_t s)
+{
+    switch (unroll) {
+        case 4: hipLaunchKernelGGL((k_spmm_seg<G, 4>), dim3(grid), dim3(256), 0, s, a, g); break;
+        default: hipLaunchKernelGGL((k_spmm_seg<G, 8>), dim3(grid), dim3(256), 0, s, a, g); break;
+    }
+    return check_launch("k_spmm_seg");
+}
+
+// G lanes per row (float4 each), 64/G rows per wave: y = ((p0 + p1) + p2) + ... in slot order, then the epilogue.
+// The acc_in row is fetched together with the first slots (it does not depend on them).
+template <int G>
+__global__ __launch_bounds__(256) void k_spmm_seg_reduce(const SpmmArgs a, const int *__restrict__ rows,
+                                                         const int *__restrict__ row_ptr, int n)
+{
+    constexpr int R = kWave / G;
+    constexpr int D = 4 * G;
+    const int lane = lane_id();
+    const int gl = lane & (G - 1);
+    const int l = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R + lane / G;
+    if (l >= n)
+        return;
+    const int row = rows[l];
+    const int c0 = row_ptr[l], c1 = row_ptr[l + 1];
+    const size_t off = (size_t)row * D + gl * 4;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.acc_out)
+        t = *reinterpret_cast<const float4 *>(a.acc_in + off);
+    const float *ws = a.ws + gl * 4;
+    float4 y = *reinterpret_cast<const float4 *>(ws + (size_t)c0 * D);
+    for (int c = c0 + 1; c < c1; c += 8) {
+        float4 p[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            p[u] = *reinterpret_cast<const float4 *>(ws + (size_t)min(c + u, c1 - 1) * D);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (c + u < c1)
+                y.x = y.x + p[u].x, y.y = y.y + p[u].y, y.z = y.z + p[u].z, y.w = y.w + p[u].w;
+    }
+    if (a.Y)
+        *reinterpret_cast<float4 *>(a.Y + off) = y;
+    if (a.acc_out) {
+        t.x = t.x + y.x, t.y = t.y + y.y, t.z = t.z + y.z, t.w = t.w + y.w;
+        if (a.acc_div != 1.0f)
+            t.x = t.x / a.acc_div, t.y = t.y / a.acc_div, t.z = t.z / a.acc_div, t.w = t.w / a.acc_div;
+        *reinterpret_cast<float4 *>(a.acc_out + off) = t;
+    }
+}
+
 // any d: wave per row, one 64-column slab at a time (re-walks the row per slab; d <= 64 is one pass)
 __global__ __launch_bounds__(256) void k_spmm_generic(const SpmmArgs a)
 {
@@ -446,4 +615,64 @@ extern "C" int tgcn_spmm_csr_f32(const int32_t *rowptr, const int32_t *colidx, c
         rc = check_launch("k_spmm_long_reduce");
     }
     return rc;
+}
+
+extern "C" int tgcn_spmm_segmented_f32(const tgcn_segment_plan_t *plan, const int32_t *rowptr, const int32_t *colidx,
+                                       const float *vals, int64_t n_rows, const float *X, int64_t n_src_rows, int32_t d,
+                                       float *Y, const float *acc_in, float *acc_out, float acc_div, uint32_t flags,
+                                       tgcn_stream_t stream)
+{
+    TGCN_REQUIRE(plan, "plan is NULL");
+    TGCN_REQUIRE(n_rows >= 0 && n_rows < INT_MAX - 256, "n_rows out of range");
+    TGCN_REQUIRE(d == 64 || d == 128 || d == 256, "segmented SpMM supports d in {64, 128, 256}");
+    TGCN_REQUIRE(n_src_rows >= 0 && n_src_rows < INT_MAX, "n_src_rows out of range");
+    if (n_rows == 0)
+        return TGCN_OK;
+    TGCN_REQUIRE(rowptr && colidx && vals && X, "rowptr / colidx / vals / X is NULL");
+    TGCN_REQUIRE(Y || acc_out, "both Y and acc_out are NULL: nothing to compute");
+    TGCN_REQUIRE(!acc_out || acc_in, "acc_out given without acc_in");
+    TGCN_REQUIRE(acc_div != 0.0f, "acc_div must be non-zero");
+    const int per_wg = tgcn_segment_positions_per_workgroup(d);
+    TGCN_REQUIRE(plan->n_segments >= 0 && plan->n_segments % per_wg == 0,
+                 "n_segments must be a multiple of tgcn_segment_positions_per_workgroup(d)");
+    TGCN_REQUIRE(plan->n_seg_rows >= 0 && plan->n_direct_rows >= 0 && plan->n_slots >= 0, "negative plan counts");
+    TGCN_REQUIRE((int64_t)plan->n_seg_rows + plan->n_direct_rows == n_rows, "plan does not cover every row once");
+    TGCN_REQUIRE(plan->n_segments == 0 || (plan->seg_meta && plan->workspace), "segment arrays are NULL");
+    TGCN_REQUIRE(plan->n_seg_rows == 0 || (plan->seg_rows && plan->seg_row_ptr && plan->workspace), "segment row arrays are NULL");
+    TGCN_REQUIRE(plan->n_direct_rows == 0 || plan->direct_rows, "direct_rows is NULL");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+
+    SpmmArgs a;
+    a.rowptr = rowptr, a.colidx = colidx, a.vals = vals, a.X = X, a.Y = Y;
+    a.acc_in = acc_in, a.acc_out = acc_out, a.acc_div = acc_div;
+    a.n_rows = (int)n_rows, a.d = d, a.row_waves = 0, a.row_order = nullptr;
+    a.threshold = INT_MAX, a.n_chunks = 0, a.chunk_beg = nullptr, a.chunk_end = nullptr, a.ws = plan->workspace;
+    SegArgs g;
+    g.seg_meta = reinterpret_cast<const int4 *>(plan->seg_meta), g.direct_rows = plan->direct_rows;
+    g.n_seg_wgs = plan->n_segments / per_wg, g.n_direct = plan->n_direct_rows;
+    const int unroll = (flags >> 8) & 0xff;
+    const int grid = g.n_seg_wgs + (g.n_direct + 3) / 4;
+    if (grid > 0) {
+        const int rc = d == 64 ? launch_seg<16>(a, g, unroll, grid, s) : d == 128 ? launch_seg<32>(a, g, unroll, grid, s)
+                                                                                 : launch_seg<64>(a, g, unroll, grid, s);
+        if (rc != TGCN_OK)
+            return rc;
+    }
+    if (plan->n_seg_rows > 0) {
+        const int rows_per_wg = 4 * (256 / d);
+        const int rgrid = (plan->n_seg_rows + rows_per_wg - 1) / rows_per_wg;
+        if (d == 64)
+            hipLaunchKernelGGL((k_spmm_seg_reduce<16>), dim3(rgrid), dim3(256), 0, s, a, plan->seg_rows, plan->seg_row_ptr, plan->n_seg_rows);
+        else if (d == 128)
+            hipLaunchKernelGGL((k_spmm_seg_reduce<32>), dim3(rgrid), dim3(256), 0, s, a, plan->seg_rows, plan->seg_row_ptr, plan->n_seg_rows);
+        else
+            hipLaunchKernelGGL((k_spmm_seg_reduce<64>), dim3(rgrid), dim3(256), 0, s, a, plan->seg_rows, plan->seg_row_ptr, plan->n_seg_rows);
+        return check_launch("k_spmm_seg_reduce");
+    }
+    return TGCN_OK;
+}
+
+extern "C" int32_t tgcn_segment_positions_per_workgroup(int32_t d)
+{
+    return (d == 64 || d == 128 || d == 256) ? kSegIters * 4 * (256 / d) : 0;
 }

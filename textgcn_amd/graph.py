@@ -190,6 +190,89 @@ def block_plan_arrays(rowptr, colidx, row_begin, row_end, col_lo, col_hi, block_
     return blkptr.astype(np.int32), n_blocks
 
 
+def segment_plan_arrays(rowptr, colidx, phases, segs_per_wg, max_len=128, n_classes=8):
+    """Host arrays of a tgcn_segment_plan_t (XCD-affine column blocking, include/tgcn.h).
+
+    phases: list of (row_begin, row_end, col_lo, col_hi, n_blocks) -- row ranges whose entries fall in one column
+    range, cut into n_blocks column blocks (a multiple or a divisor of n_classes).  A row's entries inside one block
+    form a segment (pieces of at most max_len entries); every piece gets a workspace slot, a row's slots are
+    contiguous and in entry order, so adding them in slot order is deterministic.  Pieces are laid out so that the
+    workgroup that owns positions [g*segs_per_wg, (g+1)*segs_per_wg) only meets column blocks of class g % n_classes:
+    workgroups are dealt round-robin over the 8 XCDs, so each XCD's L2 sees 1/8 of the gathered table (speed only --
+    results never depend on the placement).  Rows outside every phase, and empty rows, are `direct` rows.
+    """
+    rowptr = np.asarray(rowptr, dtype=np.int64)
+    n_rows = len(rowptr) - 1
+    direct = np.ones(n_rows, dtype=bool)
+    S = int(segs_per_wg)
+    pos_beg, pos_end, pos_slot, seg_rows, seg_row_slots = [], [], [], [], []
+    slot_base = 0
+    for (r0, r1, c0, c1, nb) in phases:
+        nb = int(nb)
+        if nb % n_classes and n_classes % nb:
+            raise ValueError('n_blocks must be a multiple or a divisor of n_classes')
+        n_r = int(r1 - r0)
+        a, b = int(rowptr[r0]), int(rowptr[r1])
+        cols = np.asarray(colidx[a:b], dtype=np.int64)
+        if len(cols) and (cols.min() < c0 or cols.max() >= c1):
+            raise ValueError('entries outside the declared column range')
+        lens = np.diff(rowptr[r0:r1 + 1])
+        width = -(-(c1 - c0) // nb)
+        span = np.int64(c1 - c0 + 1)
+        key = np.repeat(np.arange(n_r, dtype=np.int64), lens) * span + (cols - c0)
+        base = np.arange(n_r, dtype=np.int64) * span
+        blkptr = np.empty((nb + 1, n_r), dtype=np.int64)
+        for blk in range(nb):
+            blkptr[blk] = a + np.searchsorted(key, base + min(blk * width, c1 - c0), side='left')
+        blkptr[nb] = rowptr[r0 + 1:r1 + 1]
+        pieces = -(-(blkptr[1:] - blkptr[:-1]) // max_len)           # [nb, n_r]
+        row_slots = pieces.sum(axis=0)
+        row_base = slot_base + np.cumsum(row_slots) - row_slots
+        blk_off = np.cumsum(pieces, axis=0) - pieces
+        has = row_slots > 0
+        direct[r0:r1] = ~has
+        seg_rows.append(r0 + np.nonzero(has)[0])
+        seg_row_slots.append(row_slots[has])
+        slot_base += int(row_slots.sum())
+        n_sub = max(1, nb // n_classes)
+        for sub in range(n_sub):
+            classes = [[] for _ in range(n_classes)]
+            for x in range(n_classes):
+                if nb >= n_classes:
+                    blk, part, parts = sub * n_classes + x, 0, 1
+                else:
+                    blk, part, parts = x % nb, x // nb, n_classes // nb
+                cnt = pieces[blk]
+                rr = np.repeat(np.arange(n_r, dtype=np.int64), cnt)
+                within = np.arange(int(cnt.sum()), dtype=np.int64) - np.repeat(np.cumsum(cnt) - cnt, cnt)
+                beg = blkptr[blk][rr] + within * max_len
+                end = np.minimum(beg + max_len, blkptr[blk + 1][rr])
+                slot = row_base[rr] + blk_off[blk][rr] + within
+                lo, hi = len(beg) * part // parts, len(beg) * (part + 1) // parts
+                classes[x] = (beg[lo:hi], end[lo:hi], slot[lo:hi])
+            L = max(len(c[0]) for c in classes)
+            L = -(-L // S) * S
+            if L == 0:
+                continue
+            tb = np.zeros((n_classes, L), dtype=np.int64)
+            te = np.zeros((n_classes, L), dtype=np.int64)
+            ts = np.zeros((n_classes, L), dtype=np.int64)
+            for x, (cb, ce, cs) in enumerate(classes):
+                tb[x, :len(cb)], te[x, :len(cb)], ts[x, :len(cb)] = cb, ce, cs
+            inter = lambda t: t.reshape(n_classes, L // S, S).transpose(1, 0, 2).reshape(-1)   # noqa: E731
+            pos_beg.append(inter(tb)), pos_end.append(inter(te)), pos_slot.append(inter(ts))
+    cat = lambda xs: np.concatenate(xs) if xs else np.zeros(0, dtype=np.int64)   # noqa: E731
+    slots = cat(seg_row_slots)
+    seg_row_ptr = np.zeros(len(slots) + 1, dtype=np.int64)
+    np.cumsum(slots, out=seg_row_ptr[1:])
+    return {
+        'seg_beg': cat(pos_beg).astype(np.int32), 'seg_end': cat(pos_end).astype(np.int32),
+        'seg_slot': cat(pos_slot).astype(np.int32), 'seg_rows': cat(seg_rows).astype(np.int32),
+        'seg_row_ptr': seg_row_ptr.astype(np.int32), 'direct_rows': np.nonzero(direct)[0].astype(np.int32),
+        'n_slots': int(slot_base), 'segs_per_wg': S,
+    }
+
+
 def train_mask_csr(train_u, train_i, n_users):
     """CSR over all users of their train items (ascending): the device form of
     base_model.py:257 `train_user_dict[batch_users].explode()`.  Returns (rowptr int64 [U+1], items int32)."""

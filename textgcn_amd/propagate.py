@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _capi
-from .graph import NormGraph, block_plan_arrays, split_plan_arrays
+from .graph import NormGraph, block_plan_arrays, segment_plan_arrays, split_plan_arrays
 
 DEFAULT_SPLIT_THRESHOLD = 1024
 DEFAULT_BLOCK_BYTES = 3 << 20   # of X per column block: fits an XCD's 4 MB L2 next to the streaming CSR traffic
@@ -64,6 +64,9 @@ class DeviceCSR:
         self._split_threshold = split_threshold
         self._host = (rowptr, colidx) if block_specs else None
         self._block_plans = {}
+        self.segment_blocks = None    # per block_spec: number of XCD-affine column blocks (0: rows stay direct)
+        self.segment_max_len = 128
+        self._segment_plans = {}
 
     @property
     def n_chunks(self):
@@ -102,6 +105,35 @@ class DeviceCSR:
         return arr, n
 
 
+    def configure_segments(self, blocks_per_spec, max_len=128):
+        """Enable the XCD-affine segmented kernel: blocks_per_spec[i] column blocks for block_specs[i] (0 = direct)."""
+        if not self._block_specs or len(blocks_per_spec) != len(self._block_specs):
+            raise ValueError('one block count per block_spec is required')
+        self.segment_blocks = [int(b) for b in blocks_per_spec]
+        self.segment_max_len = int(max_len)
+        self._segment_plans = {}
+
+    def segment_plan(self, d):
+        """ctypes pointer to a tgcn_segment_plan_t for width d, or None when segments are not configured."""
+        if not self.segment_blocks or not any(self.segment_blocks) or d not in (64, 128, 256):
+            return None
+        if d not in self._segment_plans:
+            rowptr, colidx = self._host
+            phases = [(r0, r1, c0, c1, nb) for (r0, r1, c0, c1), nb in zip(self._block_specs, self.segment_blocks) if nb]
+            per_wg = _capi.lib().tgcn_segment_positions_per_workgroup(d)
+            h = segment_plan_arrays(rowptr, colidx, phases, per_wg, self.segment_max_len)
+            h['seg_meta'] = np.ascontiguousarray(np.stack([h['seg_beg'], h['seg_end'], h['seg_slot'],
+                                                           np.zeros_like(h['seg_beg'])], axis=1))
+            dv = {k: torch.from_numpy(v).to(self.device) for k, v in h.items() if isinstance(v, np.ndarray)}
+            ws = torch.empty((max(h['n_slots'], 1), d), dtype=torch.float32, device=self.device)
+            st = _capi.SegmentPlanStruct(len(h['seg_beg']), len(h['seg_rows']), len(h['direct_rows']), h['n_slots'],
+                                         dv['seg_meta'].data_ptr(),
+                                         dv['seg_rows'].data_ptr(), dv['seg_row_ptr'].data_ptr(),
+                                         dv['direct_rows'].data_ptr(), ws.data_ptr())
+            self._segment_plans[d] = (st, ws, dv, h)
+        return ctypes.byref(self._segment_plans[d][0])
+
+
 def _check_dense(t, name, device, rows=None, d=None):
     if not isinstance(t, torch.Tensor) or t.dtype != torch.float32:
         raise TypeError(f'{name} must be a float32 torch tensor')
@@ -114,7 +146,7 @@ def _check_dense(t, name, device, rows=None, d=None):
 
 
 def spmm(csr, x, y=None, acc_in=None, acc_out=None, acc_div=1.0, exact=False, variant=_capi.SPMM_AUTO, unroll=0,
-         vals=None, blocked=False):
+         vals=None, blocked=False, segmented=False):
     """One layer: y = A_block . x, optionally acc_out = (acc_in + y) / acc_div (see tgcn_spmm_csr_f32).
 
     x [n_src_rows, d]; y / acc_in / acc_out [n_rows, d] (y or acc_out may be None).  exact=True ignores the
@@ -137,6 +169,14 @@ def spmm(csr, x, y=None, acc_in=None, acc_out=None, acc_div=1.0, exact=False, va
         vals = csr.vals
     elif vals.dtype != torch.float32 or vals.numel() != max(csr.nnz, 1) or vals.device != dev or not vals.is_contiguous():
         raise ValueError('vals must be a contiguous float32 device tensor with one entry per stored element')
+    seg = csr.segment_plan(d) if (segmented and not exact and variant == _capi.SPMM_AUTO) else None
+    if seg is not None:
+        rc = _capi.lib().tgcn_spmm_segmented_f32(
+            seg, _capi.ptr(csr.rowptr), _capi.ptr(csr.colidx), _capi.ptr(vals), csr.n_rows, _capi.ptr(x), csr.n_src_rows, d,
+            _capi.ptr(y), _capi.ptr(acc_in), _capi.ptr(acc_out), float(acc_div), (unroll & 0xff) << 8,
+            _capi.current_stream(dev))
+        _capi.check(rc, 'tgcn_spmm_segmented_f32')
+        return y if y is not None else acc_out
     plans, n_plans = csr.block_plans(d) if (blocked and not exact and variant == _capi.SPMM_AUTO) else (None, 0)
     if n_plans:
         rc = _capi.lib().tgcn_spmm_blocked_f32(
@@ -180,7 +220,7 @@ class Propagator:
         return self._buf[d]
 
     def forward(self, e0, n_layers, single=False, exact=False, out=None, keep_layers=False, variant=_capi.SPMM_AUTO,
-                unroll=0, vals=None, blocked=False):
+                unroll=0, vals=None, blocked=False, segmented=False):
         n = self.graph.n
         _check_dense(e0, 'e0', self.device, n)
         d = e0.shape[1]
@@ -201,7 +241,7 @@ class Propagator:
                 y = ping if (k & 1) else pong
             if single:
                 spmm(self.csr, x, y=out if (last and not keep_layers) else y, exact=exact, variant=variant, unroll=unroll,
-                     vals=vals, blocked=blocked)
+                     vals=vals, blocked=blocked, segmented=segmented)
                 if last and keep_layers:
                     out.copy_(y)
             else:
@@ -209,7 +249,7 @@ class Propagator:
                 # the last layer's own Y is not needed (no store)
                 spmm(self.csr, x, y=None if (last and not keep_layers) else y, acc_in=e0 if k == 1 else acc,
                      acc_out=out if last else acc, acc_div=float(n_layers + 1) if last else 1.0, exact=exact,
-                     variant=variant, unroll=unroll, vals=vals, blocked=blocked)
+                     variant=variant, unroll=unroll, vals=vals, blocked=blocked, segmented=segmented)
             if keep_layers:
                 layers.append(y)
             x = y
