@@ -249,32 +249,28 @@ __global__ __launch_bounds__(256) void k_spmm_group(const SpmmArgs a)
     }
 }
 
-// XCD-affine segmented launch (tgcn_spmm_segmented_f32).  Workgroups [0, n_seg_wgs) walk kSegIters x 4 waves x R
-// segment positions each (R = 64/G segments per wave, one per G-lane group, float4 per lane): a wave's next segment
-// descriptor is loaded two steps ahead and its first G (col, val) pairs one step ahead, issued AFTER the current
-// step's row gathers so that waiting for the gathers does not wait for them -- a segment holds ~10 entries, so an
-// unpipelined wave would spend its time in the descriptor -> (col, val) -> gather -> store latency chain.  The
-// remaining workgroups own one direct row per wave.
-constexpr int kSegIters = 8;
-
+// XCD-affine segmented launch (tgcn_spmm_segmented_f32).  Waves [0, n_tiles) walk one tile each of the plan's
+// own (column, value) streams: 64 pairs are loaded at a time (the next 64 while the current ones are consumed),
+// rows of X are gathered 16 at a time exactly as in accumulate_wave, and every entry whose column word carries
+// bit 31 closes a piece: the running sum goes to the next workspace slot and restarts from +0.  The branch on the
+// flag is scalar (the column word sits in an SGPR after v_readlane).  The remaining waves own one direct row each.
 struct SegArgs {
-    const int4 *__restrict__ seg_meta;  // {beg, end, slot, 0} per position
+    const int2 *__restrict__ tile_meta;  // {first slot, entries}
+    const int *__restrict__ ent_col;
+    const float *__restrict__ ent_val;
     const int *__restrict__ direct_rows;
-    int n_seg_wgs;
+    int n_tiles;
+    int tile_entries;
     int n_direct;
 };
 
-template <int G, int UNROLL>
+template <int VEC, int UNROLL>
 __global__ __launch_bounds__(256) void k_spmm_seg(const SpmmArgs a, const SegArgs g)
 {
-    constexpr int R = kWave / G;
-    constexpr int D = 4 * G;
-    constexpr int VEC = D / kWave;
     const int lane = lane_id();
-    const int wg = blockIdx.x;
-    const int wv = threadIdx.x >> 6;
-    if (wg >= g.n_seg_wgs) {
-        const int w = uniform((wg - g.n_seg_wgs) * 4 + wv);
+    const int wave = uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (wave >= g.n_tiles) {
+        const int w = wave - g.n_tiles;
         if (w >= g.n_direct)
             return;
         const int row = g.direct_rows[w];
@@ -282,139 +278,134 @@ __global__ __launch_bounds__(256) void k_spmm_seg(const SpmmArgs a, const SegArg
 #pragma unroll
         for (int k = 0; k < VEC; ++k)
             acc[k] = 0.0f;
-        accumulate_wave<VEC, VEC == 4 ? 8 : 16>(a, a.rowptr[row], a.rowptr[row + 1], lane, acc);
+        accumulate_wave<VEC, (VEC == 4 ? 8 : 16)>(a, a.rowptr[row], a.rowptr[row + 1], lane, acc);
         epilogue<VEC>(a, (size_t)row * a.d + lane * VEC, acc);
         return;
     }
-    const int gl = lane & (G - 1);
-    // position of step t: ((wg * kSegIters + t) * 4 + wv) * R + lane / G
-    const int4 *meta = g.seg_meta + ((size_t)wg * kSegIters * 4 + wv) * R + lane / G;
-    constexpr int kStep = 4 * R;
-    const float *__restrict__ Xl = a.X + gl * 4;
-    int4 m_cur = meta[0];
-    int4 m_nxt = meta[kStep];
-    int c_cur, c_nxt = 0;
-    float v_cur, v_nxt = 0.0f;
-    {
-        const int idx = max(min(m_cur.x + gl, m_cur.y - 1), 0);
-        c_cur = a.colidx[idx];
-        v_cur = a.vals[idx];
-    }
-    for (int t = 0; t < kSegIters; ++t) {
-        const int beg = m_cur.x, end = m_cur.y;
-        const int n = min(G, end - beg);  // uniform inside a group; 0 for padding
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        float4 x[UNROLL];
-        float vv[UNROLL];
+    const int2 meta = g.tile_meta[wave];
+    const int n_ent = meta.y;
+    if (n_ent == 0)
+        return;
+    int slot = meta.x;
+    const size_t base = (size_t)wave * g.tile_entries;
+    const int *__restrict__ ec = g.ent_col + base;
+    const float *__restrict__ ev = g.ent_val + base;
+    const float *__restrict__ Xl = a.X + lane * VEC;
+    float *__restrict__ wsl = a.ws + lane * VEC;
+    const size_t d = (size_t)a.d;
+    float acc[VEC];
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            const int jj = max(min(u, n - 1), 0);
-            const int cj = __shfl(c_cur, jj, G);
-            vv[u] = __shfl(v_cur, jj, G);
-            x[u] = *reinterpret_cast<const float4 *>(Xl + (size_t)cj * D);
+    for (int k = 0; k < VEC; ++k)
+        acc[k] = 0.0f;
+    int c = ec[lane];  // tiles are stored whole: no bounds test
+    float v = ev[lane];
+    for (int off = 0; off < n_ent; off += kWave) {
+        const int n = min(kWave, n_ent - off);  // uniform
+        int c_nxt = 0;
+        float v_nxt = 0.0f;
+        if (off + kWave < n_ent) {  // uniform
+            c_nxt = ec[off + kWave + lane];
+            v_nxt = ev[off + kWave + lane];
         }
-        // prefetch: descriptor of step t+2, (col, val) of step t+1 (clamped, unconditional loads)
-        int4 m_n2 = m_nxt;
-        if (t + 2 < kSegIters)
-            m_n2 = meta[(t + 2) * kStep];
-        if (t + 1 < kSegIters) {
-            const int idx = max(min(m_nxt.x + gl, m_nxt.y - 1), 0);
-            c_nxt = a.colidx[idx];
-            v_nxt = a.vals[idx];
-        }
+        for (int j = 0; j < n; j += UNROLL) {
+            float x[UNROLL][VEC];
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            if (u < n) {
-                acc.x = fmaf(vv[u], x[u].x, acc.x);
-                acc.y = fmaf(vv[u], x[u].y, acc.y);
-                acc.z = fmaf(vv[u], x[u].z, acc.z);
-                acc.w = fmaf(vv[u], x[u].w, acc.w);
+            for (int u = 0; u < UNROLL; ++u) {
+                const int cj = __builtin_amdgcn_readlane(c, min(j + u, n - 1)) & 0x7fffffff;
+                load_vec<VEC>(Xl + (size_t)cj * d, x[u]);
             }
-        }
-        // the rest of the segment (entries UNROLL.. of the first G, then further G-entry slabs): not pipelined
-        int c = c_cur;
-        float v = v_cur;
-        for (int base = beg, j0 = UNROLL; base < end; base += G, j0 = 0) {
-            const int nn = min(G, end - base);
-            if (base != beg) {
-                const int idx = min(base + gl, end - 1);
-                c = a.colidx[idx];
-                v = a.vals[idx];
-            }
-            for (int j = j0; j < nn; j += UNROLL) {
 #pragma unroll
-                for (int u = 0; u < UNROLL; ++u) {
-                    const int jj = min(j + u, nn - 1);
-                    const int cj = __shfl(c, jj, G);
-                    vv[u] = __shfl(v, jj, G);
-                    x[u] = *reinterpret_cast<const float4 *>(Xl + (size_t)cj * D);
-                }
+            for (int u = 0; u < UNROLL; ++u) {
+                if (j + u < n) {
+                    const float vj = readlane_f(v, j + u);
 #pragma unroll
-                for (int u = 0; u < UNROLL; ++u) {
-                    if (j + u < nn) {
-                        acc.x = fmaf(vv[u], x[u].x, acc.x);
-                        acc.y = fmaf(vv[u], x[u].y, acc.y);
-                        acc.z = fmaf(vv[u], x[u].z, acc.z);
-                        acc.w = fmaf(vv[u], x[u].w, acc.w);
+                    for (int k = 0; k < VEC; ++k)
+                        acc[k] = fmaf(vj, x[u][k], acc[k]);
+                    if (__builtin_amdgcn_readlane(c, j + u) < 0) {  // last entry of a piece
+                        store_vec<VEC>(wsl + (size_t)slot * d, acc);
+                        ++slot;
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k)
+                            acc[k] = 0.0f;
                     }
                 }
             }
         }
-        if (end > beg)
-            *reinterpret_cast<float4 *>(a.ws + (size_t)m_cur.z * D + gl * 4) = acc;
-        m_cur = m_nxt, m_nxt = m_n2;
-        c_cur = c_nxt, v_cur = v_nxt;
+        c = c_nxt, v = v_nxt;
     }
 }
 
-template <int G>
+template <int VEC>
 int launch_seg(const SpmmArgs &a, const SegArgs &g, int unroll, int grid, hipStream_t s)
 {
+    // `unroll` = row gathers in flight per tile wave (direct rows keep accumulate_wave's default)
+    if (unroll == 0)
+        unroll = VEC == 4 ? 8 : VEC == 2 ? 16 : 32;  // measured on config 2 (d = 64): 32 in flight beats 16 by 4 %
     switch (unroll) {
-        case 4: hipLaunchKernelGGL((k_spmm_seg<G, 4>), dim3(grid), dim3(256), 0, s, a, g); break;
-        default: hipLaunchKernelGGL((k_spmm_seg<G, 8>), dim3(grid), dim3(256), 0, s, a, g); break;
+        case 8: hipLaunchKernelGGL((k_spmm_seg<VEC, 8>), dim3(grid), dim3(256), 0, s, a, g); break;
+        case 32:
+            if constexpr (VEC == 1) {
+                hipLaunchKernelGGL((k_spmm_seg<VEC, 32>), dim3(grid), dim3(256), 0, s, a, g);
+                break;
+            }
+            [[fallthrough]];
+        default: hipLaunchKernelGGL((k_spmm_seg<VEC, 16>), dim3(grid), dim3(256), 0, s, a, g); break;
     }
     return check_launch("k_spmm_seg");
 }
 
-// G lanes per row (float4 each), 64/G rows per wave: y = ((p0 + p1) + p2) + ... in slot order, then the epilogue.
-// The acc_in row is fetched together with the first slots (it does not depend on them).
-template <int G>
+// one wave per segmented row: y = ((p0 + p1) + p2) + ... over the row's pieces in column order, then the epilogue
+template <int VEC>
 __global__ __launch_bounds__(256) void k_spmm_seg_reduce(const SpmmArgs a, const int *__restrict__ rows,
-                                                         const int *__restrict__ row_ptr, int n)
+                                                         const int *__restrict__ row_slot_ptr,
+                                                         const int *__restrict__ row_slots, int n)
 {
-    constexpr int R = kWave / G;
-    constexpr int D = 4 * G;
     const int lane = lane_id();
-    const int gl = lane & (G - 1);
-    const int l = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R + lane / G;
+    const int l = uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (l >= n)
         return;
     const int row = rows[l];
-    const int c0 = row_ptr[l], c1 = row_ptr[l + 1];
-    const size_t off = (size_t)row * D + gl * 4;
-    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int s0 = row_slot_ptr[l], s1 = row_slot_ptr[l + 1];
+    const size_t off = (size_t)row * a.d + lane * VEC;
+    float t[VEC];
     if (a.acc_out)
-        t = *reinterpret_cast<const float4 *>(a.acc_in + off);
-    const float *ws = a.ws + gl * 4;
-    float4 y = *reinterpret_cast<const float4 *>(ws + (size_t)c0 * D);
-    for (int c = c0 + 1; c < c1; c += 8) {
-        float4 p[8];
+        load_vec<VEC>(a.acc_in + off, t);  // early: independent of the pieces
+    const float *__restrict__ wsl = a.ws + lane * VEC;
+    const size_t d = (size_t)a.d;
+    float y[VEC];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-            p[u] = *reinterpret_cast<const float4 *>(ws + (size_t)min(c + u, c1 - 1) * D);
+    for (int k = 0; k < VEC; ++k)
+        y[k] = 0.0f;
+    bool first = true;
+    for (int sb = s0; sb < s1; sb += kWave) {
+        const int n_s = min(kWave, s1 - sb);
+        const int sl = row_slots[sb + min(lane, n_s - 1)];
+        for (int j = 0; j < n_s; j += 8) {
+            float p[8][VEC];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (c + u < c1)
-                y.x = y.x + p[u].x, y.y = y.y + p[u].y, y.z = y.z + p[u].z, y.w = y.w + p[u].w;
+            for (int u = 0; u < 8; ++u)
+                load_vec<VEC>(wsl + (size_t)__builtin_amdgcn_readlane(sl, min(j + u, n_s - 1)) * d, p[u]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (j + u < n_s) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k)
+                        y[k] = first ? p[u][k] : y[k] + p[u][k];
+                    first = false;
+                }
+            }
+        }
     }
     if (a.Y)
-        *reinterpret_cast<float4 *>(a.Y + off) = y;
+        store_vec<VEC>(a.Y + off, y);
     if (a.acc_out) {
-        t.x = t.x + y.x, t.y = t.y + y.y, t.z = t.z + y.z, t.w = t.w + y.w;
-        if (a.acc_div != 1.0f)
-            t.x = t.x / a.acc_div, t.y = t.y / a.acc_div, t.z = t.z / a.acc_div, t.w = t.w / a.acc_div;
-        *reinterpret_cast<float4 *>(a.acc_out + off) = t;
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            t[k] = t[k] + y[k];
+            if (a.acc_div != 1.0f)
+                t[k] = t[k] / a.acc_div;
+        }
+        store_vec<VEC>(a.acc_out + off, t);
     }
 }
 
@@ -518,29 +509,6 @@ int launch_group(const SpmmArgs &a, int unroll, int grid, hipStream_t s)
 
 using namespace tgcn;
 
-int tgcn::launch_long_rows(const int *rowptr, const int *colidx, const float *vals, int n_rows, const float *X, int d, float *Y,
-                           const float *acc_in, float *acc_out, float acc_div, const tgcn_split_plan_t *plan, hipStream_t s)
-{
-    SpmmArgs a;
-    a.rowptr = rowptr, a.colidx = colidx, a.vals = vals, a.X = X, a.Y = Y;
-    a.acc_in = acc_in, a.acc_out = acc_out, a.acc_div = acc_div;
-    a.n_rows = n_rows, a.d = d, a.row_waves = 0, a.row_order = nullptr;  // no row waves: every wave of the launch is a chunk wave
-    a.threshold = plan->threshold, a.n_chunks = plan->n_chunks;
-    a.chunk_beg = plan->chunk_beg, a.chunk_end = plan->chunk_end, a.ws = plan->workspace;
-    const int grid = (a.n_chunks + 3) / 4;
-    int rc = d == 64 ? launch_wave<1>(a, 0, grid, s) : d == 128 ? launch_wave<2>(a, 0, grid, s) : launch_wave<4>(a, 0, grid, s);
-    if (rc != TGCN_OK)
-        return rc;
-    const int rgrid = (plan->n_long + 3) / 4;
-    if (d == 64)
-        hipLaunchKernelGGL((k_spmm_long_reduce<1>), dim3(rgrid), dim3(256), 0, s, a, plan->long_rows, plan->long_chunk_ptr, plan->n_long);
-    else if (d == 128)
-        hipLaunchKernelGGL((k_spmm_long_reduce<2>), dim3(rgrid), dim3(256), 0, s, a, plan->long_rows, plan->long_chunk_ptr, plan->n_long);
-    else
-        hipLaunchKernelGGL((k_spmm_long_reduce<4>), dim3(rgrid), dim3(256), 0, s, a, plan->long_rows, plan->long_chunk_ptr, plan->n_long);
-    return check_launch("k_spmm_long_reduce");
-}
-
 extern "C" int tgcn_spmm_csr_f32(const int32_t *rowptr, const int32_t *colidx, const float *vals, int64_t n_rows,
                                  const float *X, int64_t n_src_rows, int32_t d, float *Y, const float *acc_in,
                                  float *acc_out, float acc_div, const tgcn_split_plan_t *plan, const int32_t *row_order,
@@ -632,13 +600,15 @@ extern "C" int tgcn_spmm_segmented_f32(const tgcn_segment_plan_t *plan, const in
     TGCN_REQUIRE(Y || acc_out, "both Y and acc_out are NULL: nothing to compute");
     TGCN_REQUIRE(!acc_out || acc_in, "acc_out given without acc_in");
     TGCN_REQUIRE(acc_div != 0.0f, "acc_div must be non-zero");
-    const int per_wg = tgcn_segment_positions_per_workgroup(d);
-    TGCN_REQUIRE(plan->n_segments >= 0 && plan->n_segments % per_wg == 0,
-                 "n_segments must be a multiple of tgcn_segment_positions_per_workgroup(d)");
+    TGCN_REQUIRE(plan->n_tiles >= 0 && plan->n_tiles % 4 == 0, "n_tiles must be a multiple of 4");
+    TGCN_REQUIRE(plan->tile_entries > 0 && plan->tile_entries % 64 == 0, "tile_entries must be a positive multiple of 64");
+    TGCN_REQUIRE((int64_t)plan->n_tiles * plan->tile_entries < INT_MAX, "segment streams too large");
     TGCN_REQUIRE(plan->n_seg_rows >= 0 && plan->n_direct_rows >= 0 && plan->n_slots >= 0, "negative plan counts");
     TGCN_REQUIRE((int64_t)plan->n_seg_rows + plan->n_direct_rows == n_rows, "plan does not cover every row once");
-    TGCN_REQUIRE(plan->n_segments == 0 || (plan->seg_meta && plan->workspace), "segment arrays are NULL");
-    TGCN_REQUIRE(plan->n_seg_rows == 0 || (plan->seg_rows && plan->seg_row_ptr && plan->workspace), "segment row arrays are NULL");
+    TGCN_REQUIRE(plan->n_tiles == 0 || (plan->tile_meta && plan->ent_col && plan->ent_val && plan->workspace),
+                 "segment stream arrays are NULL");
+    TGCN_REQUIRE(plan->n_seg_rows == 0 || (plan->seg_rows && plan->row_slot_ptr && plan->row_slots && plan->workspace),
+                 "segment row arrays are NULL");
     TGCN_REQUIRE(plan->n_direct_rows == 0 || plan->direct_rows, "direct_rows is NULL");
     hipStream_t s = static_cast<hipStream_t>(stream);
 
@@ -648,31 +618,26 @@ extern "C" int tgcn_spmm_segmented_f32(const tgcn_segment_plan_t *plan, const in
     a.n_rows = (int)n_rows, a.d = d, a.row_waves = 0, a.row_order = nullptr;
     a.threshold = INT_MAX, a.n_chunks = 0, a.chunk_beg = nullptr, a.chunk_end = nullptr, a.ws = plan->workspace;
     SegArgs g;
-    g.seg_meta = reinterpret_cast<const int4 *>(plan->seg_meta), g.direct_rows = plan->direct_rows;
-    g.n_seg_wgs = plan->n_segments / per_wg, g.n_direct = plan->n_direct_rows;
+    g.tile_meta = reinterpret_cast<const int2 *>(plan->tile_meta), g.ent_col = plan->ent_col, g.ent_val = plan->ent_val;
+    g.direct_rows = plan->direct_rows;
+    g.n_tiles = plan->n_tiles, g.tile_entries = plan->tile_entries, g.n_direct = plan->n_direct_rows;
     const int unroll = (flags >> 8) & 0xff;
-    const int grid = g.n_seg_wgs + (g.n_direct + 3) / 4;
+    const int grid = (g.n_tiles + g.n_direct + 3) / 4;
     if (grid > 0) {
-        const int rc = d == 64 ? launch_seg<16>(a, g, unroll, grid, s) : d == 128 ? launch_seg<32>(a, g, unroll, grid, s)
-                                                                                 : launch_seg<64>(a, g, unroll, grid, s);
+        const int rc = d == 64 ? launch_seg<1>(a, g, unroll, grid, s) : d == 128 ? launch_seg<2>(a, g, unroll, grid, s)
+                                                                                : launch_seg<4>(a, g, unroll, grid, s);
         if (rc != TGCN_OK)
             return rc;
     }
     if (plan->n_seg_rows > 0) {
-        const int rows_per_wg = 4 * (256 / d);
-        const int rgrid = (plan->n_seg_rows + rows_per_wg - 1) / rows_per_wg;
+        const int rgrid = (plan->n_seg_rows + 3) / 4;
         if (d == 64)
-            hipLaunchKernelGGL((k_spmm_seg_reduce<16>), dim3(rgrid), dim3(256), 0, s, a, plan->seg_rows, plan->seg_row_ptr, plan->n_seg_rows);
+            hipLaunchKernelGGL((k_spmm_seg_reduce<1>), dim3(rgrid), dim3(256), 0, s, a, plan->seg_rows, plan->row_slot_ptr, plan->row_slots, plan->n_seg_rows);
         else if (d == 128)
-            hipLaunchKernelGGL((k_spmm_seg_reduce<32>), dim3(rgrid), dim3(256), 0, s, a, plan->seg_rows, plan->seg_row_ptr, plan->n_seg_rows);
+            hipLaunchKernelGGL((k_spmm_seg_reduce<2>), dim3(rgrid), dim3(256), 0, s, a, plan->seg_rows, plan->row_slot_ptr, plan->row_slots, plan->n_seg_rows);
         else
-            hipLaunchKernelGGL((k_spmm_seg_reduce<64>), dim3(rgrid), dim3(256), 0, s, a, plan->seg_rows, plan->seg_row_ptr, plan->n_seg_rows);
+            hipLaunchKernelGGL((k_spmm_seg_reduce<4>), dim3(rgrid), dim3(256), 0, s, a, plan->seg_rows, plan->row_slot_ptr, plan->row_slots, plan->n_seg_rows);
         return check_launch("k_spmm_seg_reduce");
     }
     return TGCN_OK;
-}
-
-extern "C" int32_t tgcn_segment_positions_per_workgroup(int32_t d)
-{
-    return (d == 64 || d == 128 || d == 256) ? kSegIters * 4 * (256 / d) : 0;
 }

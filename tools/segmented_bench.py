@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timing of the XCD-affine segmented SpMM (tgcn_spmm_segmented_f32) against the plain kernel on a BASELINE config.
 
-    python tools/segmented_bench.py --workload c2 --configs 0,8 8,8 4,8 0,16 --max-len 128 --unroll 8
+    python tools/segmented_bench.py --workload c2 --configs 0,8 8,8 0,16 --tile 256
 Each --configs entry is users_blocks,items_blocks (column blocks for user rows / item rows; 0 = rows stay direct)."""
 import argparse
 import json
@@ -17,9 +17,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--workload', default='c2')
-    ap.add_argument('--configs', nargs='+', default=['0,8', '8,8', '4,8', '0,16'])
-    ap.add_argument('--max-len', type=int, nargs='+', default=[128])
-    ap.add_argument('--unroll', type=int, nargs='+', default=[8])
+    ap.add_argument('--configs', nargs='+', default=['0,8', '8,8', '0,16'])
+    ap.add_argument('--tile', type=int, nargs='+', default=[256])
+    ap.add_argument('--unroll', type=int, nargs='+', default=[0])
     ap.add_argument('--steps', type=int, default=30)
     args = ap.parse_args()
     from textgcn_amd import propagate, synth
@@ -49,15 +49,15 @@ def main():
     print(json.dumps({'variant': 'plain', 'ms_per_forward': round(base, 4)}), flush=True)
     for cfg in args.configs:
         bu, bi = (int(t) for t in cfg.split(','))
-        for ml in args.max_len:
-            prop.csr.configure_segments([bu, bi], max_len=ml)
+        for ml in args.tile:
+            prop.csr.configure_segments([bu, bi], tile_entries=ml)
             for un in args.unroll:
                 ms = timed(lambda: prop.forward(e0, K, out=out, segmented=True, unroll=un))
                 err = float(torch.linalg.norm(out - ref) / torch.linalg.norm(ref))
-                h = prop.csr._segment_plans[d][3]
-                print(json.dumps({'variant': f'segmented users={bu} items={bi}', 'max_len': ml, 'unroll': un,
+                h = prop.csr._segment_plan[0]
+                print(json.dumps({'variant': f'segmented users={bu} items={bi}', 'tile': ml, 'unroll': un,
                                   'ms_per_forward': round(ms, 4), 'vs_plain': round(base / ms, 3), 'normwise_vs_plain': err,
-                                  'positions': len(h['seg_beg']), 'slots': h['n_slots'],
+                                  'tiles': len(h['tile_meta']), 'slots': h['n_slots'],
                                   'direct_rows': len(h['direct_rows'])}), flush=True)
 
 
