@@ -104,6 +104,7 @@ def main():
     ap.add_argument('--workload', default=None, help='c2 (default), c3, c4, small, tiny')
     ap.add_argument('--exact', action='store_true', help='no long-row split: bit-identical to the CPU reference')
     ap.add_argument('--split-threshold', type=int, default=None)
+    ap.add_argument('--no-segment', action='store_true', help='keep every row on the one-wave-per-row kernel (no XCD-affine segments)')
     ap.add_argument('--score-batches', type=int, default=20)
     ap.add_argument('--score-batch-size', type=int, default=2048, help='users per scoring call (reference batch_size = 2048)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -150,7 +151,7 @@ def main():
     thr = args.split_threshold or propagate.DEFAULT_SPLIT_THRESHOLD
 
     if world == 1:
-        prop = propagate.Propagator(graph, dev, split_threshold=thr)
+        prop = propagate.Propagator(graph, dev, split_threshold=thr, segment=None if args.no_segment else 'auto')
         e0d = e0.to(dev)
         out = torch.empty_like(e0d)
 
@@ -197,6 +198,10 @@ def main():
         t = reduce_max_sum([t])[0][0]
     edges = args.steps * K * graph.nnz
     value = edges / t
+    seg_note = 'none'
+    if world == 1 and not args.exact and prop.csr.segment_blocks and any(prop.csr.segment_blocks):
+        seg_note = (f'user rows x{prop.csr.segment_blocks[0]}, item rows x{prop.csr.segment_blocks[1]} column blocks, '
+                    f'{prop.csr.segment_tile}-entry tiles (tgcn_spmm_segmented_f32)')
 
     # ---------------- roofline of the dominant kernel (one SpMM layer launch on this rank)
     layer_bytes = [algorithmic_bytes_per_layer(nnz_local, n_rows_local, n_src, d, k, K, False) for k in range(1, K + 1)]
@@ -207,7 +212,7 @@ def main():
                 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
                 # measured memory-side bytes (PMC pass, profiles/) over the live launch time: what the fabric moves
                 'traffic_GBs': round(traffic / mean_layer_s / 1e9, 1) if traffic else None,
-                'kernel': 'k_spmm (one layer launch, incl. long-row reduce)',
+                'kernel': 'one SpMM layer (k_spmm_seg + k_spmm_seg_reduce, or k_spmm_wave + k_spmm_long_reduce)',
                 'algorithmic_bytes_per_launch': int(np.mean(layer_bytes)), 'launch_us': round(mean_layer_s * 1e6, 2),
                 'gather_model_GBs': round((nnz_local * (8 + 4 * d) + n_rows_local * d * 4) / mean_layer_s / 1e9, 1)}
 
@@ -217,6 +222,7 @@ def main():
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': wl_name, 'nnz_A': graph.nnz, 'n_nodes': graph.n, 'max_degree': int(graph.degrees().max()),
                    'mode': 'exact (one fmaf chain per row)' if args.exact else f'rows > {thr} entries split in chunks',
+                   'xcd_segments': seg_note,
                    'sharding': 'none' if world == 1 else f'row-sharded x{world}, RCCL all-gather per layer (users ∥ item half-step)',
                    'graph_build_s': round(build_s, 1)},
         'roofline': roofline,

@@ -84,25 +84,40 @@ int tgcn_spmm_csr_f32(const int32_t *rowptr, const int32_t *colidx, const float 
                       float *acc_out, float acc_div, const tgcn_split_plan_t *plan, const int32_t *row_order,
                       uint32_t flags, tgcn_stream_t stream);
 
-/* Cache-blocked form of the same product (bit-identical results; faster when X does not fit an XCD's 4 MB L2).
- * A block plan covers local rows [row_begin, row_begin + n_rows) whose entries all fall in one column range
- * (user rows read item columns and vice versa -- A is bipartite), cut into n_blocks column blocks of ~3 MB of
- * X:  blkptr[b * ld + (r - row_begin)] = offset in colidx/vals of row r's first entry with column >= the first
- * column of block b  (b = n_blocks: one past the row's last entry).  Rows longer than the split threshold have
- * empty segments (all pointers equal) and are handled through `split`, as in tgcn_spmm_csr_f32.  The plans
- * together must cover every row exactly once.  Built on the host by textgcn_amd.graph.block_plan_arrays. */
-typedef struct tgcn_block_plan {
-    int32_t n_blocks;
-    int32_t row_begin;
-    int32_t n_rows;
-    int32_t ld;
-    const int32_t *blkptr; /* [(n_blocks + 1), ld] */
-} tgcn_block_plan_t;
+/* XCD-affine segmented form of the same product (d in {64, 128, 256}).  The plan holds its own copy of the
+ * entries of the segmented rows, as streams: stream x of a row range keeps the entries whose column falls in column
+ * blocks x, x+8, ... ordered by (block, row, column).  A row's run inside one block is a segment; streams are cut
+ * into tiles of `tile_entries` entries, one wavefront each, and a segment crossing a cut becomes two pieces.  The
+ * last entry of a piece carries bit 31 in its column word; the wavefront sums a piece as a sequential fmaf chain
+ * from +0 into workspace[slot] (slots count pieces in tile order from tile_meta[t][0]).  A second launch adds the
+ * pieces row_slots[row_slot_ptr[i] .. row_slot_ptr[i+1]) of row seg_rows[i] in that (column) order and applies the
+ * Y / acc epilogue.  Tiles are laid out so that a workgroup (4 consecutive tiles) stays in one stream and workgroups
+ * g, g+8, g+16 ... share a stream: workgroups are dealt round-robin over the 8 XCDs, so every XCD's 4 MB L2 serves
+ * 1/8 of the gathered table instead of missing to the Infinity Cache.  Placement is a speed matter only.
+ * `direct_rows` are summed by one wavefront each from rowptr/colidx/vals exactly as in tgcn_spmm_csr_f32.
+ * Deterministic; differs from the one-chain-per-row result in rounding only (same contract as the long-row split).
+ * Built on the host by textgcn_amd.graph.segment_plan_arrays. */
+typedef struct tgcn_segment_plan {
+    int32_t n_tiles;      /* multiple of 4 */
+    int32_t tile_entries; /* multiple of 64 */
+    int32_t n_seg_rows;
+    int32_t n_direct_rows;
+    int32_t n_slots;
+    int32_t _pad;
+    const int32_t *tile_meta;    /* [n_tiles][2]: {first slot, entries in the tile (0: padding)} */
+    const int32_t *ent_col;      /* [n_tiles * tile_entries]: column | (last entry of its piece ? 1 << 31 : 0) */
+    const float *ent_val;        /* [n_tiles * tile_entries] */
+    const int32_t *seg_rows;     /* [n_seg_rows] local row ids */
+    const int32_t *row_slot_ptr; /* [n_seg_rows + 1] */
+    const int32_t *row_slots;    /* [n_slots] a row's pieces in column order */
+    const int32_t *direct_rows;  /* [n_direct_rows] local row ids */
+    float *workspace;            /* [n_slots, d] fp32 scratch */
+} tgcn_segment_plan_t;
 
-int tgcn_spmm_blocked_f32(const tgcn_block_plan_t *plans, int32_t n_plans, const int32_t *rowptr,
-                          const int32_t *colidx, const float *vals, int64_t n_rows, const float *X,
-                          int64_t n_src_rows, int32_t d, float *Y, const float *acc_in, float *acc_out,
-                          float acc_div, const tgcn_split_plan_t *split, tgcn_stream_t stream);
+int tgcn_spmm_segmented_f32(const tgcn_segment_plan_t *plan, const int32_t *rowptr, const int32_t *colidx,
+                            const float *vals, int64_t n_rows, const float *X, int64_t n_src_rows, int32_t d,
+                            float *Y, const float *acc_in, float *acc_out, float acc_div, uint32_t flags,
+                            tgcn_stream_t stream);
 
 /* K5: S[b, i] = <U[user_ids[b], :], It[i, :]>  (user_ids == NULL: U rows 0..B-1), S row stride lds.
  *   replaces torch.matmul(users_emb, items_emb.t())                TextGCN/base_model.py:179

@@ -129,23 +129,55 @@ def test_train_mask_csr_matches_oracle(golden, oracle):
     assert np.array_equal(rp, orp) and np.array_equal(items, oitems)
 
 
-def test_block_plan_arrays_segments_partition_rows(golden):
-    from textgcn_amd.graph import block_plan_arrays
-    g = golden('g5_medium')
-    gr = NormGraph.from_pairs(g['train_u'], g['train_i'], int(g['n_users']), int(g['n_items']))
-    u, n = gr.n_users, gr.n
-    for (r0, r1, c0, c1) in ((0, u, u, n), (u, n, 0, u)):
-        bp, nb = block_plan_arrays(gr.rowptr, gr.colidx, r0, r1, c0, c1, 100, long_threshold=64)
-        assert bp.shape == (nb + 1, r1 - r0) and nb >= 2
-        lens = np.diff(gr.rowptr[r0:r1 + 1])
-        assert np.all(np.diff(bp.astype(np.int64), axis=0) >= 0)
-        short = lens <= 64
-        assert np.array_equal(bp[0][short], gr.rowptr[r0:r1][short]) and np.array_equal(bp[nb][short], gr.rowptr[r0 + 1:r1 + 1][short])
-        assert np.all(bp[:, ~short] == gr.rowptr[r0:r1][~short])            # long rows: empty segments
-        width = -(-(c1 - c0) // nb)
-        for r in np.nonzero(short)[0][::37]:
-            for b in range(nb):
-                seg = gr.colidx[bp[b, r]:bp[b + 1, r]]
-                assert np.all((seg >= c0 + b * width) & (seg < c0 + (b + 1) * width))
-    with pytest.raises(ValueError):
-        block_plan_arrays(gr.rowptr, gr.colidx, 0, u, 0, u, 100)                # wrong column range
+def test_segment_plan_streams_reproduce_the_product():
+    """XCD-affine segment plan (graph.segment_plan_arrays): walking the tiles as the kernel does and adding a row's
+    pieces in row_slots order reproduces A.x; every tile stays in one column-block class and the 4 tiles of a
+    workgroup share it; a row's pieces are in ascending column order."""
+    from textgcn_amd.graph import NormGraph, segment_plan_arrays
+    from textgcn_amd import synth
+    u, i = synth.interactions(300, 170, 6000, seed=3)
+    g = NormGraph.from_pairs(u, i, 300, 170)
+    U, N = g.n_users, g.n
+    x = np.random.default_rng(0).standard_normal((N, 8))
+    ref = np.zeros((N, 8))
+    np.add.at(ref, np.repeat(np.arange(N), np.diff(g.rowptr)), g.vals[:, None].astype(np.float64) * x[g.colidx])
+    for nb_items, nb_users, T in ((8, 0, 64), (16, 8, 128), (8, 24, 64)):
+        phases = [(U, N, 0, U, nb_items)] + ([(0, U, U, N, nb_users)] if nb_users else [])
+        p = segment_plan_arrays(g.rowptr, g.colidx, g.vals, phases, tile_entries=T)
+        n_tiles = len(p['tile_meta'])
+        assert n_tiles % 4 == 0 and len(p['ent_col']) == n_tiles * T == len(p['ent_val'])
+        ws = np.zeros((p['n_slots'], 8))
+        written = np.zeros(p['n_slots'], dtype=np.int32)
+        tile_class = np.full(n_tiles, -1)
+        slot_first_col = np.zeros(p['n_slots'], dtype=np.int64)
+        for t, (slot, n) in enumerate(p['tile_meta']):
+            acc, first_col = np.zeros(8), None
+            for e in range(t * T, t * T + n):
+                c = int(p['ent_col'][e])
+                flag, c = c < 0, c & 0x7fffffff
+                first_col = c if first_col is None else first_col
+                acc = acc + np.float64(p['ent_val'][e]) * x[c]
+                for (r0, r1, c0, c1, nb) in phases:
+                    if c0 <= c < c1:
+                        cls = ((c - c0) // -(-(c1 - c0) // nb)) % 8
+                        assert tile_class[t] in (-1, cls)
+                        tile_class[t] = cls
+                if flag:
+                    ws[slot], written[slot], slot_first_col[slot] = acc, written[slot] + 1, first_col
+                    slot, acc, first_col = slot + 1, np.zeros(8), None
+            assert n == 0 or first_col is None     # a tile's last entry closes its piece
+        assert np.all(written == 1)
+        live = tile_class.reshape(-1, 4)
+        for wg in live:
+            assert len(set(wg[wg >= 0].tolist())) <= 1
+        y = np.zeros((N, 8))
+        for k, r in enumerate(p['seg_rows']):
+            sl = p['row_slots'][p['row_slot_ptr'][k]:p['row_slot_ptr'][k + 1]]
+            assert len(sl) and np.all(np.diff(slot_first_col[sl]) > 0)
+            y[r] = ws[sl].sum(axis=0)
+        seg = np.zeros(N, dtype=bool)
+        seg[p['seg_rows']] = True
+        assert sorted(np.concatenate([p['seg_rows'], p['direct_rows']]).tolist()) == list(range(N))
+        assert np.allclose(y[seg], ref[seg], rtol=1e-12, atol=1e-12)
+        if not nb_users:
+            assert np.all(p['direct_rows'] < U) and len(p['direct_rows']) == U

@@ -207,44 +207,6 @@ def test_argument_validation(cuda):
         spmm(csr, x, y=None, acc_in=None, acc_out=None)   # nothing to compute -> C ABI error surfaces
 
 
-@pytest.mark.parametrize('d', [64, 128, 256])
-@pytest.mark.parametrize('block_bytes', [16 << 10, 256 << 10, 3 << 20])
-def test_blocked_kernel_bit_identical(cuda, oracle, d, block_bytes):
-    """The cache-blocked kernel (register-resident accumulators across column blocks) must reproduce the plain
-    kernel bit for bit: short rows equal the oracle's sequential chain, split rows go through the same chunk path."""
-    from textgcn_amd.propagate import Propagator
-    gr = _random_graph(3000, 1200, 60000, seed=11, zipf=1.0)
-    rng = np.random.default_rng(d)
-    e0 = rng.standard_normal((gr.n, d)).astype(np.float32)
-    idx, val = gr.to_coo()
-    prop = Propagator(gr, cuda, split_threshold=200, block_bytes=block_bytes)
-    e0d = torch.from_numpy(e0).to(cuda)
-    plans, n_plans = prop.csr.block_plans(d)
-    assert n_plans == 2
-    out_b, layers_b = prop.forward(e0d, 3, keep_layers=True, blocked=True)
-    out_p, layers_p = prop.forward(e0d, 3, keep_layers=True, blocked=False)
-    for k in range(4):
-        assert torch.equal(layers_b[k], layers_p[k]), k
-    assert torch.equal(out_b, out_p)
-    assert torch.equal(prop.forward(e0d, 3, blocked=True), out_p)          # fused (no stored layers) path
-    assert torch.equal(prop.forward(e0d, 3, single=True, blocked=True), layers_p[3])
-    ref = oracle.spmm_coo(idx, val, e0)
-    short = gr.degrees() <= 200
-    assert np.array_equal(bits(layers_b[1].cpu().numpy()[short]), bits(ref[short]))
-    assert normwise(layers_b[1].cpu().numpy(), ref) <= 1e-5
-
-
-def test_blocked_kernel_without_split_plan_is_exact(cuda, oracle):
-    from textgcn_amd.propagate import Propagator
-    gr = _random_graph(900, 500, 20000, seed=12)
-    e0 = np.random.default_rng(0).standard_normal((gr.n, 64)).astype(np.float32)
-    prop = Propagator(gr, cuda, split_threshold=None, block_bytes=64 << 10)
-    out = prop.forward(torch.from_numpy(e0).to(cuda), 2, blocked=True)
-    idx, val = gr.to_coo()
-    ref, _ = oracle.propagate(idx, val, e0, 2)
-    assert np.array_equal(bits(out.cpu().numpy()), bits(ref))
-
-
 def test_full_size_c3_properties(cuda, oracle):
     """BASELINE config 3 shape (U=180k, I=60k, nnz=1.6M, d=128, K=4): sampled rows of every layer against the
     oracle chain, exact == split on short rows of layer 1, linearity, layer mean identity."""
@@ -309,3 +271,45 @@ def test_edge_cases_empty_and_isolated(cuda, oracle):
     ref, _ = oracle.propagate(idx, val, x.cpu().numpy(), 2)
     assert np.array_equal(bits(out1), bits(ref))
     assert torch.equal(Propagator(g1, cuda).forward(x, 0), x)   # K = 0: representation is E0
+
+
+@pytest.mark.parametrize('d', [64, 128, 256])
+@pytest.mark.parametrize('blocks', [(0, 8), (8, 16), (24, 0)])
+@pytest.mark.parametrize('tile', [256, 64])
+def test_segmented_xcd_affine_kernel(cuda, oracle, d, blocks, tile):
+    """tgcn_spmm_segmented_f32: rows cut at column-block boundaries, piece sums added in column order.  Direct rows
+    are bit-exact, segmented rows agree with the one-chain result to rounding, runs are identical (no atomics), and the
+    fused epilogue (acc_in/acc_out/acc_div, Y optional) matches the oracle's layer sum."""
+    from textgcn_amd.propagate import Propagator, spmm
+    gr = _random_graph(1500, 700, 30000, seed=5, zipf=1.0)
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((gr.n, d)).astype(np.float32)
+    e0 = rng.standard_normal((gr.n, d)).astype(np.float32)
+    idx, val = gr.to_coo()
+    ref = oracle.spmm_coo(idx, val, x)
+    prop = Propagator(gr, cuda)
+    prop.csr.configure_segments(list(blocks), tile_entries=tile)    # specs: (user rows, item rows)
+    xd, e0d = torch.from_numpy(x).to(cuda), torch.from_numpy(e0).to(cuda)
+    outs = []
+    for unroll in (0, 8, 0):
+        y = torch.full((gr.n, d), float('nan'), device=cuda)
+        spmm(prop.csr, xd, y=y, segmented=True, unroll=unroll)
+        outs.append(y.cpu().numpy())
+    assert normwise(outs[0], ref) <= 5e-6    # rounding only (the path's tolerance is 1e-4)
+    assert np.array_equal(bits(outs[0]), bits(outs[1])) and np.array_equal(bits(outs[0]), bits(outs[2]))
+    direct = np.zeros(gr.n, dtype=bool)
+    if blocks[0] == 0:
+        direct[:gr.n_users] = True
+    if blocks[1] == 0:
+        direct[gr.n_users:] = True
+    direct |= gr.degrees() == 0
+    assert np.array_equal(bits(outs[0][direct]), bits(ref[direct]))
+    # fused epilogue on top of the segmented sums
+    acc = torch.full((gr.n, d), float('nan'), device=cuda)
+    spmm(prop.csr, xd, y=None, acc_in=e0d, acc_out=acc, acc_div=4.0, segmented=True)
+    want = (e0 + outs[0]) / np.float32(4.0)
+    assert np.array_equal(bits(acc.cpu().numpy()), bits(want.astype(np.float32)))
+    # whole forward through the segmented path
+    full = prop.forward(e0d, 3, segmented=True).cpu().numpy()
+    exact = prop.forward(e0d, 3, exact=True).cpu().numpy()
+    assert normwise(full, exact) <= 5e-6

@@ -19,9 +19,12 @@ class SplitPlanStruct(Structure):
                 ('long_chunk_ptr', c_void_p), ('workspace', c_void_p)]
 
 
-class BlockPlanStruct(Structure):
-    """mirror of tgcn_block_plan_t"""
-    _fields_ = [('n_blocks', c_int32), ('row_begin', c_int32), ('n_rows', c_int32), ('ld', c_int32), ('blkptr', c_void_p)]
+class SegmentPlanStruct(Structure):
+    """mirror of tgcn_segment_plan_t"""
+    _fields_ = [('n_tiles', c_int32), ('tile_entries', c_int32), ('n_seg_rows', c_int32), ('n_direct_rows', c_int32),
+                ('n_slots', c_int32), ('_pad', c_int32), ('tile_meta', c_void_p), ('ent_col', c_void_p),
+                ('ent_val', c_void_p), ('seg_rows', c_void_p), ('row_slot_ptr', c_void_p), ('row_slots', c_void_p),
+                ('direct_rows', c_void_p), ('workspace', c_void_p)]
 
 
 _SIGNATURES = {
@@ -29,9 +32,8 @@ _SIGNATURES = {
     'tgcn_last_error': (c_char_p, []),
     'tgcn_spmm_csr_f32': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p,
                                          c_void_p, c_void_p, c_float, POINTER(SplitPlanStruct), c_void_p, c_uint32, c_void_p]),
-    'tgcn_spmm_blocked_f32': (ctypes.c_int, [POINTER(BlockPlanStruct), c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
-                                             c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_float, POINTER(SplitPlanStruct),
-                                             c_void_p]),
+    'tgcn_spmm_segmented_f32': (ctypes.c_int, [POINTER(SegmentPlanStruct), c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
+                                               c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_float, c_uint32, c_void_p]),
     'tgcn_score_dense_f32': (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_int64,
                                             c_void_p]),
     'tgcn_mask_f32': (ctypes.c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),

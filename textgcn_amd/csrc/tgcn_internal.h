@@ -52,9 +52,6 @@ int launch_score_dense(const float *U, const int64_t *user_ids, int B, const flo
                        int64_t lds, hipStream_t stream);
 int launch_topk(const float *S, int64_t lds, int B, int I, int k, int do_round, float *out_val, int64_t *out_idx,
                 hipStream_t stream);
-// chunk waves + ordered reduce for the rows a split plan marks long (d in {64,128,256}, plan non-empty)
-int launch_long_rows(const int *rowptr, const int *colidx, const float *vals, int n_rows, const float *X, int d, float *Y,
-                     const float *acc_in, float *acc_out, float acc_div, const tgcn_split_plan_t *plan, hipStream_t stream);
 int launch_mask(float *S, int64_t lds, int B, int I, const int *mask_rowptr, const int *mask_items, int item_div,
                 hipStream_t stream);
 

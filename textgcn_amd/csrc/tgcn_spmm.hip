@@ -249,6 +249,166 @@ __global__ __launch_bounds__(256) void k_spmm_group(const SpmmArgs a)
     }
 }
 
+// XCD-affine segmented launch (tgcn_spmm_segmented_f32).  Waves [0, n_tiles) walk one tile each of the plan's
+// own (column, value) streams: 64 pairs are loaded at a time (the next 64 while the current ones are consumed),
+// rows of X are gathered 16 at a time exactly as in accumulate_wave, and every entry whose column word carries
+// bit 31 closes a piece: the running sum goes to the next workspace slot and restarts from +0.  The branch on the
+// flag is scalar (the column word sits in an SGPR after v_readlane).  The remaining waves own one direct row each.
+struct SegArgs {
+    const int2 *__restrict__ tile_meta;  // {first slot, entries}
+    const int *__restrict__ ent_col;
+    const float *__restrict__ ent_val;
+    const int *__restrict__ direct_rows;
+    int n_tiles;
+    int tile_entries;
+    int n_direct;
+};
+
+template <int VEC, int UNROLL>
+__global__ __launch_bounds__(256) void k_spmm_seg(const SpmmArgs a, const SegArgs g)
+{
+    const int lane = lane_id();
+    const int wave = uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (wave >= g.n_tiles) {
+        const int w = wave - g.n_tiles;
+        if (w >= g.n_direct)
+            return;
+        const int row = g.direct_rows[w];
+        float acc[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k)
+            acc[k] = 0.0f;
+        accumulate_wave<VEC, (VEC == 4 ? 8 : 16)>(a, a.rowptr[row], a.rowptr[row + 1], lane, acc);
+        epilogue<VEC>(a, (size_t)row * a.d + lane * VEC, acc);
+        return;
+    }
+    const int2 meta = g.tile_meta[wave];
+    const int n_ent = meta.y;
+    if (n_ent == 0)
+        return;
+    int slot = meta.x;
+    const size_t base = (size_t)wave * g.tile_entries;
+    const int *__restrict__ ec = g.ent_col + base;
+    const float *__restrict__ ev = g.ent_val + base;
+    const float *__restrict__ Xl = a.X + lane * VEC;
+    float *__restrict__ wsl = a.ws + lane * VEC;
+    const size_t d = (size_t)a.d;
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k)
+        acc[k] = 0.0f;
+    int c = ec[lane];  // tiles are stored whole: no bounds test
+    float v = ev[lane];
+    for (int off = 0; off < n_ent; off += kWave) {
+        const int n = min(kWave, n_ent - off);  // uniform
+        int c_nxt = 0;
+        float v_nxt = 0.0f;
+        if (off + kWave < n_ent) {  // uniform
+            c_nxt = ec[off + kWave + lane];
+            v_nxt = ev[off + kWave + lane];
+        }
+        for (int j = 0; j < n; j += UNROLL) {
+            float x[UNROLL][VEC];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int cj = __builtin_amdgcn_readlane(c, min(j + u, n - 1)) & 0x7fffffff;
+                load_vec<VEC>(Xl + (size_t)cj * d, x[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                if (j + u < n) {
+                    const float vj = readlane_f(v, j + u);
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k)
+                        acc[k] = fmaf(vj, x[u][k], acc[k]);
+                    if (__builtin_amdgcn_readlane(c, j + u) < 0) {  // last entry of a piece
+                        store_vec<VEC>(wsl + (size_t)slot * d, acc);
+                        ++slot;
+#pragma unroll
+                        for (int k = 0; k < VEC; ++k)
+                            acc[k] = 0.0f;
+                    }
+                }
+            }
+        }
+        c = c_nxt, v = v_nxt;
+    }
+}
+
+template <int VEC>
+int launch_seg(const SpmmArgs &a, const SegArgs &g, int unroll, int grid, hipStream_t s)
+{
+    // `unroll` = row gathers in flight per tile wave (direct rows keep accumulate_wave's default)
+    if (unroll == 0)
+        unroll = VEC == 4 ? 8 : VEC == 2 ? 16 : 32;  // measured on config 2 (d = 64): 32 in flight beats 16 by 4 %
+    switch (unroll) {
+        case 8: hipLaunchKernelGGL((k_spmm_seg<VEC, 8>), dim3(grid), dim3(256), 0, s, a, g); break;
+        case 32:
+            if constexpr (VEC == 1) {
+                hipLaunchKernelGGL((k_spmm_seg<VEC, 32>), dim3(grid), dim3(256), 0, s, a, g);
+                break;
+            }
+            [[fallthrough]];
+        default: hipLaunchKernelGGL((k_spmm_seg<VEC, 16>), dim3(grid), dim3(256), 0, s, a, g); break;
+    }
+    return check_launch("k_spmm_seg");
+}
+
+// one wave per segmented row: y = ((p0 + p1) + p2) + ... over the row's pieces in column order, then the epilogue
+template <int VEC>
+__global__ __launch_bounds__(256) void k_spmm_seg_reduce(const SpmmArgs a, const int *__restrict__ rows,
+                                                         const int *__restrict__ row_slot_ptr,
+                                                         const int *__restrict__ row_slots, int n)
+{
+    const int lane = lane_id();
+    const int l = uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (l >= n)
+        return;
+    const int row = rows[l];
+    const int s0 = row_slot_ptr[l], s1 = row_slot_ptr[l + 1];
+    const size_t off = (size_t)row * a.d + lane * VEC;
+    float t[VEC];
+    if (a.acc_out)
+        load_vec<VEC>(a.acc_in + off, t);  // early: independent of the pieces
+    const float *__restrict__ wsl = a.ws + lane * VEC;
+    const size_t d = (size_t)a.d;
+    float y[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k)
+        y[k] = 0.0f;
+    bool first = true;
+    for (int sb = s0; sb < s1; sb += kWave) {
+        const int n_s = min(kWave, s1 - sb);
+        const int sl = row_slots[sb + min(lane, n_s - 1)];
+        for (int j = 0; j < n_s; j += 8) {
+            float p[8][VEC];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                load_vec<VEC>(wsl + (size_t)__builtin_amdgcn_readlane(sl, min(j + u, n_s - 1)) * d, p[u]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (j + u < n_s) {
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k)
+                        y[k] = first ? p[u][k] : y[k] + p[u][k];
+                    first = false;
+                }
+            }
+        }
+    }
+    if (a.Y)
+        store_vec<VEC>(a.Y + off, y);
+    if (a.acc_out) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            t[k] = t[k] + y[k];
+            if (a.acc_div != 1.0f)
+                t[k] = t[k] / a.acc_div;
+        }
+        store_vec<VEC>(a.acc_out + off, t);
+    }
+}
+
 // any d: wave per row, one 64-column slab at a time (re-walks the row per slab; d <= 64 is one pass)
 __global__ __launch_bounds__(256) void k_spmm_generic(const SpmmArgs a)
 {
@@ -349,29 +509,6 @@ int launch_group(const SpmmArgs &a, int unroll, int grid, hipStream_t s)
 
 using namespace tgcn;
 
-int tgcn::launch_long_rows(const int *rowptr, const int *colidx, const float *vals, int n_rows, const float *X, int d, float *Y,
-                           const float *acc_in, float *acc_out, float acc_div, const tgcn_split_plan_t *plan, hipStream_t s)
-{
-    SpmmArgs a;
-    a.rowptr = rowptr, a.colidx = colidx, a.vals = vals, a.X = X, a.Y = Y;
-    a.acc_in = acc_in, a.acc_out = acc_out, a.acc_div = acc_div;
-    a.n_rows = n_rows, a.d = d, a.row_waves = 0, a.row_order = nullptr;  // no row waves: every wave of the launch is a chunk wave
-    a.threshold = plan->threshold, a.n_chunks = plan->n_chunks;
-    a.chunk_beg = plan->chunk_beg, a.chunk_end = plan->chunk_end, a.ws = plan->workspace;
-    const int grid = (a.n_chunks + 3) / 4;
-    int rc = d == 64 ? launch_wave<1>(a, 0, grid, s) : d == 128 ? launch_wave<2>(a, 0, grid, s) : launch_wave<4>(a, 0, grid, s);
-    if (rc != TGCN_OK)
-        return rc;
-    const int rgrid = (plan->n_long + 3) / 4;
-    if (d == 64)
-        hipLaunchKernelGGL((k_spmm_long_reduce<1>), dim3(rgrid), dim3(256), 0, s, a, plan->long_rows, plan->long_chunk_ptr, plan->n_long);
-    else if (d == 128)
-        hipLaunchKernelGGL((k_spmm_long_reduce<2>), dim3(rgrid), dim3(256), 0, s, a, plan->long_rows, plan->long_chunk_ptr, plan->n_long);
-    else
-        hipLaunchKernelGGL((k_spmm_long_reduce<4>), dim3(rgrid), dim3(256), 0, s, a, plan->long_rows, plan->long_chunk_ptr, plan->n_long);
-    return check_launch("k_spmm_long_reduce");
-}
-
 extern "C" int tgcn_spmm_csr_f32(const int32_t *rowptr, const int32_t *colidx, const float *vals, int64_t n_rows,
                                  const float *X, int64_t n_src_rows, int32_t d, float *Y, const float *acc_in,
                                  float *acc_out, float acc_div, const tgcn_split_plan_t *plan, const int32_t *row_order,
@@ -446,4 +583,61 @@ extern "C" int tgcn_spmm_csr_f32(const int32_t *rowptr, const int32_t *colidx, c
         rc = check_launch("k_spmm_long_reduce");
     }
     return rc;
+}
+
+extern "C" int tgcn_spmm_segmented_f32(const tgcn_segment_plan_t *plan, const int32_t *rowptr, const int32_t *colidx,
+                                       const float *vals, int64_t n_rows, const float *X, int64_t n_src_rows, int32_t d,
+                                       float *Y, const float *acc_in, float *acc_out, float acc_div, uint32_t flags,
+                                       tgcn_stream_t stream)
+{
+    TGCN_REQUIRE(plan, "plan is NULL");
+    TGCN_REQUIRE(n_rows >= 0 && n_rows < INT_MAX - 256, "n_rows out of range");
+    TGCN_REQUIRE(d == 64 || d == 128 || d == 256, "segmented SpMM supports d in {64, 128, 256}");
+    TGCN_REQUIRE(n_src_rows >= 0 && n_src_rows < INT_MAX, "n_src_rows out of range");
+    if (n_rows == 0)
+        return TGCN_OK;
+    TGCN_REQUIRE(rowptr && colidx && vals && X, "rowptr / colidx / vals / X is NULL");
+    TGCN_REQUIRE(Y || acc_out, "both Y and acc_out are NULL: nothing to compute");
+    TGCN_REQUIRE(!acc_out || acc_in, "acc_out given without acc_in");
+    TGCN_REQUIRE(acc_div != 0.0f, "acc_div must be non-zero");
+    TGCN_REQUIRE(plan->n_tiles >= 0 && plan->n_tiles % 4 == 0, "n_tiles must be a multiple of 4");
+    TGCN_REQUIRE(plan->tile_entries > 0 && plan->tile_entries % 64 == 0, "tile_entries must be a positive multiple of 64");
+    TGCN_REQUIRE((int64_t)plan->n_tiles * plan->tile_entries < INT_MAX, "segment streams too large");
+    TGCN_REQUIRE(plan->n_seg_rows >= 0 && plan->n_direct_rows >= 0 && plan->n_slots >= 0, "negative plan counts");
+    TGCN_REQUIRE((int64_t)plan->n_seg_rows + plan->n_direct_rows == n_rows, "plan does not cover every row once");
+    TGCN_REQUIRE(plan->n_tiles == 0 || (plan->tile_meta && plan->ent_col && plan->ent_val && plan->workspace),
+                 "segment stream arrays are NULL");
+    TGCN_REQUIRE(plan->n_seg_rows == 0 || (plan->seg_rows && plan->row_slot_ptr && plan->row_slots && plan->workspace),
+                 "segment row arrays are NULL");
+    TGCN_REQUIRE(plan->n_direct_rows == 0 || plan->direct_rows, "direct_rows is NULL");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+
+    SpmmArgs a;
+    a.rowptr = rowptr, a.colidx = colidx, a.vals = vals, a.X = X, a.Y = Y;
+    a.acc_in = acc_in, a.acc_out = acc_out, a.acc_div = acc_div;
+    a.n_rows = (int)n_rows, a.d = d, a.row_waves = 0, a.row_order = nullptr;
+    a.threshold = INT_MAX, a.n_chunks = 0, a.chunk_beg = nullptr, a.chunk_end = nullptr, a.ws = plan->workspace;
+    SegArgs g;
+    g.tile_meta = reinterpret_cast<const int2 *>(plan->tile_meta), g.ent_col = plan->ent_col, g.ent_val = plan->ent_val;
+    g.direct_rows = plan->direct_rows;
+    g.n_tiles = plan->n_tiles, g.tile_entries = plan->tile_entries, g.n_direct = plan->n_direct_rows;
+    const int unroll = (flags >> 8) & 0xff;
+    const int grid = (g.n_tiles + g.n_direct + 3) / 4;
+    if (grid > 0) {
+        const int rc = d == 64 ? launch_seg<1>(a, g, unroll, grid, s) : d == 128 ? launch_seg<2>(a, g, unroll, grid, s)
+                                                                                : launch_seg<4>(a, g, unroll, grid, s);
+        if (rc != TGCN_OK)
+            return rc;
+    }
+    if (plan->n_seg_rows > 0) {
+        const int rgrid = (plan->n_seg_rows + 3) / 4;
+        if (d == 64)
+            hipLaunchKernelGGL((k_spmm_seg_reduce<1>), dim3(rgrid), dim3(256), 0, s, a, plan->seg_rows, plan->row_slot_ptr, plan->row_slots, plan->n_seg_rows);
+        else if (d == 128)
+            hipLaunchKernelGGL((k_spmm_seg_reduce<2>), dim3(rgrid), dim3(256), 0, s, a, plan->seg_rows, plan->row_slot_ptr, plan->row_slots, plan->n_seg_rows);
+        else
+            hipLaunchKernelGGL((k_spmm_seg_reduce<4>), dim3(rgrid), dim3(256), 0, s, a, plan->seg_rows, plan->row_slot_ptr, plan->row_slots, plan->n_seg_rows);
+        return check_launch("k_spmm_seg_reduce");
+    }
+    return TGCN_OK;
 }

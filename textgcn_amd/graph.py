@@ -159,35 +159,96 @@ def split_plan_arrays(rowptr, threshold):
     }
 
 
-def block_plan_arrays(rowptr, colidx, row_begin, row_end, col_lo, col_hi, block_width, long_threshold=None, min_segment=4):
-    """Host array of a tgcn_block_plan_t: rows [row_begin, row_end) of a (local) CSR whose entries lie in columns
-    [col_lo, col_hi), cut into column blocks of `block_width` columns.  Returns (blkptr int32 [(n_blocks+1), n_rows],
-    n_blocks).  Rows with more than `long_threshold` entries get empty segments (they go through the split plan).
-    The block count is capped so that a row's mean segment keeps at least `min_segment` entries."""
+def segment_plan_arrays(rowptr, colidx, vals, phases, tile_entries=256, n_classes=8):
+    """Host arrays of a tgcn_segment_plan_t (XCD-affine column blocking, include/tgcn.h).
+
+    phases: list of (row_begin, row_end, col_lo, col_hi, n_blocks) -- row ranges whose entries fall in one column
+    range, cut into n_blocks column blocks (a multiple of n_classes).  The entries of a phase are copied into
+    n_classes streams: stream x holds the entries of blocks x, x + n_classes, ... ordered by (block, row, column).
+    A row's run inside one block is a segment; streams are cut into tiles of `tile_entries` entries (one wavefront
+    each) and a segment crossing a cut becomes two pieces.  The last entry of every piece carries bit 31 in its
+    column word; pieces are numbered in stream order (workspace slots).  Tiles are laid out so that a workgroup (4
+    consecutive tiles) stays inside one stream and workgroups g, g + n_classes, ... share a stream: workgroups are
+    dealt round-robin over the 8 XCDs, so each XCD's L2 serves 1/n_classes of the gathered table (speed only --
+    results never depend on the placement).  A row's value is the sum of its pieces in column order (`row_slots`).
+    Rows outside every phase, and rows without entries, are `direct` rows.
+    """
     rowptr = np.asarray(rowptr, dtype=np.int64)
-    n_rows = int(row_end - row_begin)
-    a, b = int(rowptr[row_begin]), int(rowptr[row_end])
-    cols = np.asarray(colidx[a:b], dtype=np.int64)
-    if len(cols) and (cols.min() < col_lo or cols.max() >= col_hi):
-        raise ValueError('entries outside the declared column range')
-    n_blocks = max(1, -(-(col_hi - col_lo) // int(block_width)))
-    mean_deg = (b - a) / max(n_rows, 1)
-    n_blocks = int(max(1, min(n_blocks, mean_deg // min_segment if mean_deg >= min_segment else 1)))
-    width = -(-(col_hi - col_lo) // n_blocks)
-    lens = np.diff(rowptr[row_begin:row_end + 1])
-    rows = np.repeat(np.arange(n_rows, dtype=np.int64), lens)
-    span = np.int64(col_hi - col_lo + 1)
-    key = rows * span + (cols - col_lo)                      # ascending: CSR rows ascending, columns ascending inside
-    blkptr = np.empty((n_blocks + 1, n_rows), dtype=np.int64)
-    base = np.arange(n_rows, dtype=np.int64) * span
-    for blk in range(n_blocks + 1):
-        bound = min(blk * width, col_hi - col_lo)
-        blkptr[blk] = a + np.searchsorted(key, base + bound, side='left')
-    blkptr[n_blocks] = rowptr[row_begin + 1:row_end + 1]
-    if long_threshold:
-        is_long = lens > long_threshold
-        blkptr[:, is_long] = rowptr[row_begin:row_end][is_long]
-    return blkptr.astype(np.int32), n_blocks
+    colidx = np.asarray(colidx)
+    vals = np.asarray(vals, dtype=np.float32)
+    n_rows = len(rowptr) - 1
+    T = int(tile_entries)
+    if T <= 0 or T % 64:
+        raise ValueError('tile_entries must be a positive multiple of 64')
+    direct = np.ones(n_rows, dtype=bool)
+    tiles_col, tiles_val, tiles_meta = [], [], []      # per phase, already in launch order
+    flag_orig, flag_slot = [], []                      # piece ends: original entry offset, slot id
+    slot_base = 0
+    for (r0, r1, c0, c1, nb) in phases:
+        nb = int(nb)
+        if nb <= 0 or nb % n_classes:
+            raise ValueError('n_blocks must be a positive multiple of n_classes')
+        n_r = int(r1 - r0)
+        a, b = int(rowptr[r0]), int(rowptr[r1])
+        if b == a:
+            continue
+        cols = np.asarray(colidx[a:b], dtype=np.int64)
+        if cols.min() < c0 or cols.max() >= c1:
+            raise ValueError('entries outside the declared column range')
+        lens = np.diff(rowptr[r0:r1 + 1])
+        direct[r0:r1] = lens == 0
+        rows = np.repeat(np.arange(n_r, dtype=np.int64), lens)
+        width = -(-(c1 - c0) // nb)
+        blk = (cols - c0) // width
+        cls, sub = blk % n_classes, blk // n_classes
+        n_sub = nb // n_classes
+        order = np.argsort((cls * n_sub + sub) * n_r + rows, kind='stable')      # (class, block, row, column)
+        o_cls, o_key = cls[order], (blk * n_r + rows)[order]
+        cls_len = np.bincount(o_cls, minlength=n_classes)
+        cls_start = np.cumsum(cls_len) - cls_len
+        pos_in_cls = np.arange(len(order), dtype=np.int64) - cls_start[o_cls]
+        last = np.ones(len(order), dtype=bool)
+        last[:-1] = (o_key[1:] != o_key[:-1]) | (o_cls[1:] != o_cls[:-1])        # segment ends
+        last |= (pos_in_cls % T) == T - 1                                         # tile cuts
+        tiles_per_cls = -(-cls_len // T)
+        n_t = int(-(-tiles_per_cls.max() // 4) * 4)                               # tiles per class, padded to workgroups
+        tile_in_cls = pos_in_cls // T
+        # launch order: workgroup w = (tile_in_cls // 4) * n_classes + class, tile = w * 4 + tile_in_cls % 4
+        tile_id = ((tile_in_cls // 4) * n_classes + o_cls) * 4 + tile_in_cls % 4
+        dst = tile_id * T + pos_in_cls % T
+        ent_col = np.zeros(n_t * n_classes * T, dtype=np.int64)
+        ent_val = np.zeros(n_t * n_classes * T, dtype=np.float32)
+        ent_col[dst] = cols[order] | (last.astype(np.int64) << 31)
+        ent_val[dst] = vals[a:b][order]
+        slot = slot_base + np.cumsum(last) - 1                                    # slot of the piece an entry ends
+        meta = np.zeros((n_t * n_classes, 2), dtype=np.int64)
+        meta[:, 1] = np.bincount(tile_id, minlength=n_t * n_classes)
+        first = np.ones(len(order), dtype=bool)
+        first[1:] = tile_id[1:] != tile_id[:-1]
+        # slot of a tile's first piece = pieces closed before its first entry
+        meta[tile_id[first], 0] = slot_base + (np.cumsum(last) - last)[first]
+        tiles_col.append(ent_col), tiles_val.append(ent_val), tiles_meta.append(meta)
+        flag_orig.append(a + order[last]), flag_slot.append(slot[last])
+        slot_base += int(last.sum())
+    cat = lambda xs, dt: np.concatenate(xs).astype(dt) if xs else np.zeros(0, dtype=dt)   # noqa: E731
+    f_orig, f_slot = cat(flag_orig, np.int64), cat(flag_slot, np.int64)
+    by_entry = np.argsort(f_orig, kind='stable')               # row-major, ascending column: a row's pieces in order
+    f_orig, f_slot = f_orig[by_entry], f_slot[by_entry]
+    f_row = np.searchsorted(rowptr, f_orig, side='right') - 1
+    cnt = np.bincount(f_row, minlength=n_rows) if len(f_row) else np.zeros(n_rows, dtype=np.int64)
+    seg_rows = np.nonzero(cnt)[0]
+    row_slot_ptr = np.zeros(len(seg_rows) + 1, dtype=np.int64)
+    np.cumsum(cnt[seg_rows], out=row_slot_ptr[1:])
+    direct[seg_rows] = False
+    ent_col = cat(tiles_col, np.int64)
+    return {
+        'tile_entries': T, 'n_slots': int(slot_base),
+        'tile_meta': np.ascontiguousarray(cat(tiles_meta, np.int64).reshape(-1, 2).astype(np.int32)),
+        'ent_col': (ent_col & 0x7fffffff).astype(np.int32) | np.where(ent_col >> 31, np.int32(-2**31), np.int32(0)),
+        'ent_val': cat(tiles_val, np.float32),
+        'seg_rows': seg_rows.astype(np.int32), 'row_slot_ptr': row_slot_ptr.astype(np.int32),
+        'row_slots': f_slot.astype(np.int32), 'direct_rows': np.nonzero(direct)[0].astype(np.int32),
+    }
 
 
 def train_mask_csr(train_u, train_i, n_users):

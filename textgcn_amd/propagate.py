@@ -10,20 +10,42 @@ import numpy as np
 import torch
 
 from . import _capi
-from .graph import NormGraph, block_plan_arrays, split_plan_arrays
+from .graph import NormGraph, segment_plan_arrays, split_plan_arrays
 
 DEFAULT_SPLIT_THRESHOLD = 1024
-DEFAULT_BLOCK_BYTES = 3 << 20   # of X per column block: fits an XCD's 4 MB L2 next to the streaming CSR traffic
+L2_SHARE_BYTES = 3 << 20        # of an XCD's 4 MB L2 that a gathered table can count on next to the streaming traffic
+SEGMENT_CLASSES = 8             # one column-block class per XCD
+SEGMENT_TILE_ENTRIES = 1024     # entries per tile wave (measured on config 2: 512..1024 within 1 %, 256 -8 %, 2048 -30 %)
+
+
+def segment_blocks_auto(rowptr, colidx, spec, d):
+    """Number of XCD-affine column blocks for one (row_begin, row_end, col_lo, col_hi) row range, or 0 to keep it on
+    the one-wave-per-row kernel.  Segmenting pays when the gathered table misses an XCD's L2 but an eighth of it fits,
+    the hottest rows do not already serve most gathers from L2 (Zipf-popular items do), and a row leaves enough
+    entries per block to amortise the extra workspace round trip (measured on BASELINE config 2: item rows, mean 100
+    entries, +16 %; user rows, mean 50 entries over a Zipf table, -30 %)."""
+    r0, r1, c0, c1 = spec
+    row_bytes = 4 * d
+    table = (c1 - c0) * row_bytes
+    if d not in (64, 128, 256) or table <= L2_SHARE_BYTES or table > SEGMENT_CLASSES * (L2_SHARE_BYTES + (L2_SHARE_BYTES >> 2)):
+        return 0
+    a, b = int(rowptr[r0]), int(rowptr[r1])
+    if b - a < (1 << 20) or (b - a) / max(r1 - r0, 1) < 8 * SEGMENT_CLASSES:
+        return 0
+    counts = np.bincount(np.asarray(colidx[a:b], dtype=np.int64) - c0, minlength=c1 - c0)
+    hot = np.sort(counts)[::-1][:L2_SHARE_BYTES // row_bytes].sum()
+    return SEGMENT_CLASSES if hot < 0.5 * (b - a) else 0
 
 
 class DeviceCSR:
-    """CSR of a contiguous block of rows of A on one device (+ optional long-row split plan)."""
+    """CSR of a contiguous block of rows of A on one device (+ optional long-row split plan and segment plan)."""
 
     def __init__(self, rowptr, colidx, vals, n_src_rows, device, split_threshold=None, block_specs=None,
-                 block_bytes=DEFAULT_BLOCK_BYTES, order_rows=True):
+                 order_rows=True, segment=None):
         """block_specs: optional list of (row_begin, row_end, col_lo, col_hi) covering all rows once -- row ranges
-        whose entries fall in one column range (user rows x item columns, item rows x user columns).  Enables the
-        cache-blocked kernel (tgcn_spmm_blocked_f32) for widths 64/128/256."""
+        whose entries fall in one column range (user rows x item columns, item rows x user columns).
+        segment: None (off), 'auto' (segment_blocks_auto per spec) or a list of block counts per spec: enables the
+        XCD-affine segmented kernel (tgcn_spmm_segmented_f32) for widths 64/128/256."""
         rowptr = np.asarray(rowptr, dtype=np.int64)
         if rowptr[-1] >= np.iinfo(np.int32).max:
             raise ValueError('row block has >= 2^31 entries')
@@ -60,10 +82,12 @@ class DeviceCSR:
             self._plan_dev = {k: torch.from_numpy(v).to(self.device) for k, v in self._plan_host.items()
                               if k != 'threshold'}
         self._block_specs = block_specs
-        self._block_bytes = int(block_bytes)
         self._split_threshold = split_threshold
-        self._host = (rowptr, colidx) if block_specs else None
-        self._block_plans = {}
+        self._host = (rowptr, np.asarray(colidx), lens) if block_specs else None
+        self._segment_mode = segment
+        self.segment_blocks = None    # per (d): block counts per block_spec
+        self.segment_tile = SEGMENT_TILE_ENTRIES
+        self._segment_plans = {}
 
     @property
     def n_chunks(self):
@@ -82,24 +106,43 @@ class DeviceCSR:
             self._plan_struct[d] = (st, ws)
         return ctypes.byref(self._plan_struct[d][0])
 
+    def configure_segments(self, blocks_per_spec, tile_entries=SEGMENT_TILE_ENTRIES):
+        """Set the XCD-affine segmentation by hand: blocks_per_spec[i] column blocks (a multiple of 8) for
+        block_specs[i]; 0 keeps that row range on the one-wave-per-row path.  ('auto' picks these per width.)"""
+        if not self._block_specs or len(blocks_per_spec) != len(self._block_specs):
+            raise ValueError('one block count per block_spec is required')
+        self._segment_mode = [int(b) for b in blocks_per_spec]
+        self.segment_tile = int(tile_entries)
+        self._segment_plans = {}
 
-    def block_plans(self, d):
-        """(ctypes array of tgcn_block_plan_t, count) for width d, or (None, 0) when blocking is not configured."""
-        if not self._block_specs or d not in (64, 128, 256):
-            return None, 0
-        if d not in self._block_plans:
-            rowptr, colidx = self._host
-            width = max(1024, self._block_bytes // (4 * d))
-            structs, keep = [], []
-            for (r0, r1, c0, c1) in self._block_specs:
-                bp, nb = block_plan_arrays(rowptr, colidx, r0, r1, c0, c1, width, self._split_threshold)
-                t = torch.from_numpy(np.ascontiguousarray(bp)).to(self.device)
-                keep.append(t)
-                structs.append(_capi.BlockPlanStruct(nb, int(r0), int(r1 - r0), int(r1 - r0), t.data_ptr()))
-            arr = (_capi.BlockPlanStruct * len(structs))(*structs)
-            self._block_plans[d] = (arr, len(structs), keep)
-        arr, n, _ = self._block_plans[d]
-        return arr, n
+    def segment_plan(self, d):
+        """ctypes pointer to a tgcn_segment_plan_t for width d, or None when no row range is segmented at this width."""
+        if self._segment_mode is None or not self._block_specs or d not in (64, 128, 256) or self.nnz == 0:
+            return None
+        if d not in self._segment_plans:
+            rowptr, colidx, lens = self._host
+            if self._segment_mode == 'auto':
+                blocks = [segment_blocks_auto(rowptr, colidx, sp, d) for sp in self._block_specs]
+            else:
+                blocks = list(self._segment_mode)
+            entry = None
+            if any(blocks):
+                phases = [(r0, r1, c0, c1, nb) for (r0, r1, c0, c1), nb in zip(self._block_specs, blocks) if nb]
+                h = segment_plan_arrays(rowptr, colidx, self.vals.cpu().numpy(), phases, self.segment_tile)
+                dr = h['direct_rows']
+                h['direct_rows'] = dr[np.argsort(-lens[dr], kind='stable')].astype(np.int32)   # longest first
+                dv = {k: torch.from_numpy(v).to(self.device) for k, v in h.items() if isinstance(v, np.ndarray)}
+                ws = torch.empty((max(h['n_slots'], 1), d), dtype=torch.float32, device=self.device)
+                st = _capi.SegmentPlanStruct(len(h['tile_meta']), h['tile_entries'], len(h['seg_rows']), len(h['direct_rows']),
+                                             h['n_slots'], 0, dv['tile_meta'].data_ptr(), dv['ent_col'].data_ptr(),
+                                             dv['ent_val'].data_ptr(), dv['seg_rows'].data_ptr(),
+                                             dv['row_slot_ptr'].data_ptr(), dv['row_slots'].data_ptr(),
+                                             dv['direct_rows'].data_ptr(), ws.data_ptr())
+                entry = (st, ws, dv, h)
+            self._segment_plans[d] = (entry, blocks)
+        entry, blocks = self._segment_plans[d]
+        self.segment_blocks = blocks
+        return None if entry is None else ctypes.byref(entry[0])
 
 
 def _check_dense(t, name, device, rows=None, d=None):
@@ -114,14 +157,14 @@ def _check_dense(t, name, device, rows=None, d=None):
 
 
 def spmm(csr, x, y=None, acc_in=None, acc_out=None, acc_div=1.0, exact=False, variant=_capi.SPMM_AUTO, unroll=0,
-         vals=None, blocked=False):
+         vals=None, segmented=None):
     """One layer: y = A_block . x, optionally acc_out = (acc_in + y) / acc_div (see tgcn_spmm_csr_f32).
 
     x [n_src_rows, d]; y / acc_in / acc_out [n_rows, d] (y or acc_out may be None).  exact=True ignores the
-    long-row plan: every row is one sequential fmaf chain, bit-identical to the reference's CPU kernel.
+    long-row and segment plans: every row is one sequential fmaf chain, bit-identical to the reference's CPU kernel.
     vals: optional replacement of the stored values on the same structure (edge dropout, transposed values).
-    blocked: opt into the cache-blocked kernel (tgcn_spmm_blocked_f32).  Bit-identical output; measured SLOWER than
-    the plain kernel on MI355X in round 1, so it is off by default."""
+    segmented: None = use the XCD-affine segmented kernel (tgcn_spmm_segmented_f32) when the CSR has a segment plan
+    for this width (DeviceCSR(segment=...)), False = never, True = require it."""
     dev = csr.device
     if dev.type != 'cuda':
         raise RuntimeError('textgcn_amd kernels run on a ROCm GPU only (device is %s)' % dev)
@@ -132,19 +175,25 @@ def spmm(csr, x, y=None, acc_in=None, acc_out=None, acc_div=1.0, exact=False, va
             _check_dense(t, name, dev, csr.n_rows, d)
     if y is not None and y.data_ptr() == x.data_ptr():
         raise ValueError('y must not alias x')
-    plan = None if exact else csr.plan(d)
+    own_vals = vals is None
     if vals is None:
         vals = csr.vals
     elif vals.dtype != torch.float32 or vals.numel() != max(csr.nnz, 1) or vals.device != dev or not vals.is_contiguous():
         raise ValueError('vals must be a contiguous float32 device tensor with one entry per stored element')
-    plans, n_plans = csr.block_plans(d) if (blocked and not exact and variant == _capi.SPMM_AUTO) else (None, 0)
-    if n_plans:
-        rc = _capi.lib().tgcn_spmm_blocked_f32(
-            plans, n_plans, _capi.ptr(csr.rowptr), _capi.ptr(csr.colidx), _capi.ptr(vals), csr.n_rows, _capi.ptr(x),
-            csr.n_src_rows, d, _capi.ptr(y), _capi.ptr(acc_in), _capi.ptr(acc_out), float(acc_div), plan,
+    # the segment plan carries its own copy of the stored values: a per-call `vals` (dropout) takes the plain kernels
+    seg = None
+    if segmented is not False and not exact and variant == _capi.SPMM_AUTO and own_vals:
+        seg = csr.segment_plan(d)
+    if segmented is True and seg is None:
+        raise ValueError('segmented=True but this CSR has no segment plan for the call (width, exact, vals or variant)')
+    if seg is not None:
+        rc = _capi.lib().tgcn_spmm_segmented_f32(
+            seg, _capi.ptr(csr.rowptr), _capi.ptr(csr.colidx), _capi.ptr(vals), csr.n_rows, _capi.ptr(x), csr.n_src_rows, d,
+            _capi.ptr(y), _capi.ptr(acc_in), _capi.ptr(acc_out), float(acc_div), (unroll & 0xff) << 8,
             _capi.current_stream(dev))
-        _capi.check(rc, 'tgcn_spmm_blocked_f32')
+        _capi.check(rc, 'tgcn_spmm_segmented_f32')
         return y if y is not None else acc_out
+    plan = None if exact else csr.plan(d)
     rc = _capi.lib().tgcn_spmm_csr_f32(
         _capi.ptr(csr.rowptr), _capi.ptr(csr.colidx), _capi.ptr(vals), csr.n_rows, _capi.ptr(x), csr.n_src_rows, d,
         _capi.ptr(y), _capi.ptr(acc_in), _capi.ptr(acc_out), float(acc_div), plan, _capi.ptr(csr.row_order),
@@ -161,14 +210,14 @@ class Propagator:
     E(k+1) = A . E(k).  Buffers are allocated once per embedding width and reused.
     """
 
-    def __init__(self, graph: NormGraph, device, split_threshold=DEFAULT_SPLIT_THRESHOLD, block_bytes=DEFAULT_BLOCK_BYTES):
+    def __init__(self, graph: NormGraph, device, split_threshold=DEFAULT_SPLIT_THRESHOLD, segment='auto'):
         self.graph = graph
         self.device = torch.device(device)
         u, n = graph.n_users, graph.n
         # A is bipartite: user rows hold item columns and vice versa
-        specs = [(0, u, u, n), (u, n, 0, u)] if block_bytes else None
+        specs = [(0, u, u, n), (u, n, 0, u)]
         self.csr = DeviceCSR(graph.rowptr, graph.colidx, graph.vals, graph.n, self.device, split_threshold,
-                             block_specs=specs, block_bytes=block_bytes or DEFAULT_BLOCK_BYTES)
+                             block_specs=specs, segment=segment)
         self._buf = {}
         self._graphs = {}
         self._graph_out = {}
@@ -180,7 +229,7 @@ class Propagator:
         return self._buf[d]
 
     def forward(self, e0, n_layers, single=False, exact=False, out=None, keep_layers=False, variant=_capi.SPMM_AUTO,
-                unroll=0, vals=None, blocked=False):
+                unroll=0, vals=None, segmented=None):
         n = self.graph.n
         _check_dense(e0, 'e0', self.device, n)
         d = e0.shape[1]
@@ -201,7 +250,7 @@ class Propagator:
                 y = ping if (k & 1) else pong
             if single:
                 spmm(self.csr, x, y=out if (last and not keep_layers) else y, exact=exact, variant=variant, unroll=unroll,
-                     vals=vals, blocked=blocked)
+                     vals=vals, segmented=segmented)
                 if last and keep_layers:
                     out.copy_(y)
             else:
@@ -209,7 +258,7 @@ class Propagator:
                 # the last layer's own Y is not needed (no store)
                 spmm(self.csr, x, y=None if (last and not keep_layers) else y, acc_in=e0 if k == 1 else acc,
                      acc_out=out if last else acc, acc_div=float(n_layers + 1) if last else 1.0, exact=exact,
-                     variant=variant, unroll=unroll, vals=vals, blocked=blocked)
+                     variant=variant, unroll=unroll, vals=vals, segmented=segmented)
             if keep_layers:
                 layers.append(y)
             x = y

@@ -65,11 +65,17 @@ def main():
     summary['calibration_known_bytes'] = known
     # ---- HBM-side traffic of one SpMM layer launch (bench pass), corrected per MI355X_MICROARCH.md §HBM:
     # FETCH_SIZE (KiB) tallies 128-B requests at 64 B for wide coalesced reads -> x2; WRITE_SIZE is exact.
-    spmm = [k for k in summary.get('bench_FETCH_SIZE', {}) if k.startswith(('k_spmm_wave', 'k_spmm_group', 'k_spmm_blocked'))]
+    fs, wsz = summary.get('bench_FETCH_SIZE', {}), summary.get('bench_WRITE_SIZE', {})
+    main = [k for k in fs if k.startswith(('k_spmm_seg<', 'k_spmm_wave', 'k_spmm_group'))]
+    main = sorted(main, key=lambda k: -fs[k]['FETCH_SIZE']['mean'] * fs[k]['FETCH_SIZE']['n'])[:1]
+    spmm = main + [k for k in fs if k.startswith(('k_spmm_seg_reduce', 'k_spmm_long_reduce')) and main
+                   and (k.startswith('k_spmm_seg_reduce') == main[0].startswith('k_spmm_seg<'))]
     if spmm:
         k = spmm[0]
-        fetch_kib = summary['bench_FETCH_SIZE'][k]['FETCH_SIZE']['mean']
-        write_kib = summary['bench_WRITE_SIZE'][k]['WRITE_SIZE']['mean']
+        n_main = fs[k]['FETCH_SIZE']['n']
+        # one layer = the main launch + its reduce launch: per-layer bytes = sum over the kernels of (total / layers)
+        fetch_kib = sum(fs[x]['FETCH_SIZE']['mean'] * fs[x]['FETCH_SIZE']['n'] for x in spmm) / n_main
+        write_kib = sum(wsz[x]['WRITE_SIZE']['mean'] * wsz[x]['WRITE_SIZE']['n'] for x in spmm) / wsz[k]['WRITE_SIZE']['n']
         cal = {}
         if known and 'cal_FETCH_SIZE' in summary:
             ck = [x for x in summary['cal_FETCH_SIZE'] if x.startswith('k_spmm')][0]
@@ -79,7 +85,7 @@ def main():
                    'known_write_bytes': known['write_bytes_per_launch']}
         traffic = {'hbm_bytes_per_layer': int(2 * fetch_kib * 1024 + write_kib * 1024),
                    'read_bytes_corrected': int(2 * fetch_kib * 1024), 'write_bytes': int(write_kib * 1024),
-                   'fetch_size_kib_raw': fetch_kib, 'write_size_kib_raw': write_kib, 'kernel': k,
+                   'fetch_size_kib_raw': fetch_kib, 'write_size_kib_raw': write_kib, 'kernels': spmm,
                    'correction': "FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B), WRITE_SIZE x1; the counters sit on "
                                  "the L2's memory side, so Infinity-Cache hits are included (this is L2-miss traffic)",
                    'calibration': cal, 'round': args.round}
