@@ -88,7 +88,7 @@ int tgcn_spmm_csr_f32(const int32_t *rowptr, const int32_t *colidx, const float 
  * entries of the segmented rows, as streams: stream x of a row range keeps the entries whose column falls in column
  * blocks x, x+8, ... ordered by (block, row, column).  A row's run inside one block is a segment; streams are cut
  * into tiles of `tile_entries` entries, one wavefront each, and a segment crossing a cut becomes two pieces.  The
- * last entry of a piece carries bit 31 in its column word; the wavefront sums a piece as a sequential fmaf chain
+ * last entry of a piece has its bit set in `ent_flags`; the wavefront sums a piece as a sequential fmaf chain
  * from +0 into workspace[slot] (slots count pieces in tile order from tile_meta[t][0]).  A second launch adds the
  * pieces row_slots[row_slot_ptr[i] .. row_slot_ptr[i+1]) of row seg_rows[i] in that (column) order and applies the
  * Y / acc epilogue.  Tiles are laid out so that a workgroup (4 consecutive tiles) stays in one stream and workgroups
@@ -105,8 +105,9 @@ typedef struct tgcn_segment_plan {
     int32_t n_slots;
     int32_t _pad;
     const int32_t *tile_meta;    /* [n_tiles][2]: {first slot, entries in the tile (0: padding)} */
-    const int32_t *ent_col;      /* [n_tiles * tile_entries]: column | (last entry of its piece ? 1 << 31 : 0) */
+    const int32_t *ent_col;      /* [n_tiles * tile_entries] column ids */
     const float *ent_val;        /* [n_tiles * tile_entries] */
+    const uint64_t *ent_flags;   /* [n_tiles * tile_entries / 64]: bit i of word w set = entry 64 w + i is the last of its piece */
     const int32_t *seg_rows;     /* [n_seg_rows] local row ids */
     const int32_t *row_slot_ptr; /* [n_seg_rows + 1] */
     const int32_t *row_slots;    /* [n_slots] a row's pieces in column order */

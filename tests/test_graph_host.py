@@ -145,7 +145,7 @@ def test_segment_plan_streams_reproduce_the_product():
         phases = [(U, N, 0, U, nb_items)] + ([(0, U, U, N, nb_users)] if nb_users else [])
         p = segment_plan_arrays(g.rowptr, g.colidx, g.vals, phases, tile_entries=T)
         n_tiles = len(p['tile_meta'])
-        assert n_tiles % 4 == 0 and len(p['ent_col']) == n_tiles * T == len(p['ent_val'])
+        assert n_tiles % 4 == 0 and len(p['ent_col']) == n_tiles * T == len(p['ent_val']) == 64 * len(p['ent_flags'])
         ws = np.zeros((p['n_slots'], 8))
         written = np.zeros(p['n_slots'], dtype=np.int32)
         tile_class = np.full(n_tiles, -1)
@@ -154,7 +154,7 @@ def test_segment_plan_streams_reproduce_the_product():
             acc, first_col = np.zeros(8), None
             for e in range(t * T, t * T + n):
                 c = int(p['ent_col'][e])
-                flag, c = c < 0, c & 0x7fffffff
+                flag = (int(p['ent_flags'][e // 64]) >> (e % 64)) & 1
                 first_col = c if first_col is None else first_col
                 acc = acc + np.float64(p['ent_val'][e]) * x[c]
                 for (r0, r1, c0, c1, nb) in phases:

@@ -275,8 +275,8 @@ def test_edge_cases_empty_and_isolated(cuda, oracle):
 
 @pytest.mark.parametrize('d', [64, 128, 256])
 @pytest.mark.parametrize('blocks', [(0, 8), (8, 16), (24, 0)])
-@pytest.mark.parametrize('tile', [256, 64])
-def test_segmented_xcd_affine_kernel(cuda, oracle, d, blocks, tile):
+@pytest.mark.parametrize('tile,min_len', [(256, 0), (64, 32)])
+def test_segmented_xcd_affine_kernel(cuda, oracle, d, blocks, tile, min_len):
     """tgcn_spmm_segmented_f32: rows cut at column-block boundaries, piece sums added in column order.  Direct rows
     are bit-exact, segmented rows agree with the one-chain result to rounding, runs are identical (no atomics), and the
     fused epilogue (acc_in/acc_out/acc_div, Y optional) matches the oracle's layer sum."""
@@ -288,7 +288,7 @@ def test_segmented_xcd_affine_kernel(cuda, oracle, d, blocks, tile):
     idx, val = gr.to_coo()
     ref = oracle.spmm_coo(idx, val, x)
     prop = Propagator(gr, cuda)
-    prop.csr.configure_segments(list(blocks), tile_entries=tile)    # specs: (user rows, item rows)
+    prop.csr.configure_segments(list(blocks), tile_entries=tile, min_row_len=min_len)    # specs: (user rows, item rows)
     xd, e0d = torch.from_numpy(x).to(cuda), torch.from_numpy(e0).to(cuda)
     outs = []
     for unroll in (0, 8, 0):
@@ -302,7 +302,8 @@ def test_segmented_xcd_affine_kernel(cuda, oracle, d, blocks, tile):
         direct[:gr.n_users] = True
     if blocks[1] == 0:
         direct[gr.n_users:] = True
-    direct |= gr.degrees() == 0
+    direct |= gr.degrees() < max(min_len, 1)
+    assert not direct.all()
     assert np.array_equal(bits(outs[0][direct]), bits(ref[direct]))
     # fused epilogue on top of the segmented sums
     acc = torch.full((gr.n, d), float('nan'), device=cuda)

@@ -23,7 +23,7 @@ class SegmentPlanStruct(Structure):
     """mirror of tgcn_segment_plan_t"""
     _fields_ = [('n_tiles', c_int32), ('tile_entries', c_int32), ('n_seg_rows', c_int32), ('n_direct_rows', c_int32),
                 ('n_slots', c_int32), ('_pad', c_int32), ('tile_meta', c_void_p), ('ent_col', c_void_p),
-                ('ent_val', c_void_p), ('seg_rows', c_void_p), ('row_slot_ptr', c_void_p), ('row_slots', c_void_p),
+                ('ent_val', c_void_p), ('ent_flags', c_void_p), ('seg_rows', c_void_p), ('row_slot_ptr', c_void_p), ('row_slots', c_void_p),
                 ('direct_rows', c_void_p), ('workspace', c_void_p)]
 
 

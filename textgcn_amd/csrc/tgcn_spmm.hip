@@ -251,22 +251,64 @@ __global__ __launch_bounds__(256) void k_spmm_group(const SpmmArgs a)
 
 // XCD-affine segmented launch (tgcn_spmm_segmented_f32).  Waves [0, n_tiles) walk one tile each of the plan's
 // own (column, value) streams: 64 pairs are loaded at a time (the next 64 while the current ones are consumed),
-// rows of X are gathered 16 at a time exactly as in accumulate_wave, and every entry whose column word carries
-// bit 31 closes a piece: the running sum goes to the next workspace slot and restarts from +0.  The branch on the
-// flag is scalar (the column word sits in an SGPR after v_readlane).  The remaining waves own one direct row each.
+// rows of X are gathered 16 or 32 at a time, and every entry whose bit is set in the stream's flag words
+// closes a piece: the running sum goes to the next workspace slot and restarts from +0.  The branch on the
+// flag is scalar (the flag word is wave-uniform).  The remaining waves own one direct row each.
 struct SegArgs {
     const int2 *__restrict__ tile_meta;  // {first slot, entries}
     const int *__restrict__ ent_col;
     const float *__restrict__ ent_val;
+    const unsigned long long *__restrict__ ent_flags;  // bit i of word w: entry 64 w + i closes a piece
     const int *__restrict__ direct_rows;
     int n_tiles;
     int tile_entries;
     int n_direct;
 };
 
+// One batch of a tile wave: UNROLL row gathers in flight, then the fmaf chain; an entry whose bit is set in `fm`
+// (bit u = entry j + u closes a piece) stores the running sum to the next workspace slot and restarts the chain.
+// The gathered table is < 4 GB (checked by the entry point), so a row's byte offset is one s_lshl of the column
+// id and the load is SGPR base + 32-bit VGPR offset: v_readlane, s_lshl, v_add, global_load per entry.  Flags are
+// tested four entries at a time: most groups of four close no piece and run four fmaf back to back.
+// FULL: all UNROLL entries exist (every 64-entry slab but a stream's last one), so no per-entry bounds test.
+template <int VEC, int UNROLL, bool FULL>
+__device__ __forceinline__ void tile_batch(const char *__restrict__ Xb, unsigned lane_off, float *__restrict__ wsl, int c, float v,
+                                           int j, int n, unsigned fm, int &slot, float (&acc)[VEC])
+{
+    constexpr unsigned kRowShift = VEC == 1 ? 8 : VEC == 2 ? 9 : 10;  // log2(4 * d)
+    constexpr size_t d = 64 * VEC;
+    float x[UNROLL][VEC];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+        const unsigned cj = (unsigned)__builtin_amdgcn_readlane(c, FULL ? j + u : min(j + u, n - 1));
+        load_vec<VEC>(reinterpret_cast<const float *>(Xb + ((cj << kRowShift) + lane_off)), x[u]);
+    }
+#pragma unroll
+    for (int u4 = 0; u4 < UNROLL; u4 += 4) {
+        const bool any = (fm >> u4) & 0xfu;  // scalar
+#pragma unroll
+        for (int u = u4; u < u4 + 4; ++u) {
+            if (FULL || j + u < n) {
+                const float vj = readlane_f(v, j + u);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k)
+                    acc[k] = fmaf(vj, x[u][k], acc[k]);
+                if (any && (fm & (1u << u))) {  // last entry of a piece
+                    store_vec<VEC>(wsl + (size_t)slot * d, acc);
+                    ++slot;
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k)
+                        acc[k] = 0.0f;
+                }
+            }
+        }
+    }
+}
+
 template <int VEC, int UNROLL>
 __global__ __launch_bounds__(256) void k_spmm_seg(const SpmmArgs a, const SegArgs g)
 {
+    static_assert(UNROLL <= 32 && UNROLL % 4 == 0 && kWave % UNROLL == 0, "a batch's flag bits must fit one 32-bit word");
     const int lane = lane_id();
     const int wave = uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (wave >= g.n_tiles) {
@@ -290,48 +332,36 @@ __global__ __launch_bounds__(256) void k_spmm_seg(const SpmmArgs a, const SegArg
     const size_t base = (size_t)wave * g.tile_entries;
     const int *__restrict__ ec = g.ent_col + base;
     const float *__restrict__ ev = g.ent_val + base;
-    const float *__restrict__ Xl = a.X + lane * VEC;
+    const unsigned long long *__restrict__ ef = g.ent_flags + (base >> 6);
+    const char *__restrict__ Xb = reinterpret_cast<const char *>(a.X);
+    const unsigned lane_off = lane * VEC * 4;
     float *__restrict__ wsl = a.ws + lane * VEC;
-    const size_t d = (size_t)a.d;
     float acc[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k)
         acc[k] = 0.0f;
     int c = ec[lane];  // tiles are stored whole: no bounds test
     float v = ev[lane];
+    unsigned long long flags = ef[0];
     for (int off = 0; off < n_ent; off += kWave) {
         const int n = min(kWave, n_ent - off);  // uniform
         int c_nxt = 0;
         float v_nxt = 0.0f;
+        unsigned long long f_nxt = 0;
         if (off + kWave < n_ent) {  // uniform
             c_nxt = ec[off + kWave + lane];
             v_nxt = ev[off + kWave + lane];
+            f_nxt = ef[(off >> 6) + 1];
         }
-        for (int j = 0; j < n; j += UNROLL) {
-            float x[UNROLL][VEC];
+        if (n == kWave) {
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                const int cj = __builtin_amdgcn_readlane(c, min(j + u, n - 1)) & 0x7fffffff;
-                load_vec<VEC>(Xl + (size_t)cj * d, x[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                if (j + u < n) {
-                    const float vj = readlane_f(v, j + u);
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k)
-                        acc[k] = fmaf(vj, x[u][k], acc[k]);
-                    if (__builtin_amdgcn_readlane(c, j + u) < 0) {  // last entry of a piece
-                        store_vec<VEC>(wsl + (size_t)slot * d, acc);
-                        ++slot;
-#pragma unroll
-                        for (int k = 0; k < VEC; ++k)
-                            acc[k] = 0.0f;
-                    }
-                }
-            }
+            for (int j = 0; j < kWave; j += UNROLL)
+                tile_batch<VEC, UNROLL, true>(Xb, lane_off, wsl, c, v, j, n, (unsigned)(flags >> j), slot, acc);
+        } else {
+            for (int j = 0; j < n; j += UNROLL)
+                tile_batch<VEC, UNROLL, false>(Xb, lane_off, wsl, c, v, j, n, (unsigned)(flags >> j), slot, acc);
         }
-        c = c_nxt, v = v_nxt;
+        c = c_nxt, v = v_nxt, flags = f_nxt;
     }
 }
 
@@ -605,8 +635,10 @@ extern "C" int tgcn_spmm_segmented_f32(const tgcn_segment_plan_t *plan, const in
     TGCN_REQUIRE((int64_t)plan->n_tiles * plan->tile_entries < INT_MAX, "segment streams too large");
     TGCN_REQUIRE(plan->n_seg_rows >= 0 && plan->n_direct_rows >= 0 && plan->n_slots >= 0, "negative plan counts");
     TGCN_REQUIRE((int64_t)plan->n_seg_rows + plan->n_direct_rows == n_rows, "plan does not cover every row once");
-    TGCN_REQUIRE(plan->n_tiles == 0 || (plan->tile_meta && plan->ent_col && plan->ent_val && plan->workspace),
+    TGCN_REQUIRE(plan->n_tiles == 0 || (plan->tile_meta && plan->ent_col && plan->ent_val && plan->ent_flags && plan->workspace),
                  "segment stream arrays are NULL");
+    TGCN_REQUIRE(plan->n_tiles == 0 || (uint64_t)n_src_rows * (uint64_t)d * 4u < (1ull << 32),
+                 "segmented SpMM needs a gathered table below 4 GB (it is meant for tables of a few L2 sizes)");
     TGCN_REQUIRE(plan->n_seg_rows == 0 || (plan->seg_rows && plan->row_slot_ptr && plan->row_slots && plan->workspace),
                  "segment row arrays are NULL");
     TGCN_REQUIRE(plan->n_direct_rows == 0 || plan->direct_rows, "direct_rows is NULL");
@@ -619,6 +651,7 @@ extern "C" int tgcn_spmm_segmented_f32(const tgcn_segment_plan_t *plan, const in
     a.threshold = INT_MAX, a.n_chunks = 0, a.chunk_beg = nullptr, a.chunk_end = nullptr, a.ws = plan->workspace;
     SegArgs g;
     g.tile_meta = reinterpret_cast<const int2 *>(plan->tile_meta), g.ent_col = plan->ent_col, g.ent_val = plan->ent_val;
+    g.ent_flags = reinterpret_cast<const unsigned long long *>(plan->ent_flags);
     g.direct_rows = plan->direct_rows;
     g.n_tiles = plan->n_tiles, g.tile_entries = plan->tile_entries, g.n_direct = plan->n_direct_rows;
     const int unroll = (flags >> 8) & 0xff;

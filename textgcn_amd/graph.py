@@ -159,19 +159,19 @@ def split_plan_arrays(rowptr, threshold):
     }
 
 
-def segment_plan_arrays(rowptr, colidx, vals, phases, tile_entries=256, n_classes=8):
+def segment_plan_arrays(rowptr, colidx, vals, phases, tile_entries=256, n_classes=8, min_row_len=0):
     """Host arrays of a tgcn_segment_plan_t (XCD-affine column blocking, include/tgcn.h).
 
     phases: list of (row_begin, row_end, col_lo, col_hi, n_blocks) -- row ranges whose entries fall in one column
     range, cut into n_blocks column blocks (a multiple of n_classes).  The entries of a phase are copied into
     n_classes streams: stream x holds the entries of blocks x, x + n_classes, ... ordered by (block, row, column).
     A row's run inside one block is a segment; streams are cut into tiles of `tile_entries` entries (one wavefront
-    each) and a segment crossing a cut becomes two pieces.  The last entry of every piece carries bit 31 in its
-    column word; pieces are numbered in stream order (workspace slots).  Tiles are laid out so that a workgroup (4
+    each) and a segment crossing a cut becomes two pieces.  The last entry of every piece has its bit set in
+    `ent_flags` (one 64-bit word per 64 entries); pieces are numbered in stream order (workspace slots).  Tiles are laid out so that a workgroup (4
     consecutive tiles) stays inside one stream and workgroups g, g + n_classes, ... share a stream: workgroups are
     dealt round-robin over the 8 XCDs, so each XCD's L2 serves 1/n_classes of the gathered table (speed only --
     results never depend on the placement).  A row's value is the sum of its pieces in column order (`row_slots`).
-    Rows outside every phase, and rows without entries, are `direct` rows.
+    Rows outside every phase, rows with fewer than `min_row_len` entries and rows without entries are `direct` rows.
     """
     rowptr = np.asarray(rowptr, dtype=np.int64)
     colidx = np.asarray(colidx)
@@ -196,8 +196,13 @@ def segment_plan_arrays(rowptr, colidx, vals, phases, tile_entries=256, n_classe
         if cols.min() < c0 or cols.max() >= c1:
             raise ValueError('entries outside the declared column range')
         lens = np.diff(rowptr[r0:r1 + 1])
-        direct[r0:r1] = lens == 0
         rows = np.repeat(np.arange(n_r, dtype=np.int64), lens)
+        ent_off = np.arange(a, b, dtype=np.int64)
+        if min_row_len > 0:       # short rows leave too few entries per block: they stay direct
+            keep = (lens >= min_row_len)[rows]
+            cols, rows, ent_off = cols[keep], rows[keep], ent_off[keep]
+            if len(cols) == 0:
+                continue
         width = -(-(c1 - c0) // nb)
         blk = (cols - c0) // width
         cls, sub = blk % n_classes, blk // n_classes
@@ -219,7 +224,7 @@ def segment_plan_arrays(rowptr, colidx, vals, phases, tile_entries=256, n_classe
         ent_col = np.zeros(n_t * n_classes * T, dtype=np.int64)
         ent_val = np.zeros(n_t * n_classes * T, dtype=np.float32)
         ent_col[dst] = cols[order] | (last.astype(np.int64) << 31)
-        ent_val[dst] = vals[a:b][order]
+        ent_val[dst] = vals[ent_off[order]]
         slot = slot_base + np.cumsum(last) - 1                                    # slot of the piece an entry ends
         meta = np.zeros((n_t * n_classes, 2), dtype=np.int64)
         meta[:, 1] = np.bincount(tile_id, minlength=n_t * n_classes)
@@ -228,7 +233,7 @@ def segment_plan_arrays(rowptr, colidx, vals, phases, tile_entries=256, n_classe
         # slot of a tile's first piece = pieces closed before its first entry
         meta[tile_id[first], 0] = slot_base + (np.cumsum(last) - last)[first]
         tiles_col.append(ent_col), tiles_val.append(ent_val), tiles_meta.append(meta)
-        flag_orig.append(a + order[last]), flag_slot.append(slot[last])
+        flag_orig.append(ent_off[order][last]), flag_slot.append(slot[last])
         slot_base += int(last.sum())
     cat = lambda xs, dt: np.concatenate(xs).astype(dt) if xs else np.zeros(0, dtype=dt)   # noqa: E731
     f_orig, f_slot = cat(flag_orig, np.int64), cat(flag_slot, np.int64)
@@ -244,7 +249,8 @@ def segment_plan_arrays(rowptr, colidx, vals, phases, tile_entries=256, n_classe
     return {
         'tile_entries': T, 'n_slots': int(slot_base),
         'tile_meta': np.ascontiguousarray(cat(tiles_meta, np.int64).reshape(-1, 2).astype(np.int32)),
-        'ent_col': (ent_col & 0x7fffffff).astype(np.int32) | np.where(ent_col >> 31, np.int32(-2**31), np.int32(0)),
+        'ent_col': (ent_col & 0x7fffffff).astype(np.int32),
+        'ent_flags': np.packbits((ent_col >> 31).astype(np.uint8).reshape(-1, 64), axis=1, bitorder='little').view(np.int64).reshape(-1),   # uint64 words, carried as int64
         'ent_val': cat(tiles_val, np.float32),
         'seg_rows': seg_rows.astype(np.int32), 'row_slot_ptr': row_slot_ptr.astype(np.int32),
         'row_slots': f_slot.astype(np.int32), 'direct_rows': np.nonzero(direct)[0].astype(np.int32),

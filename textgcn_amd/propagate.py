@@ -16,6 +16,7 @@ DEFAULT_SPLIT_THRESHOLD = 1024
 L2_SHARE_BYTES = 3 << 20        # of an XCD's 4 MB L2 that a gathered table can count on next to the streaming traffic
 SEGMENT_CLASSES = 8             # one column-block class per XCD
 SEGMENT_TILE_ENTRIES = 1024     # entries per tile wave (measured on config 2: 512..1024 within 1 %, 256 -8 %, 2048 -30 %)
+SEGMENT_MIN_ROW_LEN = 32        # shorter rows stay direct: < 4 entries per block do not pay for a workspace slot (+3 %)
 
 
 def segment_blocks_auto(rowptr, colidx, spec, d):
@@ -87,6 +88,7 @@ class DeviceCSR:
         self._segment_mode = segment
         self.segment_blocks = None    # per (d): block counts per block_spec
         self.segment_tile = SEGMENT_TILE_ENTRIES
+        self.segment_min_row_len = SEGMENT_MIN_ROW_LEN
         self._segment_plans = {}
 
     @property
@@ -106,13 +108,14 @@ class DeviceCSR:
             self._plan_struct[d] = (st, ws)
         return ctypes.byref(self._plan_struct[d][0])
 
-    def configure_segments(self, blocks_per_spec, tile_entries=SEGMENT_TILE_ENTRIES):
+    def configure_segments(self, blocks_per_spec, tile_entries=SEGMENT_TILE_ENTRIES, min_row_len=SEGMENT_MIN_ROW_LEN):
         """Set the XCD-affine segmentation by hand: blocks_per_spec[i] column blocks (a multiple of 8) for
         block_specs[i]; 0 keeps that row range on the one-wave-per-row path.  ('auto' picks these per width.)"""
         if not self._block_specs or len(blocks_per_spec) != len(self._block_specs):
             raise ValueError('one block count per block_spec is required')
         self._segment_mode = [int(b) for b in blocks_per_spec]
         self.segment_tile = int(tile_entries)
+        self.segment_min_row_len = int(min_row_len)
         self._segment_plans = {}
 
     def segment_plan(self, d):
@@ -128,14 +131,13 @@ class DeviceCSR:
             entry = None
             if any(blocks):
                 phases = [(r0, r1, c0, c1, nb) for (r0, r1, c0, c1), nb in zip(self._block_specs, blocks) if nb]
-                h = segment_plan_arrays(rowptr, colidx, self.vals.cpu().numpy(), phases, self.segment_tile)
-                dr = h['direct_rows']
-                h['direct_rows'] = dr[np.argsort(-lens[dr], kind='stable')].astype(np.int32)   # longest first
+                h = segment_plan_arrays(rowptr, colidx, self.vals.cpu().numpy(), phases, self.segment_tile,
+                                        min_row_len=self.segment_min_row_len)
                 dv = {k: torch.from_numpy(v).to(self.device) for k, v in h.items() if isinstance(v, np.ndarray)}
                 ws = torch.empty((max(h['n_slots'], 1), d), dtype=torch.float32, device=self.device)
                 st = _capi.SegmentPlanStruct(len(h['tile_meta']), h['tile_entries'], len(h['seg_rows']), len(h['direct_rows']),
                                              h['n_slots'], 0, dv['tile_meta'].data_ptr(), dv['ent_col'].data_ptr(),
-                                             dv['ent_val'].data_ptr(), dv['seg_rows'].data_ptr(),
+                                             dv['ent_val'].data_ptr(), dv['ent_flags'].data_ptr(), dv['seg_rows'].data_ptr(),
                                              dv['row_slot_ptr'].data_ptr(), dv['row_slots'].data_ptr(),
                                              dv['direct_rows'].data_ptr(), ws.data_ptr())
                 entry = (st, ws, dv, h)

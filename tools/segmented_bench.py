@@ -20,6 +20,7 @@ def main():
     ap.add_argument('--configs', nargs='+', default=['0,8', '8,8', '0,16'])
     ap.add_argument('--tile', type=int, nargs='+', default=[256])
     ap.add_argument('--unroll', type=int, nargs='+', default=[0])
+    ap.add_argument('--min-row-len', type=int, nargs='+', default=[0])
     ap.add_argument('--steps', type=int, default=30)
     args = ap.parse_args()
     from textgcn_amd import propagate, synth
@@ -44,18 +45,18 @@ def main():
         torch.cuda.synchronize()
         return a.elapsed_time(b) / args.steps
 
-    base = timed(lambda: prop.forward(e0, K, out=out))
+    base = timed(lambda: prop.forward(e0, K, out=out, segmented=False))
     ref = out.clone()
     print(json.dumps({'variant': 'plain', 'ms_per_forward': round(base, 4)}), flush=True)
     for cfg in args.configs:
         bu, bi = (int(t) for t in cfg.split(','))
-        for ml in args.tile:
-            prop.csr.configure_segments([bu, bi], tile_entries=ml)
+        for ml, mr in [(x, y) for x in args.tile for y in args.min_row_len]:
+            prop.csr.configure_segments([bu, bi], tile_entries=ml, min_row_len=mr)
             for un in args.unroll:
                 ms = timed(lambda: prop.forward(e0, K, out=out, segmented=True, unroll=un))
                 err = float(torch.linalg.norm(out - ref) / torch.linalg.norm(ref))
-                h = prop.csr._segment_plan[0]
-                print(json.dumps({'variant': f'segmented users={bu} items={bi}', 'tile': ml, 'unroll': un,
+                h = prop.csr._segment_plans[d][0][3]
+                print(json.dumps({'variant': f'segmented users={bu} items={bi}', 'tile': ml, 'min_row_len': mr, 'unroll': un,
                                   'ms_per_forward': round(ms, 4), 'vs_plain': round(base / ms, 3), 'normwise_vs_plain': err,
                                   'tiles': len(h['tile_meta']), 'slots': h['n_slots'],
                                   'direct_rows': len(h['direct_rows'])}), flush=True)
