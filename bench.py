@@ -221,7 +221,7 @@ def main():
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': t / args.steps * 1e3, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': wl_name, 'nnz_A': graph.nnz, 'n_nodes': graph.n, 'max_degree': int(graph.degrees().max()),
-                   'mode': 'exact (one fmaf chain per row)' if args.exact else f'rows > {thr} entries split in chunks',
+                   'mode': 'exact (one fmaf chain per row)' if args.exact else f'one-wave-per-row kernel: rows > {thr} entries split in chunks',
                    'xcd_segments': seg_note,
                    'sharding': 'none' if world == 1 else f'row-sharded x{world}, RCCL all-gather per layer (users ∥ item half-step)',
                    'graph_build_s': round(build_s, 1)},
