@@ -18,6 +18,8 @@ def main():
     ap.add_argument('--workload', default='c2')
     ap.add_argument('--unroll', type=int, nargs='+', default=[0])
     ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--segment-items', type=int, default=0, help='also time the item rows alone through the segmented kernel with this many column blocks')
+    ap.add_argument('--tile', type=int, default=1024)
     args = ap.parse_args()
     from textgcn_amd import propagate, synth
     from textgcn_amd.graph import NormGraph
@@ -27,9 +29,16 @@ def main():
     dev = torch.device('cuda:0')
     x = synth.embeddings(g.n, d, seed=0).to(dev)
     parts = {'users': (0, n_u), 'items': (n_u, g.n), 'all': (0, g.n)}
+    if args.segment_items:
+        parts = {'items': (n_u, g.n), 'items-segmented': (n_u, g.n)}
     for name, (r0, r1) in parts.items():
         rp, ci, va = g.row_block(r0, r1)
-        csr = propagate.DeviceCSR(rp, ci, va, g.n, dev, split_threshold=propagate.DEFAULT_SPLIT_THRESHOLD)
+        if name == 'items-segmented':
+            csr = propagate.DeviceCSR(rp, ci, va, g.n, dev, split_threshold=propagate.DEFAULT_SPLIT_THRESHOLD,
+                                      block_specs=[(0, r1 - r0, 0, n_u)], segment=[args.segment_items])
+            csr.segment_tile = args.tile
+        else:
+            csr = propagate.DeviceCSR(rp, ci, va, g.n, dev, split_threshold=propagate.DEFAULT_SPLIT_THRESHOLD)
         y = torch.empty((r1 - r0, d), device=dev)
         acc = torch.empty((r1 - r0, d), device=dev)
         e0 = x[r0:r1].contiguous()
