@@ -207,7 +207,8 @@ def main():
     layer_bytes = [algorithmic_bytes_per_layer(nnz_local, n_rows_local, n_src, d, k, K, False) for k in range(1, K + 1)]
     mean_layer_s = t_dev / (args.steps * K)
     achieved = float(np.mean(layer_bytes)) / mean_layer_s / 1e9
-    traffic = load_traffic(wl if world == 1 else None)
+    # the PMC pass was taken on the default path of the workload (profiles/hbm_traffic.json)
+    traffic = load_traffic(wl if world == 1 and not args.exact and not args.no_segment else None)
     roofline = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
                 # measured memory-side bytes (PMC pass, profiles/) over the live launch time: what the fabric moves

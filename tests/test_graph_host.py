@@ -181,3 +181,22 @@ def test_segment_plan_streams_reproduce_the_product():
         assert np.allclose(y[seg], ref[seg], rtol=1e-12, atol=1e-12)
         if not nb_users:
             assert np.all(p['direct_rows'] < U) and len(p['direct_rows']) == U
+
+
+def test_segment_heuristic_picks_item_rows_of_config_2_only():
+    """propagate.segment_blocks_auto: on BASELINE config 2 the item rows (uniformly used 25.6 MB user table, 100
+    entries per row) are segmented, the user rows (Zipf-popular 12.8 MB item table, 50 entries per row) are not; a
+    small graph and a width-128 table beyond 8 L2 shares are left alone."""
+    from textgcn_amd import synth
+    from textgcn_amd.graph import NormGraph
+    from textgcn_amd.propagate import segment_blocks_auto
+    n_u, n_i, nnz, d, _ = synth.CONFIGS['c2']
+    u, i = synth.interactions(n_u, n_i, nnz, seed=0)
+    g = NormGraph.from_pairs(u, i, n_u, n_i)
+    specs = [(0, n_u, n_u, g.n), (n_u, g.n, 0, n_u)]
+    assert [segment_blocks_auto(g.rowptr, g.colidx, sp, 64) for sp in specs] == [0, 8]
+    assert [segment_blocks_auto(g.rowptr, g.colidx, sp, 128) for sp in specs] == [0, 0]     # 51 MB user table at d = 128
+    assert [segment_blocks_auto(g.rowptr, g.colidx, sp, 48) for sp in specs] == [0, 0]      # no kernel for this width
+    u, i = synth.interactions(600, 300, 9000, seed=1)
+    gs = NormGraph.from_pairs(u, i, 600, 300)
+    assert [segment_blocks_auto(gs.rowptr, gs.colidx, sp, 64) for sp in [(0, 600, 600, 900), (600, 900, 0, 600)]] == [0, 0]
