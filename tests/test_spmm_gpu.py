@@ -310,6 +310,15 @@ def test_segmented_xcd_affine_kernel(cuda, oracle, d, blocks, tile, min_len):
     spmm(prop.csr, xd, y=None, acc_in=e0d, acc_out=acc, acc_div=4.0, segmented=True)
     want = (e0 + outs[0]) / np.float32(4.0)
     assert np.array_equal(bits(acc.cpu().numpy()), bits(want.astype(np.float32)))
+    # per-call values (edge dropout, base_model.py:77-86): gathered into the plan's streams
+    torch.manual_seed(0)
+    v2 = (prop.csr.vals * (torch.rand_like(prop.csr.vals) > 0.4)).contiguous()
+    ya, yb = torch.empty((gr.n, d), device=cuda), torch.empty((gr.n, d), device=cuda)
+    spmm(prop.csr, xd, y=ya, vals=v2, segmented=True)
+    spmm(prop.csr, xd, y=yb, vals=v2, segmented=False, exact=True)
+    assert normwise(ya.cpu().numpy(), yb.cpu().numpy()) <= 5e-6
+    assert np.array_equal(bits(ya.cpu().numpy()[direct]), bits(yb.cpu().numpy()[direct]))
+    assert not torch.equal(ya, torch.from_numpy(outs[0]).to(cuda))
     # whole forward through the segmented path
     full = prop.forward(e0d, 3, segmented=True).cpu().numpy()
     exact = prop.forward(e0d, 3, exact=True).cpu().numpy()

@@ -181,7 +181,7 @@ def segment_plan_arrays(rowptr, colidx, vals, phases, tile_entries=256, n_classe
     if T <= 0 or T % 64:
         raise ValueError('tile_entries must be a positive multiple of 64')
     direct = np.ones(n_rows, dtype=bool)
-    tiles_col, tiles_val, tiles_meta = [], [], []      # per phase, already in launch order
+    tiles_col, tiles_val, tiles_meta, tiles_src = [], [], [], []      # per phase, already in launch order
     flag_orig, flag_slot = [], []                      # piece ends: original entry offset, slot id
     slot_base = 0
     for (r0, r1, c0, c1, nb) in phases:
@@ -225,6 +225,8 @@ def segment_plan_arrays(rowptr, colidx, vals, phases, tile_entries=256, n_classe
         ent_val = np.zeros(n_t * n_classes * T, dtype=np.float32)
         ent_col[dst] = cols[order] | (last.astype(np.int64) << 31)
         ent_val[dst] = vals[ent_off[order]]
+        ent_src = np.zeros(n_t * n_classes * T, dtype=np.int64)
+        ent_src[dst] = ent_off[order]
         slot = slot_base + np.cumsum(last) - 1                                    # slot of the piece an entry ends
         meta = np.zeros((n_t * n_classes, 2), dtype=np.int64)
         meta[:, 1] = np.bincount(tile_id, minlength=n_t * n_classes)
@@ -232,7 +234,7 @@ def segment_plan_arrays(rowptr, colidx, vals, phases, tile_entries=256, n_classe
         first[1:] = tile_id[1:] != tile_id[:-1]
         # slot of a tile's first piece = pieces closed before its first entry
         meta[tile_id[first], 0] = slot_base + (np.cumsum(last) - last)[first]
-        tiles_col.append(ent_col), tiles_val.append(ent_val), tiles_meta.append(meta)
+        tiles_col.append(ent_col), tiles_val.append(ent_val), tiles_meta.append(meta), tiles_src.append(ent_src)
         flag_orig.append(ent_off[order][last]), flag_slot.append(slot[last])
         slot_base += int(last.sum())
     cat = lambda xs, dt: np.concatenate(xs).astype(dt) if xs else np.zeros(0, dtype=dt)   # noqa: E731
@@ -252,6 +254,7 @@ def segment_plan_arrays(rowptr, colidx, vals, phases, tile_entries=256, n_classe
         'ent_col': (ent_col & 0x7fffffff).astype(np.int32),
         'ent_flags': np.packbits((ent_col >> 31).astype(np.uint8).reshape(-1, 64), axis=1, bitorder='little').view(np.int64).reshape(-1),   # uint64 words, carried as int64
         'ent_val': cat(tiles_val, np.float32),
+        'ent_src': cat(tiles_src, np.int32),      # offset in colidx/vals each stream entry was copied from (padding: 0)
         'seg_rows': seg_rows.astype(np.int32), 'row_slot_ptr': row_slot_ptr.astype(np.int32),
         'row_slots': f_slot.astype(np.int32), 'direct_rows': np.nonzero(direct)[0].astype(np.int32),
     }

@@ -118,8 +118,9 @@ class DeviceCSR:
         self.segment_min_row_len = int(min_row_len)
         self._segment_plans = {}
 
-    def segment_plan(self, d):
-        """ctypes pointer to a tgcn_segment_plan_t for width d, or None when no row range is segmented at this width."""
+    def segment_plan(self, d, vals=None):
+        """ctypes pointer to a tgcn_segment_plan_t for width d, or None when no row range is segmented at this width.
+        vals: per-call replacement of the stored values (same layout as self.vals)."""
         if self._segment_mode is None or not self._block_specs or d not in (64, 128, 256) or self.nnz == 0:
             return None
         if d not in self._segment_plans:
@@ -144,7 +145,17 @@ class DeviceCSR:
             self._segment_plans[d] = (entry, blocks)
         entry, blocks = self._segment_plans[d]
         self.segment_blocks = blocks
-        return None if entry is None else ctypes.byref(entry[0])
+        if entry is None:
+            return None
+        if vals is None:
+            return ctypes.byref(entry[0])
+        # per-call values (edge dropout, transposed values): the plan's streams get their own gathered copy
+        st, dv = entry[0], entry[2]
+        ev = vals.index_select(0, dv['ent_src'])
+        tmp = _capi.SegmentPlanStruct.from_buffer_copy(st)
+        tmp.ent_val = ev.data_ptr()
+        self._segment_keep = (tmp, ev)     # alive until the next call on this CSR (the launch is stream-ordered after the gather)
+        return ctypes.byref(tmp)
 
 
 def _check_dense(t, name, device, rows=None, d=None):
@@ -182,12 +193,12 @@ def spmm(csr, x, y=None, acc_in=None, acc_out=None, acc_div=1.0, exact=False, va
         vals = csr.vals
     elif vals.dtype != torch.float32 or vals.numel() != max(csr.nnz, 1) or vals.device != dev or not vals.is_contiguous():
         raise ValueError('vals must be a contiguous float32 device tensor with one entry per stored element')
-    # the segment plan carries its own copy of the stored values: a per-call `vals` (dropout) takes the plain kernels
+    # the segment plan carries its own copy of the stored values: a per-call `vals` (dropout) is gathered into it
     seg = None
-    if segmented is not False and not exact and variant == _capi.SPMM_AUTO and own_vals:
-        seg = csr.segment_plan(d)
+    if segmented is not False and not exact and variant == _capi.SPMM_AUTO:
+        seg = csr.segment_plan(d, None if own_vals else vals)
     if segmented is True and seg is None:
-        raise ValueError('segmented=True but this CSR has no segment plan for the call (width, exact, vals or variant)')
+        raise ValueError('segmented=True but this CSR has no segment plan for the call (width, exact or variant)')
     if seg is not None:
         rc = _capi.lib().tgcn_spmm_segmented_f32(
             seg, _capi.ptr(csr.rowptr), _capi.ptr(csr.colidx), _capi.ptr(vals), csr.n_rows, _capi.ptr(x), csr.n_src_rows, d,
