@@ -8,6 +8,8 @@
 // so the result is bit-identical to the reference's CPU forward.  Rows longer than the split plan's
 // threshold are the one exception: their chunks are chained independently and the chunk sums are
 // added in chunk order by a second launch (deterministic; differs from the reference in rounding only).
+// The segmented form (tgcn_spmm_segmented_f32) has the same contract for the rows it cuts at column-block
+// boundaries; its direct rows are exact chains.
 //
 // Roofline: HBM-bound gather.  Algorithmic bytes per layer:
 //   nnz*(4+4) + (rows+1)*4 + n_src*d*4 (X read once) + rows*d*4 (Y) [+ acc read/write]
@@ -23,6 +25,10 @@
 //                             is ds_bpermute (__shfl with width G).
 //   k_spmm_generic            any d: wave per row, 64-column slabs.
 //   k_spmm_long_reduce<VEC>   adds the chunk sums of split rows and applies the epilogue.
+//   k_spmm_seg<VEC,UNROLL>    XCD-affine column blocking: tile waves walk per-class entry streams (the workgroups of
+//                             one XCD only gather from 1/8 of the table, which then lives in that XCD's L2) and
+//                             write piece sums; the other waves of the launch own one direct row each.
+//   k_spmm_seg_reduce<VEC>    adds a row's piece sums in column order and applies the epilogue.
 #include <climits>
 
 #include "tgcn_internal.h"
