@@ -24,6 +24,8 @@
 // bit with the dense path and with the CPU restatement used in the parity tests.
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "tgcn_internal.h"
 #include "tgcn_topk.h"
 
@@ -237,6 +239,178 @@ __global__ __launch_bounds__(256) void k_score_filter(const FilterArgs a)
     }
     if (user_ok)
         a.counts[((size_t)user * a.S + split) * 2 + h] = cnt;
+}
+
+// d <= 128 form of k_score_filter with the threshold test of stage s-1 folded into the MFMA block of stage s.  A
+// 32x32x2 fp32 MFMA keeps the matrix pipe busy for 64 cycles after a 4-cycle issue, so one compare-and-branch per two
+// MFMAs runs in the shadow of the wave's own matrix work; with the test after the block (k_score_filter) the two or
+// three waves of a SIMD drift into lockstep -- they share the pipe, finish their blocks together and test together --
+// and the pipe idles through every epilogue (PMC: 58 % MFMA-busy, 63 % of the wave cycles waiting).  Costs a second
+// accumulator set (stages alternate between them).
+template <int DQ, bool FULLK>
+__device__ __forceinline__ void filter_pipelined(const FilterArgs &a)
+{
+    static_assert(DQ == 16 || DQ == 32, "one test slot per MFMA pair (d <= 64) or per two pairs (d <= 128)");
+    constexpr int kSlotsPerReg = (2 * DQ) / 32;
+    constexpr int ROW = 4 * DQ + 2;
+    __shared__ __attribute__((aligned(16))) float smem[2 * kStage * ROW];
+    const int lane = lane_id();
+    const int w = threadIdx.x >> 6;
+    const int r32 = lane & 31;
+    const int h = lane >> 5;
+    const int u0 = blockIdx.x * kUsersPerWG;
+    const int split = blockIdx.y;
+    const int i_beg = split * a.items_per_split;
+    const int i_end = min(a.I, i_beg + a.items_per_split);
+    {
+        float4 v[(kStage * DQ) / 256];
+        load_rows<DQ, FULLK>(v, a.U, a.user_ids, u0, a.B, a.d);
+        store_rows<DQ>(smem, v);
+        load_rows<DQ, FULLK>(v, a.U, a.user_ids, u0 + kStage, a.B, a.d);
+        store_rows<DQ>(smem + kStage * ROW, v);
+    }
+    __syncthreads();
+    float2 bf[DQ];
+    {
+        const float *pu = smem + (w * 32 + r32) * ROW + 2 * h;
+#pragma unroll
+        for (int q = 0; q < DQ; ++q)
+            bf[q] = *reinterpret_cast<const float2 *>(pu + q * 4);
+    }
+    const int user = u0 + w * 32 + r32;
+    const bool user_ok = user < a.B;
+    const float tau = user_ok ? a.tau[(size_t)user * a.tau_stride] : INFINITY;
+    float2 *__restrict__ log = a.logs + ((size_t)(user_ok ? user : 0) * a.S + split) * 2 * a.cap2 + (size_t)h * a.cap2;
+    int cnt = 0;
+    __syncthreads();
+    if (i_beg >= i_end) {
+        if (user_ok)
+            a.counts[((size_t)user * a.S + split) * 2 + h] = 0;
+        return;
+    }
+
+    float4 nxt[(kStage * DQ) / 256];
+    load_rows<DQ, FULLK>(nxt, a.It, nullptr, i_beg, i_end, a.d);
+    store_rows<DQ>(smem, nxt);
+    __syncthreads();
+    int buf = 0;
+    const int cap2 = a.cap2;
+
+    // C/D layout: col (user) = lane & 31, row (item) = (reg & 3) + 8 * (reg >> 2) + 4 * h
+    auto test = [&](float val, int item) {
+        if (val > tau) {
+            if (cnt < cap2)
+                log[cnt] = make_float2(val, __int_as_float(item));
+            ++cnt;
+        }
+    };
+    // one stage: c0/c1 <- scores of items [s0, s0 + 64); p0/p1 (items [s_prev, s_prev + 64), a full stage) are tested
+    // between the MFMAs when PREV
+    auto stage = [&](auto prev_tag, f32x16 &c0, f32x16 &c1, const f32x16 &p0, const f32x16 &p1, int s_prev, int s0) {
+        constexpr bool PREV = decltype(prev_tag)::value;
+        const bool more = s0 + kStage < i_end;
+        if (more)
+            load_rows<DQ, FULLK>(nxt, a.It, nullptr, s0 + kStage, i_end, a.d);
+        const float *pi = smem + buf * kStage * ROW + r32 * ROW + 2 * h;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            c0[r] = 0.0f, c1[r] = 0.0f;
+        constexpr int QB = 4;
+        float2 fa0[2][QB], fa1[2][QB];
+#pragma unroll
+        for (int q = 0; q < QB; ++q) {
+            fa0[0][q] = *reinterpret_cast<const float2 *>(pi + q * 4);
+            fa1[0][q] = *reinterpret_cast<const float2 *>(pi + 32 * ROW + q * 4);
+        }
+#pragma unroll
+        for (int g = 0; g < DQ / QB; ++g) {
+            if (g + 1 < DQ / QB) {
+#pragma unroll
+                for (int q = 0; q < QB; ++q) {
+                    fa0[(g + 1) & 1][q] = *reinterpret_cast<const float2 *>(pi + ((g + 1) * QB + q) * 4);
+                    fa1[(g + 1) & 1][q] = *reinterpret_cast<const float2 *>(pi + 32 * ROW + ((g + 1) * QB + q) * 4);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < QB; ++q) {
+                const float2 b2 = bf[g * QB + q];
+                const int t0 = (g * QB + q) * 2;  // 2*DQ test slots per stage; one of every kSlotsPerReg is used
+                c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[g & 1][q].x, b2.x, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[g & 1][q].x, b2.x, c1, 0, 0, 0);
+                if constexpr (PREV) {
+                    if (t0 % kSlotsPerReg == 0) {  // folded: the loops are fully unrolled
+                        const int reg = t0 / kSlotsPerReg, r = reg & 15;
+                        test(reg < 16 ? p0[r] : p1[r], s_prev + (reg < 16 ? 0 : 32) + (r & 3) + 8 * (r >> 2) + 4 * h);
+                    }
+                }
+                c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[g & 1][q].y, b2.y, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[g & 1][q].y, b2.y, c1, 0, 0, 0);
+                if constexpr (PREV) {
+                    if ((t0 + 1) % kSlotsPerReg == 0) {
+                        const int reg = (t0 + 1) / kSlotsPerReg, r = reg & 15;
+                        test(reg < 16 ? p0[r] : p1[r], s_prev + (reg < 16 ? 0 : 32) + (r & 3) + 8 * (r >> 2) + 4 * h);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more)
+            store_rows<DQ>(smem + (buf ^ 1) * kStage * ROW, nxt);
+        __syncthreads();
+        buf ^= 1;
+    };
+    // the last stage of a split (possibly partial: rows past i_end) is tested after the loop
+    auto test_last = [&](const f32x16 &p0, const f32x16 &p1, int s_prev) {
+        const int lim = i_end - s_prev;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row < lim)
+                test(p0[r], s_prev + row);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row < lim)
+                test(p1[r], s_prev + row);
+        }
+    };
+
+    f32x16 A0, A1, B0, B1;
+    int s0 = i_beg;
+    stage(std::false_type{}, A0, A1, B0, B1, 0, s0);
+    for (;;) {
+        int s_prev = s0;
+        s0 += kStage;
+        if (s0 >= i_end) {
+            test_last(A0, A1, s_prev);
+            break;
+        }
+        stage(std::true_type{}, B0, B1, A0, A1, s_prev, s0);
+        s_prev = s0;
+        s0 += kStage;
+        if (s0 >= i_end) {
+            test_last(B0, B1, s_prev);
+            break;
+        }
+        stage(std::true_type{}, A0, A1, B0, B1, s_prev, s0);
+    }
+    if (user_ok)
+        a.counts[((size_t)user * a.S + split) * 2 + h] = cnt;
+}
+
+// register budgets: d <= 64 fits 3 waves per SIMD (168 VGPRs), d <= 128 two
+template <bool FULLK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_score_filter16(const FilterArgs a)
+{
+    filter_pipelined<16, FULLK>(a);
+}
+
+template <bool FULLK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_score_filter32(const FilterArgs a)
+{
+    filter_pipelined<32, FULLK>(a);
 }
 
 struct SelectArgs {
@@ -479,12 +653,11 @@ Plan make_plan(int B, int I, int d, int k)
         p.total = align256((size_t)B * I * sizeof(float));
         return p;
     }
-    const int user_tiles = (B + kUsersPerWG - 1) / kUsersPerWG;
-    // 3 workgroups per CU (what registers + LDS admit) when the user tiles alone give >= 1 per CU, else 2 per CU:
-    // with few user tiles more splits mean more prologues for no reliable gain (48 splits: 142 us on one box, 218 on another)
-    int S = ((user_tiles >= 64 ? 768 : 512) + user_tiles - 1) / user_tiles;
+    // 32 item splits (512 workgroups for one 2048-user call, 2 per CU).  Larger calls keep 32: measured on config 2
+    // with 16 384 users per call, 8 / 12 / 24 / 32 / 48 splits -> 0.60 / 0.58 / 0.65 / 0.66 / 0.65 T pairs/s (many short
+    // workgroups keep the chip evenly loaded); 2048 users: 32 and 48 splits tie.
     const int max_S = max(1, I / (8 * kStage));   // at least 8 stages per split
-    S = max(1, min(min(S, 32), max_S));
+    int S = min(32, max_S);
     if (const char *dbg = getenv("TGCN_DEBUG_SPLITS"))  // dev only
         S = max(1, min(atoi(dbg), max_S));
     p.items_per_split = (((I + S - 1) / S + kStage - 1) / kStage) * kStage;
@@ -579,7 +752,20 @@ extern "C" int tgcn_score_topk_f32(const float *U, const int64_t *user_ids, int3
         const char *dbg = getenv("TGCN_DEBUG_FILTER_MODE");
         fa.debug_mode = dbg ? atoi(dbg) : 0;
     }
-    rc = d <= 64 ? launch_filter<16>(fa, s) : d <= 128 ? launch_filter<32>(fa, s) : launch_filter<64>(fa, s);
+    if (d <= 128 && fa.debug_mode == 0) {
+        const dim3 grid((B + kUsersPerWG - 1) / kUsersPerWG, p.S);
+        if (d == 64)
+            hipLaunchKernelGGL((k_score_filter16<true>), grid, dim3(256), 0, s, fa);
+        else if (d < 64)
+            hipLaunchKernelGGL((k_score_filter16<false>), grid, dim3(256), 0, s, fa);
+        else if (d == 128)
+            hipLaunchKernelGGL((k_score_filter32<true>), grid, dim3(256), 0, s, fa);
+        else
+            hipLaunchKernelGGL((k_score_filter32<false>), grid, dim3(256), 0, s, fa);
+        rc = check_launch("k_score_filter16/32");
+    } else {
+        rc = d <= 64 ? launch_filter<16>(fa, s) : d <= 128 ? launch_filter<32>(fa, s) : launch_filter<64>(fa, s);
+    }
     if (rc != TGCN_OK)
         return rc;
 
