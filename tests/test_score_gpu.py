@@ -206,12 +206,13 @@ def test_fused_topk_small_catalogue_and_gather(cuda):
     _fused_vs_dense(cuda, table, it2, 40, mask=_rand_mask(rng, 333, 30000, 1, 50), user_ids=ids)
 
 
-def test_fused_topk_hard_cases(cuda):
+@pytest.mark.parametrize('d', [64, 128, 40])
+def test_fused_topk_hard_cases(cuda, d):
     """Cases built to defeat the threshold estimate: all-equal scores (no candidate passes a strict bar), scores
     increasing with the item id, a user whose train list covers most of the catalogue (log overflow / fewer
     than k unmasked items), duplicated item rows (ties broken by index)."""
     rng = np.random.default_rng(2)
-    b, i, d, k = 200, 20000, 64, 40
+    b, i, k = 200, 20000, 40
     u = np.abs(rng.standard_normal((b, d))).astype(np.float32) * 0.1
     it = (rng.standard_normal((i, d)) * 0.1).astype(np.float32)
     # (a) every item identical -> every score equal per user
