@@ -242,3 +242,54 @@ def test_predict_streams_do_not_change_results(cuda, tmp_path):
     scoring.mask_train(s, torch.from_numpy(brp).to(cuda), torch.from_numpy(bit).to(cuda))
     rv, ri = scoring.topk(s, 40, round4=True)
     assert torch.equal(i3, ri) and torch.equal(v3, rv)
+
+
+def test_model_takes_segmented_kernels_where_they_pay(cuda):
+    """A graph whose user table (10 MB) misses an XCD's L2 while an eighth fits: the model's default path segments
+    the item rows (propagate.segment_blocks_auto) in inference, in dropout-free training and -- through the gathered
+    value stream -- under edge dropout; results agree with the exact chain to rounding, gradients included."""
+    import pandas as pd
+    from textgcn_amd import synth
+    from textgcn_amd.graph import NormGraph, train_mask_csr
+    from textgcn_amd.model import LightGCN
+    n_u, n_i, nnz = 40000, 3000, 1300000
+    u, i = synth.interactions(n_u, n_i, nnz, seed=7)
+    g = NormGraph.from_pairs(u, i, n_u, n_i)
+    rp, items = train_mask_csr(u, i, n_u)
+    ds = types.SimpleNamespace(n_users=n_u, n_items=n_i, graph=g, norm_matrix=None, mask_rowptr=rp, mask_items=items,
+                               true_test_lil=[[0]], train_user_dict=None, test_df=pd.DataFrame({'user_id': [0], 'asin': [0]}),
+                               user_mapping=pd.DataFrame({'remap_id': [0], 'org_id': ['u']}),
+                               item_mapping=pd.DataFrame({'remap_id': [0], 'org_id': ['i']}))
+    torch.manual_seed(0)
+    fast = LightGCN(_params(k=[20], exact=False, dropout=0.0), ds)
+    exact = LightGCN(_params(k=[20], exact=True, dropout=0.0), ds)
+    _set_weights(exact, fast.embedding_user.weight.detach().cpu().numpy(), fast.embedding_item.weight.detach().cpu().numpy())
+    with torch.no_grad():
+        fu, fi = fast.representation
+        eu, ei = exact.representation
+    assert fast._engine.csr.segment_blocks == [0, 8] and not exact._engine.csr.segment_blocks
+    assert normwise(torch.cat([fu, fi]).cpu().numpy(), torch.cat([eu, ei]).cpu().numpy()) <= 5e-6
+    assert not torch.equal(fi, ei)     # the item rows really took the other kernel
+    # training forward + backward (no dropout: stored values; the backward propagates through the same kernels)
+    w = torch.randn(g.n, 64, device=cuda)
+    grads = []
+    for m in (fast, exact):
+        m.training = True
+        m.zero_grad()
+        mu, mi = m.representation
+        (torch.cat([mu, mi]) * w).sum().backward()
+        grads.append(torch.cat([m.embedding_user.weight.grad, m.embedding_item.weight.grad]).clone())
+        m.training = False
+    assert normwise(grads[0].cpu().numpy(), grads[1].cpu().numpy()) <= 5e-6
+    # edge dropout: per-call values go through the plan's gathered stream; same mask for both models
+    fast.dropout = exact.dropout = 0.4
+    outs = []
+    for m in (fast, exact):
+        m.training = True
+        torch.manual_seed(5)
+        with torch.no_grad():
+            mu, mi = m.representation
+        outs.append(torch.cat([mu, mi]).clone())
+        m.training = False
+    assert normwise(outs[0].cpu().numpy(), outs[1].cpu().numpy()) <= 5e-6
+    assert not torch.equal(outs[0], torch.cat([fu, fi]))
