@@ -2,7 +2,7 @@
 
 Replaces the loop of TextGCN/base_model.py:93-106 (representation): K x torch.sparse.mm (:148), the
 torch.cat of the two embedding tables (:91) and torch.mean(torch.stack(...)) (:157).  Device memory is
-plain torch tensors; the arithmetic is tgcn_spmm_csr_f32 (include/tgcn.h).
+plain torch tensors; the arithmetic is tgcn_spmm_csr_f32 / tgcn_spmm_segmented_f32 (include/tgcn.h).
 """
 import ctypes
 
