@@ -249,3 +249,31 @@ def test_fused_topk_vs_oracle_sample(cuda, oracle):
                                 mask_rowptr=torch.from_numpy(rp.astype(np.int32)).to(cuda),
                                 mask_items=torch.from_numpy(items.astype(np.int32)).to(cuda), round4=True)
     assert np.array_equal(idx.cpu().numpy(), ri) and np.array_equal(bits(v.cpu().numpy()), bits(rv))
+
+
+@pytest.mark.parametrize('b,i,d,k', [(70, 20000, 64, 100), (33, 9000, 128, 150), (9, 300, 64, 130), (5, 200, 48, 65)])
+def test_topk_beyond_64_takes_several_passes(cuda, b, i, d, k):
+    """k above the kernels' 64-entry list: ceil(k/64) passes with the items already taken masked out -- fused and
+    dense entry points against torch.topk on the masked score matrix (values everywhere; item ids where scores are
+    finite and untied)."""
+    from textgcn_amd import scoring
+    rng = np.random.default_rng(b + i + k)
+    u = torch.from_numpy((rng.standard_normal((b, d)) * 0.1).astype(np.float32)).to(cuda)
+    it = torch.from_numpy((rng.standard_normal((i, d)) * 0.1).astype(np.float32)).to(cuda)
+    rp, items = _rand_mask(rng, b, i, 0, 60)
+    rpd, itd = torch.from_numpy(rp.astype(np.int32)).to(cuda), torch.from_numpy(items.astype(np.int32)).to(cuda)
+    s = scoring.score_dense(u, it)
+    scoring.mask_train(s, rpd, itd)
+    rv, ri = torch.topk(s, k, dim=1)
+    for v, idx in (scoring.score_topk(u, it, k, mask_rowptr=rpd, mask_items=itd), scoring.topk(s, k)):
+        assert torch.equal(v, rv)
+        fin = torch.isfinite(rv)
+        untied = fin.clone()
+        untied[:, 1:] &= rv[:, 1:] != rv[:, :-1]
+        untied[:, :-1] &= rv[:, :-1] != rv[:, 1:]
+        assert torch.equal(idx[untied], ri[untied])
+        got = torch.gather(s, 1, idx)
+        assert torch.equal(got[fin], rv[fin])                       # every listed item really has that score
+        for r in range(b):
+            f = idx[r][fin[r]]
+            assert f.unique().numel() == f.numel()                  # no item twice among the finite ones

@@ -56,11 +56,26 @@ def mask_train(scores, mask_rowptr, mask_items):
     return scores
 
 
+MAX_K_PER_PASS = 64   # the kernels keep a user's list in one register per lane (include/tgcn.h)
+
+
 def topk(scores, k, round4=False):
-    """(values [B,k] fp32, indices [B,k] int64), ordered by (value desc, index asc)."""
+    """(values [B,k] fp32, indices [B,k] int64), ordered by (value desc, index asc).  k > 64 (the kernels' list
+    length) takes ceil(k/64) passes over a copy in which the items already taken are set to -inf; on a row with
+    fewer than k finite scores the positions past the last finite one hold -inf with unspecified item ids, as with
+    torch.topk (base_model.py:261)."""
     dev = _dev(scores)
     if scores.dtype != torch.float32 or scores.dim() != 2 or scores.stride(1) != 1:
         raise TypeError('scores must be float32 [B, I] with unit inner stride')
+    if k > MAX_K_PER_PASS:
+        if k > scores.shape[1]:
+            raise ValueError('k exceeds the number of items')
+        work, vals, idxs = scores.clone(), [], []
+        for k0 in range(0, k, MAX_K_PER_PASS):
+            v, i = topk(work, min(MAX_K_PER_PASS, k - k0), round4)
+            vals.append(v), idxs.append(i)
+            work.scatter_(1, i, float('-inf'))
+        return torch.cat(vals, dim=1), torch.cat(idxs, dim=1)
     b = scores.shape[0]
     val = torch.empty((b, k), dtype=torch.float32, device=dev)
     idx = torch.empty((b, k), dtype=torch.int64, device=dev)
@@ -102,6 +117,26 @@ def score_topk(users_emb, items_emb, k, user_ids=None, mask_rowptr=None, mask_it
         if mask_rowptr.dtype != torch.int32 or mask_items.dtype != torch.int32 or mask_rowptr.numel() != b + 1:
             raise TypeError('mask arrays must be int32 with B+1 row pointers')
     n_items, d = items_emb.shape
+    if k > MAX_K_PER_PASS:
+        # ceil(k/64) passes; the items taken so far join the user's mask list for the next pass
+        if k > n_items:
+            raise ValueError('k exceeds the number of items')
+        rows = torch.arange(b, device=dev, dtype=torch.int64)
+        if mask_rowptr is None:
+            rowptr, keys = torch.zeros(b + 1, dtype=torch.int64, device=dev), torch.zeros(0, dtype=torch.int64, device=dev)
+        else:
+            rowptr = mask_rowptr.to(torch.int64)
+            keys = torch.repeat_interleave(rows, rowptr[1:] - rowptr[:-1]) * n_items + mask_items.to(torch.int64)
+        vals, idxs = [], []
+        for k0 in range(0, k, MAX_K_PER_PASS):
+            kk = min(MAX_K_PER_PASS, k - k0)
+            v, i = score_topk(users_emb, items_emb, kk, user_ids, rowptr.to(torch.int32),
+                              (keys % n_items).to(torch.int32) if keys.numel() else torch.zeros(1, dtype=torch.int32, device=dev),
+                              round4, slot)
+            vals.append(v), idxs.append(i)
+            keys = torch.sort(torch.cat([keys, (rows[:, None] * n_items + i).reshape(-1)]))[0]
+            rowptr = rowptr + kk * torch.arange(b + 1, device=dev, dtype=torch.int64)
+        return torch.cat(vals, dim=1), torch.cat(idxs, dim=1)
     val = torch.empty((b, k), dtype=torch.float32, device=dev)
     idx = torch.empty((b, k), dtype=torch.int64, device=dev)
     lib = _capi.lib()
