@@ -166,6 +166,9 @@ def set_weights(model, eu, ei):
         model.embedding_item.weight.copy_(torch.from_numpy(ei))
 
 
+ONLY = os.environ.get('GOLDEN_ONLY')   # 'g4' / 'g7': regenerate just that fixture (the synth-60x40 data is rebuilt either way)
+
+
 def save(name, **arrays):
     path = os.path.join(OUT, name)
     np.savez_compressed(path, **arrays)
@@ -225,11 +228,13 @@ def synth_pairs(rng, n_u, n_i, per_user_lo, per_user_hi, n_test_users):
     return sorted(set(train)), sorted(set(test))
 
 
-def g2_synth(work):
+def g2_synth(work, write=True):
     rng = np.random.default_rng(2)
     train, test = synth_pairs(rng, 60, 40, 3, 9, 30)
     data = os.path.join(work, 'synth60')
     write_tsvs(data, train, test)
+    if not write:
+        return data
     out = {}
     variants = {
         'a': (['--emb_size', '64', '--n_layers', '3'], 64),
@@ -436,18 +441,50 @@ def g4_ltr(work, data):
     b = dataset_bundle(ds)
     for k in ('train_u', 'train_i', 'test_u', 'test_i'):
         out[k] = b[k]
-    save('g4_ltr.npz', **out)
+    if ONLY in (None, 'g4'):
+        save('g4_ltr.npz', **out)
+    if ONLY in (None, 'g7'):
+        g7_ltr_pop(work, data, ckpt, ds, rng)
+
+
+# --------------------------------------------------------------------------- G7: LTRLinearWPop (registry name ltr_pop)
+def g7_ltr_pop(work, data, ckpt, ds, rng):
+    """ltr_models.py:213-241 on the same data: the five text/graph features plus user and item popularity as the
+    dataset computes them (reviews_models.py:100-113), through a 7-input Linear."""
+    args = run_args(['--model', 'ltr_pop', '--no_train', '-k', '5', '10', '--batch_size', '32', '--load_base', ckpt, '--freeze'], data, work)
+    model = TextGCN.LTRLinearWPop(args, ds)
+    with torch.no_grad():
+        model.layers[0].weight.copy_(torch.tensor([[0.75, -0.5, 0.25, 0.125, -0.375, 1.5, -2.25]]))
+        model.layers[0].bias.copy_(torch.tensor([0.0625]))
+    out = {'n_users': np.int64(ds.n_users), 'n_items': np.int64(ds.n_items),
+           'popularity_users': ds.popularity_users.numpy().copy(), 'popularity_items': ds.popularity_items.numpy().copy(),
+           'w': model.layers[0].weight.detach().numpy().copy(), 'b': model.layers[0].bias.detach().numpy().copy(),
+           'feature_names': np.array(model.feature_names), 'state_keys': np.array(sorted(model.state_dict().keys()))}
+    with torch.no_grad():
+        ue, ie = model.representation
+        users = np.arange(ds.n_users)
+        out['scores'] = model.score_batchwise(ue[users], ie, users).numpy().copy()
+        pairs_u = rng.integers(0, ds.n_users, 200)
+        pairs_i = rng.integers(0, ds.n_items, 200)
+        out['pairs_u'], out['pairs_i'] = pairs_u, pairs_i
+        out['pair_scores'] = model.score_pairwise(ue[pairs_u], ie[pairs_i], torch.from_numpy(pairs_u), torch.from_numpy(pairs_i)).numpy().copy()
+        pred, sc = model.predict(users, with_scores=True)
+        out['topk_idx'], out['topk_val'] = np.asarray(pred, dtype=np.int64), np.asarray(sc, dtype=np.float32)
+    save('g7_ltr_pop.npz', **out)
 
 
 def main():
     work = tempfile.mkdtemp(prefix='tgcn_golden_')
     try:
-        g1_dummy(work)
-        data60 = g2_synth(work)
-        g3_dropout(work, data60)
+        if ONLY is None:
+            g1_dummy(work)
+        data60 = g2_synth(work, write=ONLY is None)
+        if ONLY is None:
+            g3_dropout(work, data60)
         g4_ltr(work, data60)
-        g5_medium(work)
-        g6_builder(work)
+        if ONLY is None:
+            g5_medium(work)
+            g6_builder(work)
     finally:
         os.chdir('/')
         shutil.rmtree(work, ignore_errors=True)

@@ -101,3 +101,43 @@ def test_hip_ltr_hidden_layers_collapse_to_affine(golden, cuda, tmp_path):
                              uv['reviews'] @ iv['desc'].T, uv['desc'] @ iv['reviews'].T], dim=-1)
         ref = m.layers(feats).squeeze(-1)
     assert normwise(s.cpu().numpy(), ref.cpu().numpy()) <= 1e-5
+
+
+@pytest.mark.gpu
+def test_hip_ltr_pop_matches_reference(golden, cuda, tmp_path):
+    """ltr_pop (LTRLinearWPop, ltr_models.py:213-241) against the reference's own outputs (G7): the two popularity
+    features ride in two more columns of the folded GEMM."""
+    from golden_inputs import exact_embedding
+    from textgcn_amd.ltr import LTRLinearWPop
+    from textgcn_amd.model import get_class
+    g4, g = golden('g4_ltr'), golden('g7_ltr_pop')
+    assert get_class('ltr_pop')[1] is LTRLinearWPop
+    n_u, n_i = int(g['n_users']), int(g['n_items'])
+    ds = _dataset(g4)
+    ds.popularity_users, ds.popularity_items = torch.from_numpy(g['popularity_users']), torch.from_numpy(g['popularity_items'])
+    p = types.SimpleNamespace(k=[5, 10], emb_size=64, n_layers=3, device='cuda:0', load=None, load_base=None, freeze=True,
+                              batch_size=32, quiet=True, exact=True, ltr_layers=[], save_path=str(tmp_path))
+    m = LTRLinearWPop(p, ds)
+    assert m.feature_names == list(g['feature_names']) and m.layers[0].weight.shape == (1, 7)
+    with torch.no_grad():
+        m.embedding_user.weight.copy_(torch.from_numpy(exact_embedding(n_u, 64, 11)))
+        m.embedding_item.weight.copy_(torch.from_numpy(exact_embedding(n_i, 64, 12)))
+        m.layers[0].weight.copy_(torch.from_numpy(g['w']))
+        m.layers[0].bias.copy_(torch.from_numpy(g['b']))
+    assert sorted(m.state_dict().keys()) == list(g['state_keys'])
+    with torch.no_grad():
+        ue, ie = m.representation
+        users = torch.arange(n_u, device=cuda)
+        s = m.score_batchwise(ue[users], ie, users)
+        assert normwise(s.cpu().numpy(), g['scores']) <= 1e-5
+        assert normwise(s.cpu().numpy(), g4['scores']) > 1e-2                 # the popularity terms really count
+        pu, pi = torch.from_numpy(g['pairs_u']).to(cuda), torch.from_numpy(g['pairs_i']).to(cuda)
+        ps = m.score_pairwise(ue[pu], ie[pi], pu, pi)
+        assert ps.shape == (200, 1) and normwise(ps.cpu().numpy(), g['pair_scores']) <= 1e-5
+    pred, sc = m.predict(np.arange(n_u), with_scores=True)
+    pred, sc = np.asarray(pred), np.asarray(sc, dtype=np.float32)
+    ref_i, ref_v = g['topk_idx'], g['topk_val']
+    row_ok = (np.abs(np.diff(ref_v, axis=1)) > 2e-4).all(axis=1)
+    assert row_ok.mean() > 0.8
+    assert np.array_equal(pred[row_ok], ref_i[row_ok])
+    assert np.abs(sc - ref_v).max() <= 1.01e-4

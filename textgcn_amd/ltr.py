@@ -43,6 +43,13 @@ class LTRData(InteractionData):
             if t.dim() != 2 or t.shape[0] != want:
                 raise ValueError(f'{name} must be [{want}, t], got {tuple(t.shape)}')
             setattr(self, name, t)
+        # ltr_pop (LTRLinearWPop) additionally reads the dataset's two popularity columns (reviews_models.py:100-113)
+        for name, want in (('popularity_users', self.n_users), ('popularity_items', self.n_items)):
+            if name in tables:
+                t = torch.as_tensor(tables[name], dtype=torch.float32).reshape(-1, 1)
+                if t.shape[0] != want:
+                    raise ValueError(f'{name} must have {want} rows, got {t.shape[0]}')
+                setattr(self, name, t)
 
 
 class LTRLinear(LightGCN):
@@ -112,7 +119,7 @@ class LTRLinear(LightGCN):
         w, b = self.effective_weights()
         n = emb_ids.numel() if emb_ids is not None else users_emb.shape[0]
         out = torch.empty((n, self._k()), dtype=torch.float32, device=self.device)
-        w5 = (ctypes.c_float * 5)(*[float(x) for x in w])
+        w5 = (ctypes.c_float * 5)(*[float(x) for x in w[:5]])   # the five dot-product features; subclasses add columns
         rc = _capi.lib().tgcn_ltr_fold_users_f32(_capi.ptr(users_emb), _capi.ptr(self.users_as_avg_reviews),
                                                  _capi.ptr(self.users_as_avg_desc), _capi.ptr(emb_ids), _capi.ptr(text_ids), n,
                                                  self.emb_size, self.text_dim, w5, b, _capi.ptr(out), _capi.current_stream(self.device))
@@ -188,3 +195,66 @@ class LTRLinear(LightGCN):
         if not y_idx:
             return None, None
         return torch.cat(y_val), torch.cat(y_idx)
+
+
+class LTRLinearWPop(LTRLinear):
+    """reference: TextGCN/ltr_models.py:213-241 (registry name `ltr_pop`): LTRLinear plus two scalar features, the
+    user's and the item's popularity as the dataset provides them (`dataset.popularity_users [U, 1]`,
+    `dataset.popularity_items [I, 1]`).  With layers(f) = f . w + b the two extra terms are
+    (w5 * pop_u[u]) * 1 + w6 * pop_i[i]: two more columns of the folded GEMM -- the user
+    operand carries (w5 * pop_u[u], w6), the item operand (1, pop_i[i]) -- in the zero padding the folded width leaves
+    (or in a widened operand when fewer than two padding columns exist)."""
+
+    def _copy_dataset_params(self, dataset):
+        super()._copy_dataset_params(dataset)
+        to = lambda t: torch.as_tensor(t, dtype=torch.float32).to(self.device).reshape(-1, 1).contiguous()  # noqa: E731
+        self.popularity_users = to(dataset.popularity_users)   # ltr_models.py:216-219
+        self.popularity_items = to(dataset.popularity_items)
+
+    def _setup_layers(self, params):
+        self.feature_names += ['user popularity', 'item popularity']   # ltr_models.py:221-223
+        super()._setup_layers(params)
+
+    def _pop_columns(self):
+        """(first popularity column, operand width)"""
+        base = self.emb_size + 2 * self.text_dim + 1
+        k = self._k()
+        return base, k if k >= base + 2 else k + 64
+
+    def _widen(self, t):
+        _, k2 = self._pop_columns()
+        if t.shape[1] == k2:
+            return t
+        wide = torch.zeros((t.shape[0], k2), dtype=torch.float32, device=self.device)
+        wide[:, :t.shape[1]] = t
+        return wide
+
+    def _fold_users(self, users_emb, emb_ids, text_ids):
+        out = self._widen(super()._fold_users(users_emb, emb_ids, text_ids))
+        w, _ = self.effective_weights()
+        c, _ = self._pop_columns()
+        pop = self.popularity_users[:, 0] if text_ids is None else self.popularity_users[text_ids, 0]
+        out[:, c] = float(w[5]) * pop
+        out[:, c + 1] = float(w[6])
+        return out
+
+    def _pack_items(self, items_emb):
+        key = (items_emb.data_ptr(), items_emb._version, 'pop')
+        if self._packed is None or self._packed[0] != key:
+            self._packed = None
+            out = self._widen(super()._pack_items(items_emb)).clone()
+            c, _ = self._pop_columns()
+            out[:, c] = 1.0
+            out[:, c + 1] = self.popularity_items[:, 0]
+            self._packed = (key, out)
+        return self._packed[1]
+
+    def score_pairwise_ltr(self, users_emb, items_emb, users, items):
+        users = torch.as_tensor(users, dtype=torch.int64, device=self.device)
+        items = torch.as_tensor(items, dtype=torch.int64, device=self.device)
+        ru, du = self.users_as_avg_reviews[users], self.users_as_avg_desc[users]
+        ri, di = self.items_as_avg_reviews[items], self.items_as_desc[items]
+        dot = lambda a, c: (a * c).sum(dim=1, keepdim=True)  # noqa: E731
+        feats = torch.cat([dot(users_emb, items_emb), dot(ru, ri), dot(du, di), dot(ru, di), dot(du, ri),
+                           self.popularity_users[users], self.popularity_items[items]], dim=1)   # ltr_models.py:233-241
+        return self.layers(feats)

@@ -428,7 +428,8 @@ def get_class(name):
     from .interactions import InteractionData
     table = {'lgcn': [InteractionData, LightGCN]}
     from .adv_sampling import AdvSamplData, AdvSamplModel
-    from .ltr import LTRData, LTRLinear
+    from .ltr import LTRData, LTRLinear, LTRLinearWPop
     table['adv_sampling'] = [AdvSamplData, AdvSamplModel]
     table['ltr_linear'] = [LTRData, LTRLinear]
+    table['ltr_pop'] = [LTRData, LTRLinearWPop]
     return table[name]
