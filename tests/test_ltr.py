@@ -28,6 +28,17 @@ def test_oracle_ltr_matches_reference(golden, oracle):
     assert list(g['state_keys']) == ['embedding_item.weight', 'embedding_user.weight', 'layers.0.bias', 'layers.0.weight']
 
 
+def test_oracle_ltr_pop_matches_reference(golden, oracle):
+    """G7: ltr_pop scores of the reference (LTRLinearWPop) against the oracle's restatement."""
+    g4, g = golden('g4_ltr'), golden('g7_ltr_pop')
+    s = oracle.ltr_pop_score(g4['users_emb'], g4['users_as_avg_reviews'], g4['users_as_avg_desc'], g4['items_emb'],
+                             g4['items_as_avg_reviews'], g4['items_as_desc'], g['popularity_users'], g['popularity_items'],
+                             g['w'], float(g['b'][0]))
+    assert normwise(s, g['scores']) <= 1e-6
+    assert list(g['state_keys']) == ['embedding_item.weight', 'embedding_user.weight', 'layers.0.bias', 'layers.0.weight']
+    assert list(g['feature_names'][-2:]) == ['user popularity', 'item popularity']
+
+
 def _dataset(g):
     n_u, n_i = int(g['n_users']), int(g['n_items'])
     from textgcn_amd.graph import NormGraph
