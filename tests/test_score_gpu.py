@@ -115,8 +115,10 @@ def test_topk_rejects_bad_k(cuda):
         scoring.topk(s, 0)
     with pytest.raises(RuntimeError):
         scoring.topk(s, 11)
-    with pytest.raises(RuntimeError):
-        scoring.topk(torch.zeros((2, 100), device=cuda), 65)
+    with pytest.raises(ValueError):
+        scoring.topk(torch.zeros((2, 100), device=cuda), 101)         # k > 64 takes several passes, but never k > I
+    v, i = scoring.topk(torch.arange(200, dtype=torch.float32, device=cuda).reshape(2, 100), 65)
+    assert i[0].tolist() == list(range(99, 34, -1)) and v[1, 0].item() == 199.0
 
 
 def test_pairwise_bit_exact_vs_oracle(cuda, oracle):
