@@ -31,7 +31,7 @@ import scipy.sparse as sp
 import torch
 
 REF = '/root/reference'
-OUT = os.path.dirname(os.path.abspath(__file__))
+OUT = os.environ.get('GOLDEN_OUT') or os.path.dirname(os.path.abspath(__file__))
 
 
 # --------------------------------------------------------------------------- stand-ins
