@@ -293,3 +293,51 @@ def test_model_takes_segmented_kernels_where_they_pay(cuda):
         m.training = False
     assert normwise(outs[0].cpu().numpy(), outs[1].cpu().numpy()) <= 5e-6
     assert not torch.equal(outs[0], torch.cat([fu, fi]))
+
+
+@pytest.mark.parametrize('device', [torch.device('cuda'), 'cuda', None])
+def test_unindexed_device_runs_fit_predict_and_ltr(golden, cuda, tmp_path, device):
+    """The reference's parser hands over torch.device('cuda') without an index (TextGCN/parser.py:174), which compares
+    unequal to the cuda:0 that tensors report; the package resolves it where it enters.  `None`: the field is absent
+    and the class default ('cuda') applies.  Runs the whole drop-in flow: fit, predict, ltr_linear on top."""
+    import pandas as pd
+    from textgcn_amd import synth
+    from textgcn_amd.interactions import InteractionData
+    from textgcn_amd.ltr import LTRLinear
+    from textgcn_amd.model import LightGCN
+    u, i = synth.interactions(90, 60, 1200, seed=5)
+    folder = tmp_path / 'data'
+    folder.mkdir()
+    te = np.zeros(len(u), dtype=bool)
+    second = np.unique(u, return_index=True)[1] + 1         # second interaction of every user -> test
+    second = second[second < len(u)]
+    te[second[u[second] == u[second - 1]]] = True
+    for name, sel in (('train.tsv', ~te), ('test.tsv', te)):
+        with open(folder / name, 'w') as f:
+            f.write('user_id\tasin\n')
+            for a, b in zip(u[sel], i[sel]):
+                f.write(f'u{a:04d}\ti{b:04d}\n')
+    p = _params(k=[5, 10], batch_size=128, epochs=1, evaluate_every=1, save_path=str(tmp_path), exact=False, data=str(folder))
+    if device is None:
+        del p.device
+    else:
+        p.device = device
+    try:
+        ds = InteractionData(p)
+    except AssertionError:
+        pytest.skip('split left a test user or item without train rows')
+    m = LightGCN(p, ds)
+    assert m.device == torch.device('cuda', torch.cuda.current_device())
+    m.fit(torch.utils.data.DataLoader(ds, batch_size=128, shuffle=True))
+    pred = m.predict(np.arange(ds.n_users))
+    assert len(pred) == ds.n_users and len(pred[0]) == 10
+    # ltr_linear on top of the same (frozen) tables, same unindexed device
+    g = torch.Generator().manual_seed(0)
+    for name, rows in (('items_as_desc', ds.n_items), ('items_as_avg_reviews', ds.n_items), ('users_as_avg_reviews', ds.n_users),
+                       ('users_as_avg_desc', ds.n_users)):
+        setattr(ds, name, torch.randn((rows, 384), generator=g))
+    ds.all_items = range(ds.n_items)
+    p.load_base, p.freeze, p.ltr_layers = None, True, []
+    lm = LTRLinear(p, ds)
+    lp = lm.predict(np.arange(ds.n_users))
+    assert len(lp) == ds.n_users and len(lp[0]) == 10

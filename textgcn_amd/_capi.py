@@ -81,6 +81,17 @@ def check(rc, what):
         raise RuntimeError(f'{what} failed (code {rc}): {msg}')
 
 
+def resolve_device(device):
+    """torch.device with its index filled in: `torch.device('cuda')` (what the reference's parser hands over,
+    TextGCN/parser.py:174) compares unequal to the `cuda:0` every tensor reports, so it is resolved once, where a
+    device enters the package."""
+    import torch
+    dev = torch.device(device)
+    if dev.type == 'cuda' and dev.index is None and torch.cuda.is_available():
+        dev = torch.device('cuda', torch.cuda.current_device())
+    return dev
+
+
 def ptr(t):
     """device pointer of a torch tensor (None -> NULL)"""
     return None if t is None else c_void_p(t.data_ptr())

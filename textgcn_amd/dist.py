@@ -19,6 +19,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from ._capi import resolve_device
 from .graph import NormGraph
 from .propagate import DEFAULT_SPLIT_THRESHOLD, DeviceCSR, spmm
 
@@ -43,7 +44,7 @@ class ShardedPropagator:
     def __init__(self, graph: NormGraph, rank, world, device, group=None, split_threshold=DEFAULT_SPLIT_THRESHOLD,
                  local_spmm=None):
         self.rank, self.world = int(rank), int(world)
-        self.device = torch.device(device)
+        self.device = resolve_device(device)
         self.group = group
         self.n_users, self.n_items = graph.n_users, graph.n_items
         self.bu, self.bi, self.u_pad, self.i_pad = padded_layout(graph.n_users, graph.n_items, self.world)

@@ -25,6 +25,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import scoring
+from ._capi import resolve_device
 from .graph import NormGraph, train_mask_csr
 from .metrics import METRICS, early_stop, ranking_metrics
 from .propagate import DEFAULT_SPLIT_THRESHOLD, DeviceCSR, Propagator, spmm
@@ -93,7 +94,7 @@ class LightGCN(nn.Module):
         self.quiet = g('quiet', True)
         self.epochs = g('epochs', 1)
         self.logger = g('logger') or logging.getLogger('textgcn_amd')
-        self.device = torch.device(g('device', 'cuda' if torch.cuda.is_available() else 'cpu'))
+        self.device = resolve_device(g('device', 'cuda' if torch.cuda.is_available() else 'cpu'))
         self.dropout = g('dropout', 0.4)
         self.emb_size = g('emb_size', 64)
         self.n_layers = g('n_layers', 3)

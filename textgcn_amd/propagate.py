@@ -53,7 +53,7 @@ class DeviceCSR:
         self.n_rows = len(rowptr) - 1
         self.n_src_rows = int(n_src_rows)
         self.nnz = int(rowptr[-1])
-        self.device = torch.device(device)
+        self.device = _capi.resolve_device(device)
         self.rowptr = torch.from_numpy(rowptr.astype(np.int32)).to(self.device)
         if self.nnz == 0:   # a graph without interactions: keep non-NULL device arrays for the ABI's pointer checks
             colidx, vals = np.zeros(1, dtype=np.int32), np.zeros(1, dtype=np.float32)
@@ -225,7 +225,7 @@ class Propagator:
 
     def __init__(self, graph: NormGraph, device, split_threshold=DEFAULT_SPLIT_THRESHOLD, segment='auto'):
         self.graph = graph
-        self.device = torch.device(device)
+        self.device = _capi.resolve_device(device)
         u, n = graph.n_users, graph.n
         # A is bipartite: user rows hold item columns and vice versa
         specs = [(0, u, u, n), (u, n, 0, u)]
