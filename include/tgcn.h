@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TGCN_ABI_VERSION 2
+#define TGCN_ABI_VERSION 3
 
 #define TGCN_OK 0
 #define TGCN_ERR_ARG (-1)         /* bad argument (null pointer, size, unsupported d/k ...) */
@@ -184,6 +184,23 @@ int tgcn_score_pairwise_f32(const float *U, const int64_t *users, const float *V
 int tgcn_score_candidates_f32(const float *U, const int64_t *users, const float *It, const int64_t *cand, int32_t B,
                               int32_t m, int32_t d, const int32_t *mask_rowptr, const int32_t *mask_items, float *out,
                               tgcn_stream_t stream);
+
+/* (e) Multi-GPU exchange step of the row partition: all-gather of the freshly propagated row blocks.
+ * The reference is single-device -- there is no call to replace (grep nccl|torch.distributed|all_gather in TextGCN/ -> 0
+ * hits); the entry point exists so that a host without torch.distributed (or a C/C++ host) can drive the sharded forward
+ * with this library alone.  One communicator per process/GPU; RCCL (librccl) is bound at run time.
+ *   tgcn_comm_unique_id    fills TGCN_COMM_ID_BYTES host bytes on ONE rank; the caller hands them to the other ranks
+ *   tgcn_comm_init_rank    collective over all `world` ranks, on the calling thread's current device
+ *   tgcn_allgather_rows    full[p * rows_local .. (p+1) * rows_local, 0:d] = rank p's local[0:rows_local, 0:d], fp32 on the
+ *                          wire, enqueued on `stream`; `local` may be the rank's own block inside `full` (in place).
+ *                          Every rank passes the same rows_local and d (pad blocks to the largest). */
+typedef void *tgcn_comm_t; /* ncclComm_t */
+#define TGCN_COMM_ID_BYTES 128
+int tgcn_comm_unique_id(void *id_host);
+int tgcn_comm_init_rank(tgcn_comm_t *comm, int32_t world, int32_t rank, const void *id_host);
+int tgcn_comm_destroy(tgcn_comm_t comm);
+int tgcn_allgather_rows(tgcn_comm_t comm, const float *local, float *full, int64_t rows_local, int32_t d,
+                        tgcn_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -34,3 +34,15 @@ def score_mask_topk(users_emb, items_emb, mask_rowptr, mask_items, k):
     rating[torch.from_numpy(rows), torch.from_numpy(np.asarray(mask_items, dtype=np.int64))] = -np.inf
     probs, idx = torch.topk(rating, k=k)
     return probs.round(decimals=4), idx
+
+
+@torch.no_grad()
+def ltr_score_batchwise(users_emb, users_reviews, users_desc, items_emb, items_reviews, items_desc, weight, bias):
+    """TextGCN/ltr_models.py:131-146 (five [B, I] products -> [B, I, 5]) + :200-204 (nn.Linear(5, 1), squeeze); the
+    item-side `table[range(I)]` copies of :103-109 included (all_items is a range, dataset.py:108)."""
+    all_items = range(items_emb.shape[0])
+    i_desc, i_rev = items_desc[all_items], items_reviews[all_items]
+    feats = torch.cat([(users_emb @ items_emb.T).unsqueeze(-1), (users_reviews @ i_rev.T).unsqueeze(-1),
+                       (users_desc @ i_desc.T).unsqueeze(-1), (users_reviews @ i_desc.T).unsqueeze(-1),
+                       (users_desc @ i_rev.T).unsqueeze(-1)], axis=-1)
+    return torch.nn.functional.linear(feats, weight, bias).squeeze()

@@ -4,6 +4,9 @@
   --mode cpu : gloo on CPU tensors; the local SpMM is the CPU oracle (injected stand-in) -- exercises the
                partitioning / padding / all-gather / layer-sum logic of textgcn_amd.dist without a GPU.
   --mode gpu : every rank uses cuda:0 (one-GPU box) with the real HIP kernels; gloo staged through the host.
+  --mode nccl: ONE rank on cuda:0 with backend nccl (= RCCL) and the world == 1 short-circuit bypassed, so the production
+               collective code runs -- in-place all_gather_into_tensor(async_op=True) + work.wait() on torch's communicator
+               (--collective torch) or tgcn_allgather_rows on libtgcn's own communicator and side stream (--collective capi).
 Writes users_full / items_full of rank 0 (after gathering the user blocks) to --out.
 """
 import argparse
@@ -35,7 +38,7 @@ def main():
     ap.add_argument('--rank', type=int, required=True)
     ap.add_argument('--world', type=int, required=True)
     ap.add_argument('--port', type=int, required=True)
-    ap.add_argument('--mode', choices=['cpu', 'gpu'], required=True)
+    ap.add_argument('--mode', choices=['cpu', 'gpu', 'nccl'], required=True)
     ap.add_argument('--out', required=True)
     ap.add_argument('--n-users', type=int, default=203)
     ap.add_argument('--n-items', type=int, default=97)
@@ -43,26 +46,40 @@ def main():
     ap.add_argument('--d', type=int, default=64)
     ap.add_argument('--layers', type=int, default=3)
     ap.add_argument('--single', action='store_true')
+    ap.add_argument('--balance', default='nnz')
+    ap.add_argument('--chunks', type=int, default=1)
+    ap.add_argument('--collective', default='torch')
     args = ap.parse_args()
 
     from textgcn_amd import synth
     from textgcn_amd.dist import ShardedPropagator
     from textgcn_amd.graph import NormGraph
 
-    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{args.port}', rank=args.rank, world_size=args.world)
+    if args.mode == 'nccl':
+        torch.cuda.set_device(0)
+        dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{args.port}', rank=args.rank, world_size=args.world,
+                                device_id=torch.device('cuda', 0))
+    else:
+        dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{args.port}', rank=args.rank, world_size=args.world)
     u, i = synth.interactions(args.n_users, args.n_items, args.nnz, seed=1)
     g = NormGraph.from_pairs(u, i, args.n_users, args.n_items)
     e0 = synth.embeddings(g.n, args.d, seed=2)
     if args.mode == 'cpu':
-        sp = ShardedPropagator(g, args.rank, args.world, 'cpu', local_spmm=oracle_spmm, split_threshold=None)
+        sp = ShardedPropagator(g, args.rank, args.world, 'cpu', local_spmm=oracle_spmm, split_threshold=None,
+                               balance=args.balance, chunks=args.chunks)
+    elif args.mode == 'nccl':
+        sp = ShardedPropagator(g, args.rank, args.world, 'cuda', split_threshold=64, balance=args.balance, chunks=args.chunks,
+                               collective=args.collective, force_collective=True)
+        assert sp.backend == 'nccl' and sp.uses_collective and (sp._capi_comm is not None) == (args.collective == 'capi')
     else:
-        sp = ShardedPropagator(g, args.rank, args.world, 'cuda:0', split_threshold=64)
+        sp = ShardedPropagator(g, args.rank, args.world, 'cuda:0', split_threshold=64, balance=args.balance, chunks=args.chunks)
     eu, ei = sp.local_e0(e0)
     users_local, items_full = sp.forward(eu, ei, args.layers, single=args.single, exact=(args.mode == 'cpu'))
     users_full = sp.gather_users(users_local)
     if args.rank == 0:
-        np.savez(args.out, users=users_full[:args.n_users].cpu().numpy(), items=items_full[:args.n_items].cpu().numpy(),
-                 nnz_local=sp.nnz_local)
+        np.savez(args.out, users=users_full.cpu().numpy(), items=sp.items_in_order(items_full).cpu().numpy(),
+                 nnz_local=sp.nnz_local, user_bounds=sp.lay_u.bounds, item_bounds=sp.lay_i.bounds)
+    sp.close()
     dist.barrier()
     dist.destroy_process_group()
 

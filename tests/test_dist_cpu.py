@@ -42,19 +42,45 @@ def reference(oracle, n_users=203, n_items=97, nnz=2500, d=64, layers=3, single=
     return out[:n_users], out[n_users:]
 
 
-@pytest.mark.parametrize('world', [2, 3])
+@pytest.mark.parametrize('world,balance,chunks', [(2, 'nnz', 1), (3, 'nnz', 3), (2, 'rows', 2), (3, 'rows', 1)])
 @pytest.mark.parametrize('single', [False, True])
-def test_sharded_forward_matches_oracle_gloo(oracle, tmp_path, world, single):
+def test_sharded_forward_matches_oracle_gloo(oracle, tmp_path, world, balance, chunks, single):
+    """gloo gathers the CPU tensors asynchronously (async_op=True + work.wait(), in place in the layer table), so the
+    wait placement of the overlap schedule is exercised, not only the partition arithmetic."""
     out = str(tmp_path / 'r0.npz')
-    run_ranks(world, 'cpu', out, extra=('--single',) if single else ())
+    run_ranks(world, 'cpu', out, extra=('--balance', balance, '--chunks', str(chunks)) + (('--single',) if single else ()))
     got = np.load(out)
     ru, ri = reference(oracle, single=single)
     assert np.array_equal(bits(got['users']), bits(ru))
     assert np.array_equal(bits(got['items']), bits(ri))
+    if balance == 'nnz':   # blocks differ in rows, not (much) in entries
+        assert len(set(np.diff(got['item_bounds']))) > 1
 
 
 def test_padded_layout_and_local_blocks():
-    from textgcn_amd.dist import padded_layout
+    from textgcn_amd.dist import BlockLayout, equal_row_bounds, padded_layout
     assert padded_layout(203, 97, 3) == (68, 33, 204, 99)
     assert padded_layout(100, 50, 1) == (100, 50, 100, 50)
     assert padded_layout(8, 8, 8) == (1, 1, 8, 8)
+    assert equal_row_bounds(10, 4).tolist() == [0, 3, 6, 9, 10]
+    lay = BlockLayout([0, 5, 7, 12], chunks=2)          # blocks of 5, 2, 5 rows -> cb = 3, b = 6
+    assert (lay.cb, lay.b, lay.n_pad) == (3, 6, 18)
+    rows = lay.table_rows(np.arange(12))
+    assert len(set(rows.tolist())) == 12 and rows.max() < lay.n_pad
+    # chunk-major: chunk 0 of ranks 0, 1, 2 is the first slab, and a rank's chunk is contiguous inside it
+    assert rows[:3].tolist() == [0, 1, 2] and rows[5:7].tolist() == [3, 4] and rows[7:10].tolist() == [6, 7, 8]
+    assert rows[3:5].tolist() == [9, 10] and rows[10:12].tolist() == [15, 16]
+    assert lay.chunk_slab(1) == slice(9, 18) and lay.my_slab(2, 1) == slice(15, 18)
+
+
+def test_nnz_balanced_partition_evens_out_entries():
+    from textgcn_amd import synth
+    from textgcn_amd.graph import NormGraph
+    u, i = synth.interactions(3000, 1000, 60000, seed=4)
+    g = NormGraph.from_pairs(u, i, 3000, 1000)
+    ub, ib = g.partition(4)
+    assert ub[0] == 0 and ub[-1] == 3000 and ib[0] == 3000 and ib[-1] == 4000
+    per = np.diff(g.rowptr[ib])
+    rows_equal = np.diff(g.rowptr[3000 + np.minimum(np.arange(5) * 250, 1000)])
+    assert per.max() / per.mean() < 1.1 <= rows_equal.max() / rows_equal.mean() + 0.1
+    assert per.max() <= rows_equal.max()

@@ -9,14 +9,41 @@ from test_dist_cpu import run_ranks
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize('world', [2, 3])
-def test_sharded_hip_forward_equals_single_gpu(cuda, tmp_path, world):
+def _single_gpu_reference(cuda, n_u, n_i, nnz, d=64, K=3):
+    from textgcn_amd import synth
+    from textgcn_amd.graph import NormGraph
+    from textgcn_amd.propagate import Propagator
+    u, i = synth.interactions(n_u, n_i, nnz, seed=1)
+    g = NormGraph.from_pairs(u, i, n_u, n_i)
+    e0 = synth.embeddings(g.n, d, seed=2).to(cuda)
+    # rows > 64 entries are split in both runs; chunking depends only on the row -> identical bits
+    return Propagator(g, cuda, split_threshold=64, segment=None).forward(e0, K).cpu().numpy()
+
+
+@pytest.mark.parametrize('collective,chunks', [('torch', 1), ('torch', 4), ('capi', 1), ('capi', 3)])
+def test_rccl_collective_path_runs_on_one_rank(cuda, tmp_path, collective, chunks):
+    """The code the multi-GPU node runs -- backend nccl (= RCCL), in-place asynchronous all-gathers into the layer table,
+    waits placed by the overlap schedule -- executed on the one-GPU box with a 1-rank communicator (the world == 1
+    short-circuit is bypassed).  `capi`: libtgcn's tgcn_comm_init_rank / tgcn_allgather_rows on a side stream."""
+    out = str(tmp_path / 'r0.npz')
+    n_u, n_i, nnz = 2030, 970, 40000
+    run_ranks(1, 'nccl', out, extra=('--n-users', str(n_u), '--n-items', str(n_i), '--nnz', str(nnz), '--collective', collective,
+                                     '--chunks', str(chunks)))
+    got = np.load(out)
+    ref = _single_gpu_reference(cuda, n_u, n_i, nnz)
+    assert np.array_equal(bits(got['users']), bits(ref[:n_u]))
+    assert np.array_equal(bits(got['items']), bits(ref[n_u:]))
+
+
+@pytest.mark.parametrize('world,balance,chunks', [(2, 'nnz', 1), (3, 'nnz', 2), (3, 'rows', 1)])
+def test_sharded_hip_forward_equals_single_gpu(cuda, tmp_path, world, balance, chunks):
     from textgcn_amd import synth
     from textgcn_amd.graph import NormGraph
     from textgcn_amd.propagate import Propagator
     out = str(tmp_path / 'r0.npz')
     n_u, n_i, nnz, d, K = 2030, 970, 40000, 64, 3
-    run_ranks(world, 'gpu', out, extra=('--n-users', str(n_u), '--n-items', str(n_i), '--nnz', str(nnz)))
+    run_ranks(world, 'gpu', out, extra=('--n-users', str(n_u), '--n-items', str(n_i), '--nnz', str(nnz), '--balance', balance,
+                                        '--chunks', str(chunks)))
     got = np.load(out)
     u, i = synth.interactions(n_u, n_i, nnz, seed=1)
     g = NormGraph.from_pairs(u, i, n_u, n_i)

@@ -152,3 +152,26 @@ def test_hip_ltr_pop_matches_reference(golden, cuda, tmp_path):
     assert row_ok.mean() > 0.8
     assert np.array_equal(pred[row_ok], ref_i[row_ok])
     assert np.abs(sc - ref_v).max() <= 1.01e-4
+
+
+@pytest.mark.gpu
+def test_hip_ltr_scores_follow_in_place_embedding_updates(golden, cuda, tmp_path):
+    """score_batchwise_ltr after the embedding tables changed IN PLACE (an unfrozen training step, load_state_dict): the
+    item operand of the folded GEMM must be rebuilt -- the propagated tables are rewritten by HIP kernels at addresses the
+    allocator reuses, so no pointer/version key can vouch for a cached copy.  Checked against the unfolded pairwise form."""
+    from textgcn_amd.ltr import LTRLinear
+    g = golden('g4_ltr')
+    n_u, n_i = int(g['n_users']), int(g['n_items'])
+    p = types.SimpleNamespace(k=[5, 10], emb_size=64, n_layers=3, device='cuda:0', load=None, load_base=None, freeze=False,
+                              batch_size=32, quiet=True, exact=True, ltr_layers=[], save_path=str(tmp_path))
+    m = LTRLinear(p, _dataset(g))
+    users = torch.arange(n_u, device=cuda)
+    uu, ii = torch.meshgrid(users, torch.arange(n_i, device=cuda), indexing='ij')
+    for step in range(3):
+        with torch.no_grad():
+            ue, ie = m.representation
+            s = m.score_batchwise(ue[users], ie, users)
+            ref = m.score_pairwise(ue[uu.reshape(-1)], ie[ii.reshape(-1)], uu.reshape(-1), ii.reshape(-1)).reshape(n_u, n_i)
+            assert normwise(s.cpu().numpy(), ref.cpu().numpy()) <= 1e-5, step
+            m.embedding_item.weight.mul_(1.5).add_(0.01 * (step + 1))      # in place: same storage, new values
+            m.embedding_user.weight.add_(0.02)

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_DIR = os.path.join(_HERE, '_lib')
 LIB = os.path.join(LIB_DIR, 'libtgcn.so')
-SOURCES = ['tgcn_core.hip', 'tgcn_spmm.hip', 'tgcn_score.hip', 'tgcn_score_fused.hip', 'tgcn_ltr.hip']
+SOURCES = ['tgcn_core.hip', 'tgcn_spmm.hip', 'tgcn_score.hip', 'tgcn_score_fused.hip', 'tgcn_ltr.hip', 'tgcn_comm.hip']
 HEADERS = [os.path.join(ROOT, 'include', 'tgcn.h'), os.path.join(CSRC, 'tgcn_internal.h'), os.path.join(CSRC, 'tgcn_topk.h')]
 ARCH = 'gfx950'
 
@@ -35,12 +35,28 @@ def torch_lib_dir():
     return os.path.join(os.path.dirname(spec.origin), 'lib')
 
 
-def flags():
-    tl = torch_lib_dir()
-    return [f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-shared',
+def compile_flags():
+    return [f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC',
             '-ffp-contract=off',  # fused multiply-adds are written explicitly (fmaf / MFMA); nothing else may fuse
-            '-fno-fast-math', f'-I{os.path.join(ROOT, "include")}', f'-I{CSRC}',
-            '-no-hip-rt', f'-L{tl}', '-lamdhip64', f'-Wl,-rpath,{tl}', '-Wl,-rpath,/opt/rocm/lib']
+            '-fno-fast-math', f'-I{os.path.join(ROOT, "include")}', f'-I{CSRC}']
+
+
+def link_flags():
+    tl = torch_lib_dir()
+    return ['-shared', '-fPIC', '--hip-link', f'--offload-arch={ARCH}', '-no-hip-rt', f'-L{tl}', '-lamdhip64', '-ldl',
+            f'-Wl,-rpath,{tl}', '-Wl,-rpath,/opt/rocm/lib']
+
+
+def _obj(src):
+    return os.path.join(LIB_DIR, 'obj', os.path.splitext(src)[0] + '.o')
+
+
+def _obj_stale(src):
+    o = _obj(src)
+    if not os.path.exists(o):
+        return True
+    t = os.path.getmtime(o)
+    return any(os.path.getmtime(d) > t for d in [os.path.join(CSRC, src)] + HEADERS + [os.path.abspath(__file__)])
 
 
 def stale():
@@ -52,12 +68,26 @@ def stale():
 
 
 def build_lib(force=False, verbose=False):
+    """One object per translation unit (compiled in parallel, rebuilt only when its source or a header changed), then
+    one link: an edit to one kernel file costs that file's compile time, not the whole library's."""
     if not force and not stale():
         return LIB
-    os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc()] + flags() + [os.path.join(CSRC, s) for s in SOURCES] + ['-o', LIB]
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(os.path.join(LIB_DIR, 'obj'), exist_ok=True)
+    cc = hipcc()
+
+    def compile_one(src):
+        cmd = [cc] + compile_flags() + ['-c', os.path.join(CSRC, src), '-o', _obj(src)]
+        if verbose:
+            cmd.append('-Rpass-analysis=kernel-resource-usage')
+            print(' '.join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+
+    todo = [s for s in SOURCES if force or _obj_stale(s)]
+    with ThreadPoolExecutor(max_workers=min(4, max(1, len(todo)))) as pool:
+        list(pool.map(compile_one, todo))
+    cmd = [cc] + [_obj(s) for s in SOURCES] + link_flags() + ['-o', LIB]
     if verbose:
-        cmd.append('-Rpass-analysis=kernel-resource-usage')
         print(' '.join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
     return LIB

@@ -6,79 +6,225 @@ freshly propagated blocks.  A is bipartite ([[0, R],[R^T, 0]]): user rows read o
 versa, so a layer is two half-steps and the all-gather of the user block runs on RCCL's stream while the item
 half-step computes.
 
-Layout.  Users and items are each cut into P equal blocks of ceil(U/P) resp. ceil(I/P) rows (tables padded
-with zero rows that no column index references), so every block of every rank has the same size and
-`all_gather_into_tensor` writes straight into the layer buffer -- no packing, no uneven collective.  Padded
-row ids: user u -> u, item i -> U_pad + i.  Row ownership never changes a row's summation order, so the
-P-rank result is bit-identical to the 1-rank result.
+Partition.  Users and items are cut separately into P contiguous blocks balanced by stored entries (item
+degrees are Zipf-skewed: equal row counts would give uneven half-steps); `balance='rows'` gives equal row counts.
+Every block is padded with empty rows to the largest block, so the collective stays an even all-gather.
 
-Backends.  "nccl" (= RCCL over xGMI) gathers device buffers directly.  Any other backend (gloo in the CPU /
-single-GPU rehearsals) is staged through host memory by this module; it exists for tests only.
+Layout.  A rank's block is cut again into C row chunks of cb rows; the layer table is stored chunk-major,
+[chunk][rank][cb rows], so chunk c of all ranks is ONE contiguous slab and `all_gather_into_tensor` of that chunk
+writes straight into the table (no packing).  A half-step is C SpMM launches, and chunk c's all-gather starts as
+soon as its launch is enqueued: the gather of chunk c runs under the SpMM of chunks c+1.. and under the whole
+other half-step.  Column ids of the local CSR blocks are remapped to table rows once, on the host; the order of a
+row's entries is kept, so a row's fmaf chain -- and with it every output bit -- is the single-GPU one whatever
+P, C and the balance are.
+
+Collectives.  backend "nccl" (= RCCL over xGMI) -> torch.distributed's communicator, or, with collective='capi',
+libtgcn's own entry point tgcn_allgather_rows on a communicator made by tgcn_comm_init_rank (include/tgcn.h) on a
+side stream.  Any other backend (gloo) is the CPU / one-GPU rehearsal used by the tests: CPU tensors are gathered
+asynchronously by gloo itself, device tensors are staged through host memory.
 """
+import ctypes
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
 
+from . import _capi
 from ._capi import resolve_device
 from .graph import NormGraph
 from .propagate import DEFAULT_SPLIT_THRESHOLD, DeviceCSR, spmm
 
 
 def padded_layout(n_users, n_items, world):
+    """Equal-row blocks (balance='rows', one chunk): (rows per user block, rows per item block, U_pad, I_pad)."""
     bu = -(-n_users // world)
     bi = -(-n_items // world)
     return bu, bi, bu * world, bi * world
+
+
+def equal_row_bounds(n, world, offset=0):
+    b = -(-n // world)
+    return offset + np.minimum(np.arange(world + 1, dtype=np.int64) * b, n)
+
+
+class BlockLayout:
+    """Padded chunk-major placement of one node kind (users or items) in the layer table.
+
+    bounds [P+1]: contiguous global id ranges per rank.  Rank p's row o (0-based inside its block) lives in chunk
+    c = o // cb at table row  c * P * cb + p * cb + o % cb;  cb = ceil(max block / C), rows per rank b = C * cb."""
+
+    def __init__(self, bounds, chunks=1):
+        self.bounds = np.asarray(bounds, dtype=np.int64)
+        self.world = len(self.bounds) - 1
+        sizes = np.diff(self.bounds)
+        if self.world < 1 or np.any(sizes < 0):
+            raise ValueError('bounds must be ascending')
+        self.chunks = max(1, int(chunks))
+        self.cb = max(1, -(-int(sizes.max()) // self.chunks))
+        self.b = self.cb * self.chunks
+        self.n_pad = self.b * self.world
+        self.n = int(self.bounds[-1] - self.bounds[0])
+
+    def table_rows(self, ids):
+        """global ids (same origin as bounds) -> table rows"""
+        ids = np.asarray(ids, dtype=np.int64)
+        p = np.searchsorted(self.bounds, ids, side='right') - 1
+        p = np.minimum(p, self.world - 1)
+        o = ids - self.bounds[p]
+        c, w = np.divmod(o, self.cb)
+        return c * (self.world * self.cb) + p * self.cb + w
+
+    def size(self, rank):
+        return int(self.bounds[rank + 1] - self.bounds[rank])
+
+    def chunk_slab(self, c):
+        """table rows of chunk c of all ranks (the all-gather's output)"""
+        return slice(c * self.world * self.cb, (c + 1) * self.world * self.cb)
+
+    def my_slab(self, rank, c):
+        """table rows of this rank's chunk c (the all-gather's input, a view of chunk_slab(c))"""
+        s = c * self.world * self.cb + rank * self.cb
+        return slice(s, s + self.cb)
 
 
 def _hip_spmm(csr, x, **kw):
     return spmm(csr, x, **kw)
 
 
+class _Done:
+    def wait(self):
+        return None
+
+
+class _EventWork:
+    """completion of a collective enqueued on a side stream: wait() orders the CURRENT stream after it"""
+
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.event)
+
+
+class CapiComm:
+    """RCCL communicator owned by libtgcn (tgcn_comm_init_rank / tgcn_allgather_rows, include/tgcn.h).  The 128-byte id is
+    made by rank 0 and handed to the other ranks by `broadcast` (any out-of-band channel; the default uses the
+    torch.distributed group the process already has)."""
+
+    def __init__(self, rank, world, device, group=None, broadcast=None):
+        self.rank, self.world, self.device = rank, world, device
+        lib = _capi.lib()
+        buf = ctypes.create_string_buffer(_capi.TGCN_COMM_ID_BYTES)
+        if rank == 0:
+            _capi.check(lib.tgcn_comm_unique_id(buf), 'tgcn_comm_unique_id')
+        ident = bytes(buf.raw)
+        if world > 1:
+            if broadcast is None:
+                box = [ident]
+                dist.broadcast_object_list(box, src=0, group=group)
+                ident = box[0]
+            else:
+                ident = broadcast(ident)
+        self._comm = ctypes.c_void_p()
+        with torch.cuda.device(device):
+            _capi.check(lib.tgcn_comm_init_rank(ctypes.byref(self._comm), world, rank, ident), 'tgcn_comm_init_rank')
+        self.stream = torch.cuda.Stream(device)
+
+    def all_gather(self, full, local):
+        """full [P*b, d] <- every rank's local [b, d]; enqueued on the communicator's side stream after the work already
+        on the current stream.  Returns a handle whose wait() orders the current stream after the collective."""
+        cur = torch.cuda.current_stream(self.device)
+        self.stream.wait_stream(cur)
+        rc = _capi.lib().tgcn_allgather_rows(self._comm, _capi.ptr(local), _capi.ptr(full), local.shape[0], local.shape[1],
+                                             ctypes.c_void_p(self.stream.cuda_stream))
+        _capi.check(rc, 'tgcn_allgather_rows')
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
+        return _EventWork(ev)
+
+    def close(self):
+        if self._comm:
+            torch.cuda.synchronize(self.device)
+            _capi.lib().tgcn_comm_destroy(self._comm)
+            self._comm = ctypes.c_void_p()
+
+
 class ShardedPropagator:
     """One rank's share of the K-layer forward.
 
-    forward(e0_users_local, e0_items_local) -> (users_local [bu, d], items_full [I_pad, d]): the rank keeps
-    its own users (they are scored where they live) and the gathered item table of the layer mean.
+    forward(e0_users_local, e0_items_local) -> (users_local [bu, d], items_table [I_pad, d]): the rank keeps its own
+    users (they are scored where they live) and the gathered item table of the layer mean, in table order
+    (`items_in_order` puts it back in item-id order).
     """
 
     def __init__(self, graph: NormGraph, rank, world, device, group=None, split_threshold=DEFAULT_SPLIT_THRESHOLD,
-                 local_spmm=None):
+                 local_spmm=None, balance='nnz', chunks=1, collective='auto', force_collective=False):
         self.rank, self.world = int(rank), int(world)
         self.device = resolve_device(device)
         self.group = group
         self.n_users, self.n_items = graph.n_users, graph.n_items
-        self.bu, self.bi, self.u_pad, self.i_pad = padded_layout(graph.n_users, graph.n_items, self.world)
+        if balance == 'nnz':
+            ub, ib = graph.partition(self.world)
+        elif balance == 'rows':
+            ub = equal_row_bounds(graph.n_users, self.world)
+            ib = equal_row_bounds(graph.n_items, self.world, graph.n_users)
+        else:
+            raise ValueError("balance must be 'nnz' or 'rows'")
+        self.lay_u = BlockLayout(ub, chunks)
+        self.lay_i = BlockLayout(np.asarray(ib) - graph.n_users, chunks)      # item ids 0..I-1
+        self.bu, self.bi = self.lay_u.b, self.lay_i.b
+        self.u_pad, self.i_pad = self.lay_u.n_pad, self.lay_i.n_pad
         self.n_pad = self.u_pad + self.i_pad
         self._spmm = local_spmm or _hip_spmm   # tests inject a CPU stand-in to rehearse the exchange logic
-        self.backend = dist.get_backend(group) if self.world > 1 else 'none'
-        u0, u1 = self._user_range(self.rank)
-        i0, i1 = self._item_range(self.rank)
-        # local CSR blocks, column ids remapped to the padded layout
-        rp, ci, va = graph.row_block(u0, u1)
-        self.csr_u = self._make_csr(rp, ci.astype(np.int64) + (self.u_pad - graph.n_users), va, self.bu, split_threshold)
-        rp, ci, va = graph.row_block(graph.n_users + i0, graph.n_users + i1)
-        self.csr_i = self._make_csr(rp, ci, va, self.bi, split_threshold)
-        self.nnz_local = self.csr_u.nnz + self.csr_i.nnz
+        self.uses_collective = self.world > 1 or force_collective
+        self.backend = dist.get_backend(group) if self.uses_collective else 'none'
+        self._capi_comm = None
+        if self.uses_collective and self.backend == 'nccl':
+            if collective == 'auto':
+                collective = os.environ.get('TGCN_COLLECTIVE', 'torch')
+            if collective == 'capi':
+                self._capi_comm = CapiComm(self.rank, self.world, self.device, group)
+            elif collective != 'torch':
+                raise ValueError("collective must be 'auto', 'torch' or 'capi'")
+        # local CSR blocks, one per row chunk, column ids remapped to table rows
+        self.csr_u = self._chunk_csrs(graph, self.lay_u, 0, lambda c: self.u_pad + self.lay_i.table_rows(c - graph.n_users),
+                                      split_threshold)
+        self.csr_i = self._chunk_csrs(graph, self.lay_i, graph.n_users, self.lay_u.table_rows, split_threshold)
+        self.nnz_local = sum(c.nnz for c in self.csr_u) + sum(c.nnz for c in self.csr_i)
         self._buf = {}
+        self._item_order = None
 
-    def _user_range(self, r):
-        return min(r * self.bu, self.n_users), min((r + 1) * self.bu, self.n_users)
+    # ------------------------------------------------------------------ construction
+    def _chunk_csrs(self, graph, lay, row_origin, remap, split_threshold):
+        g0 = row_origin + int(lay.bounds[self.rank])
+        g1 = row_origin + int(lay.bounds[self.rank + 1])
+        out = []
+        for c in range(lay.chunks):
+            r0 = min(g0 + c * lay.cb, g1)
+            r1 = min(r0 + lay.cb, g1)
+            rp, ci, va = graph.row_block(r0, r1)
+            rp = np.asarray(rp, dtype=np.int64)
+            if len(rp) - 1 < lay.cb:   # pad rows: empty
+                rp = np.concatenate([rp, np.full(lay.cb - (len(rp) - 1), rp[-1], dtype=np.int64)])
+            cols = remap(np.asarray(ci, dtype=np.int64)) if len(ci) else np.zeros(0, dtype=np.int64)
+            out.append(DeviceCSR(rp, cols, va, self.n_pad, self.device, split_threshold))
+        return out
 
-    def _item_range(self, r):
-        return min(r * self.bi, self.n_items), min((r + 1) * self.bi, self.n_items)
+    def user_range(self, r=None):
+        r = self.rank if r is None else r
+        return int(self.lay_u.bounds[r]), int(self.lay_u.bounds[r + 1])
 
-    def _make_csr(self, rowptr, colidx, vals, n_rows_padded, split_threshold):
-        rowptr = np.asarray(rowptr, dtype=np.int64)
-        if len(rowptr) - 1 < n_rows_padded:   # pad rows: empty
-            rowptr = np.concatenate([rowptr, np.full(n_rows_padded - (len(rowptr) - 1), rowptr[-1], dtype=np.int64)])
-        return DeviceCSR(rowptr, colidx, vals, self.n_pad, self.device, split_threshold)
+    def item_range(self, r=None):
+        r = self.rank if r is None else r
+        return int(self.lay_i.bounds[r]), int(self.lay_i.bounds[r + 1])
 
     # ------------------------------------------------------------------ helpers
     def local_e0(self, e0_full):
         """Cut this rank's padded E0 blocks out of a full [N, d] table (host or device tensor)."""
         d = e0_full.shape[1]
-        u0, u1 = self._user_range(self.rank)
-        i0, i1 = self._item_range(self.rank)
+        u0, u1 = self.user_range()
+        i0, i1 = self.item_range()
         eu = torch.zeros((self.bu, d), dtype=torch.float32, device=self.device)
         ei = torch.zeros((self.bi, d), dtype=torch.float32, device=self.device)
         eu[:u1 - u0] = e0_full[u0:u1].to(self.device)
@@ -89,29 +235,33 @@ class ShardedPropagator:
         if d not in self._buf:
             mk = lambda n: torch.zeros((n, d), dtype=torch.float32, device=self.device)  # noqa: E731
             self._buf[d] = {'x': [mk(self.n_pad), mk(self.n_pad)], 'acc_u': mk(self.bu), 'acc_i': mk(self.bi),
-                            'out_u': mk(self.bu), 'out_i': mk(self.i_pad)}
+                            'out_u': mk(self.bu)}
         return self._buf[d]
 
-    def _all_gather(self, full, local, async_op):
-        """full [P*b, d] <- blocks of every rank (local is a view of full at this rank's offset, or a
-        separate tensor).  Returns a work handle or None."""
-        if self.world == 1:
-            if local.data_ptr() != full[self.rank * local.shape[0]:].data_ptr():
-                full[self.rank * local.shape[0]:(self.rank + 1) * local.shape[0]].copy_(local)
-            return None
-        if self.backend == 'nccl':
-            return dist.all_gather_into_tensor(full, local, group=self.group, async_op=async_op)
-        # rehearsal path (gloo): stage through host memory, synchronous
+    def _all_gather(self, full, local):
+        """full [P*cb, d] <- the [cb, d] blocks of every rank; `local` is the view of `full` at this rank's offset.
+        Asynchronous where the backend allows; returns a handle with wait()."""
+        if not self.uses_collective:
+            return _Done()
+        if self._capi_comm is not None:
+            return self._capi_comm.all_gather(full, local)
+        if self.backend == 'nccl' or full.device.type == 'cpu':
+            return dist.all_gather_into_tensor(full, local, group=self.group, async_op=True)
+        # one-GPU rehearsal (gloo, device tensors): staged through host memory, synchronous
         host_local = local.detach().cpu().contiguous()
         host_full = torch.empty((self.world * host_local.shape[0], host_local.shape[1]), dtype=host_local.dtype)
         dist.all_gather_into_tensor(host_full, host_local, group=self.group)
         full.copy_(host_full.to(full.device))
-        return None
+        return _Done()
 
     @staticmethod
-    def _wait(work):
-        if work is not None:
-            work.wait()
+    def _wait(works):
+        for w in works:
+            w.wait()
+
+    def _chunks(self, table_part, lay):
+        """[(gather target slab, this rank's view of it)] per chunk of one node kind's part of a layer table"""
+        return [(table_part[lay.chunk_slab(c)], table_part[lay.my_slab(self.rank, c)]) for c in range(lay.chunks)]
 
     # ------------------------------------------------------------------ forward
     def forward(self, e0_u, e0_i, n_layers, single=False, exact=False):
@@ -119,44 +269,58 @@ class ShardedPropagator:
         d = e0_u.shape[1]
         b = self.buffers(d)
         x, y = b['x']
-        xu, xi = x[:self.u_pad], x[self.u_pad:]
-        my_u = slice(self.rank * self.bu, (self.rank + 1) * self.bu)
-        my_i = slice(self.rank * self.bi, (self.rank + 1) * self.bi)
-        # layer-0 table: gather E0 blocks
-        xu[my_u].copy_(e0_u)
-        xi[my_i].copy_(e0_i)
-        self._wait(self._all_gather(xu, xu[my_u], False))
-        self._wait(self._all_gather(xi, xi[my_i], False))
+        lu, li = self.lay_u, self.lay_i
+        C = lu.chunks
+        rows_u = [slice(c * lu.cb, (c + 1) * lu.cb) for c in range(C)]      # local rows of chunk c
+        rows_i = [slice(c * li.cb, (c + 1) * li.cb) for c in range(C)]
+        # layer-0 table: every rank's E0 chunks
+        pending = []
+        for part, lay, e0, rows in ((x[:self.u_pad], lu, e0_u, rows_u), (x[self.u_pad:], li, e0_i, rows_i)):
+            for (full, mine), r in zip(self._chunks(part, lay), rows):
+                mine.copy_(e0[r])
+                pending.append(self._all_gather(full, mine))
+        self._wait(pending)
         if n_layers == 0:
             b['out_u'].copy_(e0_u)
-            b['out_i'].copy_(xi)
-            return b['out_u'], b['out_i']
+            return b['out_u'], x[self.u_pad:]
         acc_u, acc_i = b['acc_u'], b['acc_i']
         # Pending gathers of the table being READ (x): users feed the item half-step, items feed the user half-step.
-        wait_users = wait_items = None
+        wait_users, wait_items = [], []
         for k in range(1, n_layers + 1):
             last = k == n_layers
-            yu, yi = y[:self.u_pad], y[self.u_pad:]
             div = float(n_layers + 1) if last else 1.0
+            yu_chunks = self._chunks(y[:self.u_pad], lu)
+            yi_chunks = self._chunks(y[self.u_pad:], li)
 
             def user_half():   # reads the item rows of x
                 self._wait(wait_items)
-                if single:
-                    self._spmm(self.csr_u, x, y=b['out_u'] if last else yu[my_u], exact=exact)
-                else:
-                    self._spmm(self.csr_u, x, y=None if last else yu[my_u], acc_in=e0_u if k == 1 else acc_u,
-                               acc_out=b['out_u'] if last else acc_u, acc_div=div, exact=exact)
-                return None if last else self._all_gather(yu, yu[my_u], True)
+                works = []
+                for c in range(C):
+                    full, mine = yu_chunks[c]
+                    r = rows_u[c]
+                    if single:
+                        self._spmm(self.csr_u[c], x, y=b['out_u'][r] if last else mine, exact=exact)
+                    else:
+                        self._spmm(self.csr_u[c], x, y=None if last else mine, acc_in=e0_u[r] if k == 1 else acc_u[r],
+                                   acc_out=b['out_u'][r] if last else acc_u[r], acc_div=div, exact=exact)
+                    if not last:   # users stay where they live after the last layer
+                        works.append(self._all_gather(full, mine))
+                return works
 
             def item_half():   # reads the user rows of x
                 self._wait(wait_users)
-                if single:
-                    self._spmm(self.csr_i, x, y=yi[my_i], exact=exact)
-                else:
-                    # on the last layer the item block of the *mean* is what gets gathered: write it into yi
-                    self._spmm(self.csr_i, x, y=None if last else yi[my_i], acc_in=e0_i if k == 1 else acc_i,
-                               acc_out=yi[my_i] if last else acc_i, acc_div=div, exact=exact)
-                return self._all_gather(yi, yi[my_i], True)
+                works = []
+                for c in range(C):
+                    full, mine = yi_chunks[c]
+                    r = rows_i[c]
+                    if single:
+                        self._spmm(self.csr_i[c], x, y=mine, exact=exact)
+                    else:
+                        # on the last layer the item block of the *mean* is what gets gathered: write it into the table
+                        self._spmm(self.csr_i[c], x, y=None if last else mine, acc_in=e0_i[r] if k == 1 else acc_i[r],
+                                   acc_out=mine if last else acc_i[r], acc_div=div, exact=exact)
+                    works.append(self._all_gather(full, mine))
+                return works
 
             # Alternate the order so that EVERY all-gather overlaps a half-step: the block gathered last in layer
             # k-1 is consumed last in layer k (odd layers: users then items; even layers: items then users).
@@ -170,12 +334,29 @@ class ShardedPropagator:
             x, y = y, x
         self._wait(wait_users)
         self._wait(wait_items)
-        # after the swap, x holds the last layer: its item part is the gathered item table
-        b['out_i'].copy_(x[self.u_pad:])
-        return b['out_u'], b['out_i']
+        # after the swap, x holds the last layer: its item part is the gathered item table (a view, no copy)
+        return b['out_u'], x[self.u_pad:]
+
+    # ------------------------------------------------------------------ consumers
+    def items_in_order(self, items_table):
+        """[I_pad, d] table order -> [I, d] item-id order (one row gather; scoring reads this)."""
+        if self._item_order is None:
+            self._item_order = torch.from_numpy(self.lay_i.table_rows(np.arange(self.n_items))).to(items_table.device)
+        return items_table.index_select(0, self._item_order)
 
     def gather_users(self, users_local):
-        """All ranks' user blocks -> [U_pad, d] (for tests / single-process consumers)."""
-        full = torch.empty((self.u_pad, users_local.shape[1]), dtype=torch.float32, device=self.device)
-        self._wait(self._all_gather(full, users_local.contiguous(), False))
-        return full
+        """All ranks' user blocks -> [U, d] in user-id order (tests / single-process consumers)."""
+        d = users_local.shape[1]
+        full = torch.empty((self.world * self.bu, d), dtype=torch.float32, device=users_local.device)
+        mine = full[self.rank * self.bu:(self.rank + 1) * self.bu]
+        mine.copy_(users_local)
+        self._all_gather(full, mine).wait()
+        if full.device.type == 'cuda':
+            torch.cuda.current_stream(full.device).synchronize()
+        rows = np.concatenate([r * self.bu + np.arange(self.lay_u.size(r)) for r in range(self.world)])
+        return full[torch.from_numpy(rows).to(full.device)]
+
+    def close(self):
+        if self._capi_comm is not None:
+            self._capi_comm.close()
+            self._capi_comm = None

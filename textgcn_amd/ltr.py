@@ -91,7 +91,6 @@ class LTRLinear(LightGCN):
             self.load_model(self.load_base)
         self.feature_names = list(FEATURE_NAMES)
         self._setup_layers(params)
-        self._packed = None
 
     def _setup_layers(self, params):
         sizes = [len(self.feature_names)] + self._ltr_layers + [1]   # ltr_models.py:186-190
@@ -127,15 +126,15 @@ class LTRLinear(LightGCN):
         return out
 
     def _pack_items(self, items_emb):
-        key = (items_emb.data_ptr(), items_emb._version)
-        if self._packed is None or self._packed[0] != key:
-            out = torch.empty((self.n_items, self._k()), dtype=torch.float32, device=self.device)
-            rc = _capi.lib().tgcn_ltr_pack_items_f32(_capi.ptr(items_emb), _capi.ptr(self.items_as_avg_reviews),
-                                                     _capi.ptr(self.items_as_desc), self.n_items, self.emb_size, self.text_dim,
-                                                     _capi.ptr(out), _capi.current_stream(self.device))
-            _capi.check(rc, 'tgcn_ltr_pack_items_f32')
-            self._packed = (key, out)
-        return self._packed[1]
+        """[I, K] item operand of the folded GEMM.  Never cached across calls: the propagated tables are rewritten in
+        place by HIP kernels (no torch version bump) at addresses the caching allocator reuses, so no key over
+        (pointer, version) can tell a fresh table from a stale one; predict_tensors packs once per call and passes it on."""
+        out = torch.empty((self.n_items, self._k()), dtype=torch.float32, device=self.device)
+        rc = _capi.lib().tgcn_ltr_pack_items_f32(_capi.ptr(items_emb), _capi.ptr(self.items_as_avg_reviews),
+                                                 _capi.ptr(self.items_as_desc), self.n_items, self.emb_size, self.text_dim,
+                                                 _capi.ptr(out), _capi.current_stream(self.device))
+        _capi.check(rc, 'tgcn_ltr_pack_items_f32')
+        return out
 
     # ------------------------------------------------------------------ scoring (ltr_models.py:200-210)
     def score_batchwise_ltr(self, users_emb, items_emb, users):
@@ -167,7 +166,6 @@ class LTRLinear(LightGCN):
         users_np = np.asarray(users, dtype=np.int64)
         if 'score_batchwise' not in self.__dict__:   # still inside __init__: the loaded base model is evaluated as LightGCN
             return LightGCN.predict_tensors(self, users_np)
-        self._packed = None   # item operand is rebuilt once per predict call
         self.training = False
         kmax = max(self.k)
         users_emb, items_emb = self.representation
@@ -239,15 +237,11 @@ class LTRLinearWPop(LTRLinear):
         return out
 
     def _pack_items(self, items_emb):
-        key = (items_emb.data_ptr(), items_emb._version, 'pop')
-        if self._packed is None or self._packed[0] != key:
-            self._packed = None
-            out = self._widen(super()._pack_items(items_emb)).clone()
-            c, _ = self._pop_columns()
-            out[:, c] = 1.0
-            out[:, c + 1] = self.popularity_items[:, 0]
-            self._packed = (key, out)
-        return self._packed[1]
+        out = self._widen(super()._pack_items(items_emb)).clone()
+        c, _ = self._pop_columns()
+        out[:, c] = 1.0
+        out[:, c + 1] = self.popularity_items[:, 0]
+        return out
 
     def score_pairwise_ltr(self, users_emb, items_emb, users, items):
         users = torch.as_tensor(users, dtype=torch.int64, device=self.device)
