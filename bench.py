@@ -10,21 +10,29 @@ synthetic graph, inputs resident in HBM.  Headline value = propagated directed e
 user-item pairs/s: dense scores + train mask + top-40 per batch of 2048 users) is timed in a separate region
 and reported under "scoring" in the same JSON line.
 
-N = 1 runs BASELINE config 2 (U=100k, I=50k, nnz=5M, d=64, K=3).  N > 1 runs the same graph family scaled
-with N (U=100k*N, I=50k*N, nnz=5M*N: fixed work per GPU -> "weak"), row-sharded with one RCCL all-gather of
-the propagated user block and one of the item block per layer.
+N = 1: the headline is BASELINE config 2 (U=100k, I=50k, nnz=5M, d=64, K=3); the same line carries sub-records for the
+other single-GPU configurations -- "c4_1gpu" (config 4, U=5M I=2M nnz=100M, the size the north-star target is stated
+on, on ONE GPU), "c3" (d=128, K=4 + full-catalogue scoring) and "c5" (ltr_linear head) -- each with its own roofline,
+cpu_baseline and verify entries (--sub to choose).
+N > 1: config 4 itself, row-sharded over the N ranks (fixed total work -> "strong"), one RCCL all-gather of the
+propagated user block and one of the item block per layer, chunked so they run under the SpMM launches.
 
-roofline: HBM-bound SpMM.  `achieved` = ALGORITHMIC (compulsory) bytes of one layer launch / its mean duration,
-bytes = nnz*8 + (rows+1)*4 + n_src*d*4 + rows*d*4 + fused layer-sum traffic; `traffic` = HBM
-bytes per layer launch from the rocprofv3 PMC pass committed under profiles/ (null when no profile matches).
-cpu_baseline: the torch CPU calls the reference makes (torch.sparse.mm on the coalesced COO x K, stack+mean),
-timed on this host on a bounded sample (kind "port": oracle/torch_port.py).
+roofline: HBM-bound SpMM.  `achieved` = ALGORITHMIC (compulsory) bytes of one layer launch / its mean duration (HIP events
+on the launch stream around the timed region), bytes = nnz*8 + (rows+1)*4 + n_src*d*4 + rows*d*4 + fused layer-sum
+traffic; `traffic` = HBM bytes per layer launch from the rocprofv3 PMC pass committed under profiles/
+(`traffic_source` names it; null when the SpMM sources changed since that pass); `gather_bound` = what the same launch
+would take if every stored entry's 4d-byte row gather ran at the random-row rate measured live for a table of this size.
+cpu_baseline: the torch CPU calls the reference makes (torch.sparse.mm on the coalesced COO x K, stack+mean), timed on
+this host with all threads and with one (kind "port": oracle/torch_port.py); its output doubles as the `verify` check of
+the timed GPU output (outside the timed region).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
 import time
+import types
 
 import numpy as np
 import torch
@@ -34,6 +42,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3   # fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+SPMM_SOURCES = ('textgcn_amd/csrc/tgcn_spmm.hip', 'textgcn_amd/propagate.py', 'textgcn_amd/graph.py')
 
 
 def algorithmic_bytes_per_layer(nnz, n_rows, n_src, d, layer, n_layers, single):
@@ -49,51 +58,393 @@ def algorithmic_bytes_per_layer(nnz, n_rows, n_src, d, layer, n_layers, single):
     return b
 
 
+def spmm_sources_sha16():
+    h = hashlib.sha256()
+    for f in SPMM_SOURCES:
+        h.update(open(os.path.join(ROOT, f), 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def load_traffic(workload):
-    """HBM bytes per layer launch measured by rocprofv3 --pmc (profiles/hbm_traffic.json), or None."""
+    """(HBM bytes per layer launch, source note) from the rocprofv3 PMC pass under profiles/ -- a recorded figure, not
+    measured in this run; dropped (None) when the SpMM sources differ from the ones the pass was taken on."""
     p = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
-    if os.path.exists(p):
-        try:
-            return json.load(open(p)).get(workload, {}).get('hbm_bytes_per_layer')
-        except Exception:
-            return None
-    return None
+    try:
+        ent = json.load(open(p)).get(workload)
+    except Exception:
+        ent = None
+    if not ent:
+        return None, 'no PMC pass recorded for this workload (profiles/hbm_traffic.json)'
+    src = (f"profiles/hbm_traffic.json[{workload}]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of round {ent.get('round')}, "
+           f"kernels {ent.get('kernels') or ent.get('kernel')}, FETCH_SIZE x2 + WRITE_SIZE; recorded, not measured in this run")
+    if ent.get('sources_sha16') != spmm_sources_sha16():
+        return None, src + ' -- STALE: the SpMM sources changed since that pass, figure withheld'
+    return ent.get('hbm_bytes_per_layer'), src
 
 
-def cpu_baseline_propagation(graph, e0, n_layers, budget_s=12.0):
-    """The reference's own torch calls on this host's CPU (oracle/torch_port.py), bounded sample."""
+def cpu_threads_note():
+    return f'{torch.get_num_threads()} torch threads on {os.cpu_count()} host cpus'
+
+
+def cpu_baseline_propagation(graph, e0, n_layers, gpu_out=None, budget_s=6.0):
+    """The reference's own torch calls on this host's CPU (oracle/torch_port.py), bounded sample, all threads then one
+    thread (torch's COO SpMM kernel is single-threaded).  The CPU output is also the checker
+    of the timed GPU output (`verify`)."""
     from oracle import torch_port
     idx, val = graph.to_coo()
     a = torch_port.norm_matrix(idx, val, graph.n)
-    threads = torch.get_num_threads()
-    # sample: whole forwards while the budget lasts (at least one)
-    t0 = time.perf_counter()
-    n_fwd = 0
-    while True:
-        torch_port.representation(a, e0, n_layers)
-        n_fwd += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or n_fwd >= 5:
-            break
-    return {'value': n_fwd * n_layers * graph.nnz / el, 'unit': 'edges/s', 'cores': threads, 'kind': 'port',
-            'sample': f'{n_fwd} full {n_layers}-layer CPU forward(s) of the same graph in {el:.1f} s; '
-                      f'torch {torch.__version__} sparse.mm on coalesced COO (single-threaded kernel) + stack/mean, '
-                      f'{threads} torch threads on {os.cpu_count()} host cpus'}
+    all_threads = torch.get_num_threads()
+    recs, ref = [], None
+    for threads in (all_threads, 1):
+        torch.set_num_threads(threads)
+        t0 = time.perf_counter()
+        n_fwd = 0
+        while True:
+            ref = torch_port.representation(a, e0, n_layers)
+            n_fwd += 1
+            el = time.perf_counter() - t0
+            if el > budget_s or n_fwd >= 3:
+                break
+        recs.append({'value': n_fwd * n_layers * graph.nnz / el, 'unit': 'edges/s', 'cores': threads, 'kind': 'port',
+                     'sample': f'{n_fwd} full {n_layers}-layer CPU forward(s) of the same graph in {el:.1f} s; torch '
+                               f'{torch.__version__} sparse.mm on coalesced COO (single-threaded kernel) + stack/mean, '
+                               f'{threads} torch thread(s) on {os.cpu_count()} host cpus'})
+    torch.set_num_threads(all_threads)
+    rec = recs[0]
+    rec['one_thread'] = recs[1]
+    verify = None
+    if gpu_out is not None:
+        r = ref.numpy()
+        g = gpu_out.cpu().numpy()
+        verify = {'what': 'whole timed GPU output vs the CPU port of the reference forward (all rows)',
+                  'normwise_max_err': float(np.abs(g.astype(np.float64) - r).max() / np.abs(r).max()), 'bar': 1e-4}
+        verify['ok'] = bool(verify['normwise_max_err'] <= verify['bar'])
+    return rec, verify
 
 
-def cpu_baseline_scoring(users_emb, items_emb, mask_rowptr, mask_items, k, budget_s=8.0):
+def cpu_baseline_scoring(users_emb, items_emb, mask_rowptr, mask_items, k, gpu_topk=None, budget_s=6.0):
     from oracle import torch_port
     b = users_emb.shape[0]
     t0 = time.perf_counter()
     n = 0
     while True:
-        torch_port.score_mask_topk(users_emb, items_emb, mask_rowptr, mask_items, k)
+        pv, pi = torch_port.score_mask_topk(users_emb, items_emb, mask_rowptr, mask_items, k)
         n += 1
         el = time.perf_counter() - t0
         if el > budget_s or n >= 5:
             break
-    return {'value': n * b * items_emb.shape[0] / el, 'unit': 'pairs/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'{n} batch(es) of {b} users x {items_emb.shape[0]} items: torch.matmul + -inf mask + topk({k}) in {el:.1f} s'}
+    rec = {'value': n * b * items_emb.shape[0] / el, 'unit': 'pairs/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+           'sample': f'{n} batch(es) of {b} users x {items_emb.shape[0]} items: torch.matmul + -inf mask + topk({k}) in {el:.1f} s'}
+    verify = None
+    if gpu_topk is not None:
+        gv, gi = gpu_topk[0].cpu().numpy(), gpu_topk[1].cpu().numpy()
+        same = (gi == pi.numpy()).all(axis=1)
+        verify = {'what': f'top-{k} of the first timed batch vs the CPU port (matmul + mask + topk + round)',
+                  'rows_identical': int(same.sum()), 'rows': int(len(same)),
+                  'max_score_diff': float(np.abs(gv - pv.numpy())[np.isfinite(gv)].max())}
+        # BLAS summation order differs from the k-ordered chain in the last bits: a few near-tied neighbours may swap
+        verify['ok'] = bool(same.mean() >= 0.98 and verify['max_score_diff'] <= 1.01e-4)
+    return rec, verify
+
+
+def time_steps(step, steps, warmup, barrier):
+    """W untimed warm-up steps, then exactly `steps` steps between barriers; (device seconds by HIP events on the launch
+    stream, wall seconds)."""
+    for _ in range(warmup):
+        step()
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(steps):
+        step()
+    ev1.record()
+    barrier()
+    return ev0.elapsed_time(ev1) / 1e3, time.perf_counter() - t0
+
+
+def random_row_rate(n_rows, d, dev, entries=1 << 23):
+    """Random-row gather rate of THIS chip for a [n_rows, d] fp32 table, measured live with the production kernel:
+    rows of 64 stored entries with uniformly random columns (bytes = entries * 4d / launch time)."""
+    from textgcn_amd.propagate import DeviceCSR, spmm
+    rng = np.random.default_rng(1)
+    per_row = 64
+    n_out = entries // per_row
+    cols = rng.integers(0, n_rows, size=n_out * per_row, dtype=np.int64)
+    csr = DeviceCSR(np.arange(n_out + 1, dtype=np.int64) * per_row, cols, np.ones(len(cols), dtype=np.float32), n_rows, dev,
+                    order_rows=False)
+    x = torch.randn((n_rows, d), device=dev)
+    y = torch.empty((n_out, d), device=dev)
+    for _ in range(2):
+        spmm(csr, x, y=y, exact=True)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    reps = 5
+    for _ in range(reps):
+        spmm(csr, x, y=y, exact=True)
+    ev1.record()
+    ev1.synchronize()
+    return len(cols) * 4.0 * d / (ev0.elapsed_time(ev1) / 1e3 / reps)
+
+
+def spmm_roofline(nnz_local, n_rows_local, n_src, d, K, t_dev, steps, traffic, traffic_src, dev, gather=True):
+    layer_bytes = [algorithmic_bytes_per_layer(nnz_local, n_rows_local, n_src, d, k, K, False) for k in range(1, K + 1)]
+    mean_layer_s = t_dev / (steps * K)
+    achieved = float(np.mean(layer_bytes)) / mean_layer_s / 1e9
+    r = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+         'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
+         # recorded memory-side bytes (PMC pass, profiles/) over the live launch time: what the fabric moves
+         'traffic_GBs': round(traffic / mean_layer_s / 1e9, 1) if traffic else None,
+         'kernel': 'one SpMM layer (k_spmm_seg + k_spmm_seg_reduce, or k_spmm_wave + k_spmm_long_reduce)',
+         'algorithmic_bytes_per_launch': int(np.mean(layer_bytes)), 'launch_us': round(mean_layer_s * 1e6, 2),
+         'gather_model_GBs': round((nnz_local * (8 + 4 * d) + n_rows_local * d * 4) / mean_layer_s / 1e9, 1)}
+    if gather:
+        rate = random_row_rate(n_src, d, dev)
+        t_gather = nnz_local * 4.0 * d / rate
+        r['gather_bound'] = {'what': 'time of one layer if each stored entry cost one 4d-byte row gather at the random-row rate '
+                                     'measured live (production kernel, uniform random rows of a table this size)',
+                             'table_MB': round(n_src * d * 4 / 1e6, 1), 'random_row_rate_GBs': round(rate / 1e9, 1),
+                             'layer_us_at_that_rate': round(t_gather * 1e6, 2),
+                             'frac_of_gather_bound': round(t_gather / mean_layer_s, 4)}
+    return r
+
+
+def batch_masks(users, mrp, mit, dev, ids_origin=0):
+    """[(user ids, mask rowptr, mask items)] device triple for one scoring call"""
+    rowptr = np.zeros(len(users) + 1, dtype=np.int32)
+    np.cumsum(mrp[users + 1] - mrp[users], out=rowptr[1:])
+    if len(users) and np.all(np.diff(users) == 1):
+        items = mit[mrp[users[0]]:mrp[users[-1] + 1]]
+    else:
+        items = np.concatenate([mit[mrp[x]:mrp[x + 1]] for x in users])
+    return (torch.from_numpy(users - ids_origin).to(dev), torch.from_numpy(rowptr).to(dev),
+            torch.from_numpy(np.ascontiguousarray(items)).to(dev))
+
+
+def scoring_region(ue, ie, batches, k_top, dev, barrier):
+    """Consecutive calls are independent: issued round-robin on three HIP streams with their own scratch buffers, as
+    LightGCN.predict does, so one call's small selection kernels run under the next call's GEMM.  Returns seconds."""
+    from textgcn_amd import scoring
+    main = torch.cuda.current_stream(dev)
+    side = [torch.cuda.Stream(dev) for _ in range(3)]
+
+    def score_all(bts):   # the predict step of base_model.py:254-263, fused (tgcn_score_topk_f32)
+        for st in side:
+            st.wait_stream(main)
+        keep = []
+        for j, (ids, rp, it) in enumerate(bts):
+            with torch.cuda.stream(side[j % 3]):
+                keep.append(scoring.score_topk(ue, ie, k_top, user_ids=ids, mask_rowptr=rp, mask_items=it, round4=True,
+                                               slot=j % 3))
+        for st in side:
+            main.wait_stream(st)
+        return keep
+    score_all(batches[:3])
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    keep = score_all(batches)
+    ev1.record()
+    barrier()
+    return ev0.elapsed_time(ev1) / 1e3, keep
+
+
+# ---------------------------------------------------------------------------------------------------- sub-records (N = 1)
+def record_c4_one_gpu(dev, steps=5, warmup=2, cpu=True):
+    """BASELINE config 4 on ONE GPU: the size the north-star's >= 60 % target is stated on."""
+    from textgcn_amd import propagate, synth
+    from textgcn_amd.graph import NormGraph
+    n_u, n_i, nnz, d, K = synth.CONFIGS['c4']
+    t0 = time.time()
+    u, i = synth.interactions(n_u, n_i, nnz, seed=0)
+    graph = NormGraph.from_pairs(u, i, n_u, n_i)
+    del u, i
+    e0 = synth.embeddings(graph.n, d, seed=0)
+    build_s = time.time() - t0
+    prop = propagate.Propagator(graph, dev)
+    e0d = e0.to(dev)
+    out = torch.empty_like(e0d)
+
+    def barrier():
+        torch.cuda.synchronize()
+    t_dev, t_wall = time_steps(lambda: prop.forward(e0d, K, out=out), steps, warmup, barrier)
+    t = max(t_dev, t_wall)
+    traffic, tsrc = load_traffic('c4')
+    rec = {'metric': 'propagated edges/sec (3-layer SpMM, d=64)', 'value': steps * K * graph.nnz / t, 'unit': 'edges/s',
+           'n_gpus': 1, 'steps': steps, 'warmup': warmup, 'ms_per_step': t / steps * 1e3, 'dtype': 'f32', 'data': 'synthetic',
+           'config': {'workload': f'c4: U={n_u} I={n_i} nnz={nnz} d={d} K={K}', 'nnz_A': graph.nnz, 'n_nodes': graph.n,
+                      'max_degree': int(graph.degrees().max()), 'sharding': 'none (whole graph on one GPU)',
+                      'graph_build_s': round(build_s, 1)},
+           'roofline': spmm_roofline(graph.nnz, graph.n, graph.n, d, K, t_dev, steps, traffic, tsrc, dev)}
+    if cpu:
+        # CPU sample: the layer-1 product of the first user rows holding ~10 M stored entries (the full forward is ~25 s per
+        # layer on torch's single-threaded COO kernel); the same rows of the GPU's layer 1 are checked against it
+        from oracle import torch_port
+        r = int(np.searchsorted(graph.rowptr, 10_000_000))
+        e = int(graph.rowptr[r])
+        rows = np.repeat(np.arange(r, dtype=np.int64), np.diff(graph.rowptr[:r + 1]))
+        a = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, graph.colidx[:e].astype(np.int64)])),
+                                    torch.from_numpy(graph.vals[:e].copy()), (r, graph.n)).coalesce()
+        del rows
+        all_threads = torch.get_num_threads()
+        recs = []
+        for threads in (all_threads, 1):
+            torch.set_num_threads(threads)
+            t0 = time.perf_counter()
+            ref = torch.sparse.mm(a, e0)
+            el = time.perf_counter() - t0
+            recs.append({'value': e / el, 'unit': 'edges/s', 'cores': threads, 'kind': 'port',
+                         'sample': f'ONE layer of the first {r} user rows ({e} stored entries, 1/{graph.nnz // e} of a layer) in '
+                                   f'{el:.2f} s: torch.sparse.mm on the coalesced COO slice, {threads} thread(s); the whole-forward '
+                                   f'rate is this rate (extrapolated, BASELINE.md §3)'})
+        torch.set_num_threads(all_threads)
+        rec['cpu_baseline'] = dict(recs[0], one_thread=recs[1])
+        y1 = torch.empty_like(e0d)
+        propagate.spmm(prop.csr, e0d, y=y1)
+        got = y1[:r].cpu().numpy()
+        # the hottest row (the ~1 M-entry item row, split into ~1000 chunks) against a float64 dot over its entries
+        hot = int(np.argmax(graph.degrees()))
+        a0, a1 = int(graph.rowptr[hot]), int(graph.rowptr[hot + 1])
+        ref_hot = (graph.vals[a0:a1].astype(np.float64)[:, None] * e0.numpy()[graph.colidx[a0:a1]].astype(np.float64)).sum(axis=0)
+        got_hot = y1[hot].cpu().numpy().astype(np.float64)
+        v = {'what': f'layer 1 of the timed path: rows 0..{r} vs torch.sparse.mm on the CPU; hottest row {hot} ({a1 - a0} entries) '
+                     f'vs a float64 dot',
+             'normwise_max_err': float(np.abs(got.astype(np.float64) - ref.numpy()).max() / np.abs(ref.numpy()).max()),
+             'hottest_row_normwise_err': float(np.abs(got_hot - ref_hot).max() / np.abs(ref_hot).max()), 'bar': 1e-4}
+        v['ok'] = bool(v['normwise_max_err'] <= 1e-4 and v['hottest_row_normwise_err'] <= 1e-4)
+        rec['verify'] = v
+    return rec
+
+
+def _model_dataset(u, i, n_u, n_i, graph, text=None):
+    import pandas as pd
+    from textgcn_amd.graph import train_mask_csr
+    rp, items = train_mask_csr(u, i, n_u)
+    ds = types.SimpleNamespace(
+        n_users=n_u, n_items=n_i, graph=graph, norm_matrix=None, mask_rowptr=rp, mask_items=items,
+        true_test_lil=[[0]], train_user_dict=None, test_df=pd.DataFrame({'user_id': [0], 'asin': [0]}),
+        user_mapping=pd.DataFrame({'remap_id': [0], 'org_id': ['u0']}), item_mapping=pd.DataFrame({'remap_id': [0], 'org_id': ['i0']}),
+        all_items=range(n_i))
+    if text:
+        ds.__dict__.update(text)
+    return ds
+
+
+def _timed(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    b.synchronize()
+    return a.elapsed_time(b) / reps / 1e3
+
+
+def records_c3_c5(dev, want_c5=True, cpu=True):
+    """BASELINE configs 3 and 5 through the MODEL CLASSES (LightGCN / LTRLinear), as a user of main.py would run them:
+    c3 = U=180k I=60k nnz=1.6M d=128 K=4 + full-catalogue scoring of every user; c5 = ltr_linear on the frozen c3 tables
+    + four text tables of width 384 (folded K = 960 GEMM)."""
+    from textgcn_amd import synth
+    from textgcn_amd.graph import NormGraph
+    from textgcn_amd.ltr import LTRLinear
+    from textgcn_amd.model import LightGCN
+    n_u, n_i, nnz, d, K = synth.CONFIGS['c3']
+    t0 = time.time()
+    u, i = synth.interactions(n_u, n_i, nnz, seed=0)
+    g = NormGraph.from_pairs(u, i, n_u, n_i)
+    build_s = time.time() - t0
+    p = types.SimpleNamespace(k=[20, 40], emb_size=d, n_layers=K, device=dev, load=None, batch_size=2048, quiet=True)
+    ds = _model_dataset(u, i, n_u, n_i, g)
+    m = LightGCN(p, ds)
+    with torch.no_grad():    # weights from the CPU generator so that the CPU port sees the same table
+        e0 = synth.embeddings(g.n, d, seed=0)
+        m.embedding_user.weight.copy_(e0[:n_u])
+        m.embedding_item.weight.copy_(e0[n_u:])
+    users = np.arange(n_u)
+
+    def fwd():
+        with torch.no_grad():
+            return m.representation
+    reps = 10
+    t_fwd = _timed(fwd, reps)
+    t_all = _timed(lambda: m.predict_tensors(users), 2)    # representation + fused scoring of every user
+    t_score = t_all - t_fwd
+    pairs = n_u * n_i
+    traffic, tsrc = load_traffic('c3')
+    c3 = {'metric': f'propagated edges/sec ({K}-layer SpMM, d={d})', 'value': K * g.nnz / t_fwd, 'unit': 'edges/s', 'n_gpus': 1,
+          'steps': reps, 'ms_per_step': t_fwd * 1e3, 'dtype': 'f32', 'data': 'synthetic',
+          'config': {'workload': f'c3: U={n_u} I={n_i} nnz={nnz} d={d} K={K}', 'nnz_A': g.nnz, 'graph_build_s': round(build_s, 1),
+                     'through': 'textgcn_amd.LightGCN.representation / predict_tensors'},
+          'roofline': spmm_roofline(g.nnz, g.n, g.n, d, K, t_fwd, 1, traffic, tsrc, dev),
+          'scoring': {'metric': 'scored user-item pairs/sec (full catalogue: every user x every item, mask + top-40 fused)',
+                      'value': pairs / t_score, 'unit': 'pairs/s', 'ms_total': t_score * 1e3,
+                      'roofline': {'bound': 'mfma', 'achieved': round(2.0 * d * pairs / t_score / 1e12, 2), 'peak': MFMA_F32_PEAK_TF,
+                                   'unit': 'TFLOP/s', 'frac': round(2.0 * d * pairs / t_score / 1e12 / MFMA_F32_PEAK_TF, 4),
+                                   'traffic': None}}}
+    t1 = time.time()
+    m.predict(users[:16384], with_scores=True)
+    c3['scoring']['predict_wall_s_16384_users_incl_tolist'] = round(time.time() - t1, 3)
+    ue, ie = fwd()
+    if cpu:
+        c3['cpu_baseline'], c3['verify'] = cpu_baseline_propagation(g, e0, K, gpu_out=torch.cat([ue, ie]), budget_s=4.0)
+        bt = batch_masks(users[:2048], ds.mask_rowptr, ds.mask_items, dev)
+        from textgcn_amd import scoring
+        gpu_topk = scoring.score_topk(ue.contiguous(), ie.contiguous(), 40, user_ids=bt[0], mask_rowptr=bt[1], mask_items=bt[2],
+                                      round4=True)
+        c3['scoring']['cpu_baseline'], c3['scoring']['verify'] = cpu_baseline_scoring(
+            ue[:2048].cpu(), ie.cpu(), bt[1].cpu().numpy(), bt[2].cpu().numpy(), 40, gpu_topk=gpu_topk, budget_s=4.0)
+    out = {'c3': c3}
+    if not want_c5:
+        return out
+    gen = torch.Generator().manual_seed(5)
+    t = 384
+    text = {'items_as_desc': torch.randn((n_i, t), generator=gen), 'items_as_avg_reviews': torch.randn((n_i, t), generator=gen),
+            'users_as_avg_reviews': torch.randn((n_u, t), generator=gen), 'users_as_avg_desc': torch.randn((n_u, t), generator=gen)}
+    p5 = types.SimpleNamespace(k=[20, 40], emb_size=d, n_layers=K, device=dev, load=None, load_base=None, freeze=True,
+                               batch_size=2048, quiet=True, ltr_layers=[])
+    ltr = LTRLinear(p5, _model_dataset(u, i, n_u, n_i, g, text))
+    with torch.no_grad():
+        ltr.embedding_user.weight.copy_(e0[:n_u])
+        ltr.embedding_item.weight.copy_(e0[n_u:])
+    t_ltr = _timed(lambda: ltr.predict_tensors(users), 1) - t_fwd
+    kf = d + 2 * t
+    c5 = {'metric': 'scored user-item pairs/sec (ltr_linear: 5 text/embedding features + Linear(5,1) folded into one K=960 GEMM, '
+                    'mask + top-40, full catalogue)', 'value': pairs / t_ltr, 'unit': 'pairs/s', 'n_gpus': 1, 'ms_total': t_ltr * 1e3,
+          'dtype': 'f32', 'data': 'synthetic',
+          'config': {'workload': f'c5: c3 graph + 4 text tables x {t}, ltr_linear', 'folded_K': int(ltr._k()),
+                     'through': 'textgcn_amd.LTRLinear.predict_tensors'},
+          'roofline': {'bound': 'mfma', 'achieved': round(2.0 * kf * pairs / t_ltr / 1e12, 2), 'peak': MFMA_F32_PEAK_TF,
+                       'unit': 'TFLOP/s', 'frac': round(2.0 * kf * pairs / t_ltr / 1e12 / MFMA_F32_PEAK_TF, 4), 'traffic': None,
+                       'algorithmic_flops': 2.0 * kf * pairs}}
+    if cpu:
+        from oracle import torch_port
+        nb = 256
+        w = ltr.layers[0].weight.detach().cpu()
+        bias = ltr.layers[0].bias.detach().cpu()
+        uc, ic = ue[:nb].cpu(), ie.cpu()
+        args = (uc, text['users_as_avg_reviews'][:nb], text['users_as_avg_desc'][:nb], ic, text['items_as_avg_reviews'],
+                text['items_as_desc'], w, bias)
+        t0 = time.perf_counter()
+        n = 0
+        while True:
+            ref = torch_port.ltr_score_batchwise(*args)
+            n += 1
+            el = time.perf_counter() - t0
+            if el > 6.0 or n >= 3:
+                break
+        c5['cpu_baseline'] = {'value': n * nb * n_i / el, 'unit': 'pairs/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+                              'sample': f'{n} batch(es) of {nb} users x {n_i} items: the reference\'s 5 matmuls + cat + nn.Linear(5,1) '
+                                        f'(ltr_models.py:131-146,200-204) in {el:.1f} s'}
+        ids = torch.arange(nb, device=dev)
+        with torch.no_grad():
+            got = ltr.score_batchwise(ue[ids], ie, ids).cpu().numpy()
+        err = float(np.abs(got.astype(np.float64) - ref.numpy()).max() / np.abs(ref.numpy()).max())
+        c5['verify'] = {'what': f'[{nb}, {n_i}] ltr scores of the HIP path vs the CPU port', 'normwise_max_err': err, 'bar': 1e-4,
+                        'ok': bool(err <= 1e-4)}
+    out['c5'] = c5
+    return out
 
 
 def main():
@@ -101,7 +452,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--workload', default=None, help='c2 (default), c3, c4, small, tiny')
+    ap.add_argument('--workload', default=None, help='c2 (default at N = 1), c4 (default at N > 1), c3, small, tiny')
     ap.add_argument('--exact', action='store_true', help='no long-row split: bit-identical to the CPU reference')
     ap.add_argument('--split-threshold', type=int, default=None)
     ap.add_argument('--no-segment', action='store_true', help='keep every row on the one-wave-per-row kernel (no XCD-affine segments)')
@@ -109,6 +460,10 @@ def main():
     ap.add_argument('--score-batch-size', type=int, default=2048, help='users per scoring call (reference batch_size = 2048)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-scoring', action='store_true')
+    ap.add_argument('--sub', default=None, help="comma list of sub-records at N = 1: c4,c3,c5 (default: all for the default "
+                                                "workload, none otherwise); 'none' to skip")
+    ap.add_argument('--chunks', type=int, default=None, help='row chunks per block for the pipelined all-gather (N > 1)')
+    ap.add_argument('--balance', default='nnz', choices=['nnz', 'rows'])
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -133,16 +488,13 @@ def main():
         else:
             dist.init_process_group(backend='nccl', device_id=dev)
 
-    from textgcn_amd import propagate, scoring, synth
+    from textgcn_amd import propagate, synth
     from textgcn_amd.graph import NormGraph, train_mask_csr
 
-    wl = args.workload or 'c2'
+    default_wl = args.workload is None
+    wl = args.workload or ('c2' if world == 1 else 'c4')
     n_u, n_i, nnz, d, K = synth.CONFIGS[wl]
-    if world > 1 and args.workload is None:
-        n_u, n_i, nnz = n_u * world, n_i * world, nnz * world   # weak scaling: config 2 per GPU
-        wl_name = f'c2 x {world} (weak): U={n_u} I={n_i} nnz={nnz} d={d} K={K}'
-    else:
-        wl_name = f'{wl}: U={n_u} I={n_i} nnz={nnz} d={d} K={K}'
+    wl_name = f'{wl}: U={n_u} I={n_i} nnz={nnz} d={d} K={K}'
     t0 = time.time()
     u, i = synth.interactions(n_u, n_i, nnz, seed=0)
     graph = NormGraph.from_pairs(u, i, n_u, n_i)
@@ -160,7 +512,8 @@ def main():
         n_rows_local, n_src, nnz_local = graph.n, graph.n, graph.nnz
     else:
         from textgcn_amd.dist import ShardedPropagator
-        sp = ShardedPropagator(graph, rank, world, dev, split_threshold=thr)
+        chunks = args.chunks or (4 if graph.nnz >= 50_000_000 else 1)
+        sp = ShardedPropagator(graph, rank, world, dev, split_threshold=thr, balance=args.balance, chunks=chunks)
         eu, ei = sp.local_e0(e0)
 
         def step():
@@ -181,55 +534,47 @@ def main():
         torch.distributed.all_reduce(sm, op=torch.distributed.ReduceOp.SUM)
         return mx.tolist(), sm.tolist()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t_wall0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        step()
-    ev1.record()
-    barrier()
-    t_wall = time.perf_counter() - t_wall0
-    t_dev = ev0.elapsed_time(ev1) / 1e3
+    t_dev, t_wall = time_steps(step, args.steps, args.warmup, barrier)
     t = max(t_wall, t_dev)
     if world > 1:
         t = reduce_max_sum([t])[0][0]
-    edges = args.steps * K * graph.nnz
-    value = edges / t
+    value = args.steps * K * graph.nnz / t
     seg_note = 'none'
     if world == 1 and not args.exact and prop.csr.segment_blocks and any(prop.csr.segment_blocks):
         seg_note = (f'user rows x{prop.csr.segment_blocks[0]}, item rows x{prop.csr.segment_blocks[1]} column blocks, '
                     f'{prop.csr.segment_tile}-entry tiles (tgcn_spmm_segmented_f32)')
 
     # ---------------- roofline of the dominant kernel (one SpMM layer launch on this rank)
-    layer_bytes = [algorithmic_bytes_per_layer(nnz_local, n_rows_local, n_src, d, k, K, False) for k in range(1, K + 1)]
-    mean_layer_s = t_dev / (args.steps * K)
-    achieved = float(np.mean(layer_bytes)) / mean_layer_s / 1e9
-    # the PMC pass was taken on the default path of the workload (profiles/hbm_traffic.json)
-    traffic = load_traffic(wl if world == 1 and not args.exact and not args.no_segment else None)
-    roofline = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
-                # measured memory-side bytes (PMC pass, profiles/) over the live launch time: what the fabric moves
-                'traffic_GBs': round(traffic / mean_layer_s / 1e9, 1) if traffic else None,
-                'kernel': 'one SpMM layer (k_spmm_seg + k_spmm_seg_reduce, or k_spmm_wave + k_spmm_long_reduce)',
-                'algorithmic_bytes_per_launch': int(np.mean(layer_bytes)), 'launch_us': round(mean_layer_s * 1e6, 2),
-                'gather_model_GBs': round((nnz_local * (8 + 4 * d) + n_rows_local * d * 4) / mean_layer_s / 1e9, 1)}
+    if world == 1 and not args.exact and not args.no_segment:
+        traffic, tsrc = load_traffic(wl)    # the PMC pass was taken on the default path of the workload
+    else:
+        traffic, tsrc = None, 'no PMC pass for this mode'
+    roofline = spmm_roofline(nnz_local, n_rows_local, n_src, d, K, t_dev, args.steps, traffic, tsrc, dev, gather=(world == 1))
+    if world > 1:
+        roofline['note'] = 'per rank: this rank\'s row blocks, launch time includes waiting for the all-gathered tables'
 
     result = {
         'metric': 'propagated edges/sec (3-layer SpMM, d=64)', 'value': value, 'unit': 'edges/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': t / args.steps * 1e3, 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'scaling': 'strong' if world > 1 else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': wl_name, 'nnz_A': graph.nnz, 'n_nodes': graph.n, 'max_degree': int(graph.degrees().max()),
                    'mode': 'exact (one fmaf chain per row)' if args.exact else f'one-wave-per-row kernel: rows > {thr} entries split in chunks',
+                   'parity_of_this_mode': 'bit-identical to the reference CPU forward' if args.exact else
+                   'rows cut by the long-row split / XCD segments are summed piecewise: normwise <= 1e-5 vs the exact chain '
+                   '(tests), bar 1e-4; all other rows bit-identical',
                    'xcd_segments': seg_note,
-                   'sharding': 'none' if world == 1 else f'row-sharded x{world}, RCCL all-gather per layer (users ∥ item half-step)',
+                   'sharding': 'none' if world == 1 else (f'row-sharded x{world} ({args.balance}-balanced blocks padded to the largest, '
+                                                          f'{sp.lay_u.chunks} row chunk(s) per block), RCCL all-gather per chunk and layer '
+                                                          f'(users || item half-step)'),
                    'graph_build_s': round(build_s, 1)},
         'roofline': roofline,
     }
+    if world > 1:
+        result['config']['scaling_note'] = 'fixed total work (BASELINE config 4) split over the ranks; N = 1 of the same workload: ' \
+                                           'bench.py --gpus 1 reports it as the sub-record c4_1gpu'
 
     # ---------------- second metric: scored pairs/s (rank 0's users; every rank scores its own users)
+    first_topk = batches = None
     if not args.no_scoring:
         k_top = 40
         bsz = args.score_batch_size
@@ -237,46 +582,16 @@ def main():
             ue, ie = out[:n_u], out[n_u:]
             users_all = np.arange(n_u)
         else:
-            ue, ie = sp.forward(eu, ei, K, exact=args.exact)
-            ie = ie[:n_i]
-            users_all = np.arange(*sp._user_range(rank))
+            ue, itab = sp.forward(eu, ei, K, exact=args.exact)
+            ie = sp.items_in_order(itab)
+            users_all = np.arange(*sp.user_range())
         mrp, mit = train_mask_csr(u, i, n_u)
         n_batches = min(args.score_batches, max(1, len(users_all) // bsz))
-        batches = []
-        for bidx in range(n_batches):
-            bu_ = users_all[bidx * bsz:(bidx + 1) * bsz]
-            rp = (mrp[bu_ + 1] - mrp[bu_])
-            rowptr = np.zeros(len(bu_) + 1, dtype=np.int32)
-            np.cumsum(rp, out=rowptr[1:])
-            items = np.concatenate([mit[mrp[x]:mrp[x + 1]] for x in bu_])
-            ids = torch.from_numpy(bu_ - users_all[0]).to(dev)
-            batches.append((ids, torch.from_numpy(rowptr).to(dev), torch.from_numpy(items).to(dev)))
+        batches = [batch_masks(users_all[b * bsz:(b + 1) * bsz], mrp, mit, dev, ids_origin=users_all[0]) for b in range(n_batches)]
         ue = ue.contiguous()
         ie = ie.contiguous()
-
-        # consecutive calls are independent: issued round-robin on three HIP streams with their own scratch buffers, as
-        # LightGCN.predict does, so one call's small selection kernels run under the next call's GEMM
-        main = torch.cuda.current_stream(dev)
-        side = [torch.cuda.Stream(dev) for _ in range(3)]
-
-        def score_all(bts):   # the predict step of base_model.py:254-263, fused (tgcn_score_topk_f32)
-            for st in side:
-                st.wait_stream(main)
-            keep = []
-            for j, (ids, rp, it) in enumerate(bts):
-                with torch.cuda.stream(side[j % 3]):
-                    keep.append(scoring.score_topk(ue, ie, k_top, user_ids=ids, mask_rowptr=rp, mask_items=it, round4=True,
-                                                   slot=j % 3))
-            for st in side:
-                main.wait_stream(st)
-            return keep
-        score_all(batches[:3])
-        barrier()
-        ev0.record()
-        score_all(batches)
-        ev1.record()
-        barrier()
-        ts = ev0.elapsed_time(ev1) / 1e3
+        ts, keep = scoring_region(ue, ie, batches, k_top, dev, barrier)
+        first_topk = keep[0]
         pairs = sum(int(bt[0].numel()) for bt in batches) * n_i
         if world > 1:
             mx, sm = reduce_max_sum([ts, float(pairs)])
@@ -292,36 +607,42 @@ def main():
         big = min(16384, len(users_all))
         if world == 1 and big > bsz:
             n_big = max(1, min(4, len(users_all) // big))
-            bb = []
-            for bidx in range(n_big):
-                bu_ = users_all[bidx * big:(bidx + 1) * big]
-                rowptr = np.zeros(len(bu_) + 1, dtype=np.int32)
-                np.cumsum(mrp[bu_ + 1] - mrp[bu_], out=rowptr[1:])
-                items = mit[mrp[bu_[0]]:mrp[bu_[-1] + 1]]
-                bb.append((torch.from_numpy(bu_).to(dev), torch.from_numpy(rowptr).to(dev), torch.from_numpy(np.ascontiguousarray(items)).to(dev)))
-            score_all(bb[:1])
-            barrier()
-            ev0.record()
-            score_all(bb)
-            ev1.record()
-            barrier()
-            tb = ev0.elapsed_time(ev1) / 1e3
+            bb = [batch_masks(users_all[b * big:(b + 1) * big], mrp, mit, dev) for b in range(n_big)]
+            tb, _ = scoring_region(ue, ie, bb, k_top, dev, barrier)
             pb = sum(int(bt[0].numel()) for bt in bb) * n_i
             result['scoring']['large_batch'] = {'users_per_call': big, 'value': pb / tb, 'unit': 'pairs/s',
                                                 'ms_per_call': tb / n_big * 1e3,
                                                 'mfma_frac': round(2.0 * d * pb / tb / 1e12 / MFMA_F32_PEAK_TF, 4)}
 
-    # ---------------- CPU baseline beside it (rank 0, N = 1 only)
+    # ---------------- CPU baseline beside it + verification of the timed outputs (rank 0, N = 1 only; outside the timed regions)
     if world == 1 and not args.no_cpu_baseline:
-        result['cpu_baseline'] = cpu_baseline_propagation(graph, e0, K)
+        if graph.nnz <= 30_000_000:
+            result['cpu_baseline'], result['verify'] = cpu_baseline_propagation(graph, e0, K, gpu_out=out)
         if not args.no_scoring:
             bt = batches[0]
-            result['scoring']['cpu_baseline'] = cpu_baseline_scoring(
-                ue[bt[0]].cpu(), ie.cpu(), bt[1].cpu().numpy(), bt[2].cpu().numpy(), 40)
+            result['scoring']['cpu_baseline'], result['scoring']['verify'] = cpu_baseline_scoring(
+                ue[bt[0]].cpu(), ie.cpu(), bt[1].cpu().numpy(), bt[2].cpu().numpy(), 40, gpu_topk=first_topk)
+
+    # ---------------- the other single-GPU configurations (N = 1)
+    if world == 1:
+        sub = args.sub if args.sub is not None else ('c4,c3,c5' if default_wl else 'none')
+        sub = [] if sub == 'none' else [s.strip() for s in sub.split(',') if s.strip()]
+        del prop, e0d, out
+        if not args.no_scoring:
+            del ue, ie
+        torch.cuda.empty_cache()
+        cpu = not args.no_cpu_baseline
+        if 'c3' in sub or 'c5' in sub:
+            result.update(records_c3_c5(dev, want_c5='c5' in sub, cpu=cpu))
+            torch.cuda.empty_cache()
+        if 'c4' in sub:
+            del graph, e0, u, i
+            result['c4_1gpu'] = record_c4_one_gpu(dev, cpu=cpu)
 
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
+        sp.close()
         torch.distributed.destroy_process_group()
 
 

@@ -73,4 +73,4 @@ def test_bench_two_rank_rehearsal(cuda, tmp_path):
     lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1
     r = json.loads(lines[0])
-    assert r['n_gpus'] == 2 and r['value'] > 0 and r['scaling'] == 'weak' and 'roofline' in r and r['scoring']['value'] > 0
+    assert r['n_gpus'] == 2 and r['value'] > 0 and r['scaling'] == 'strong' and 'roofline' in r and r['scoring']['value'] > 0

@@ -22,8 +22,7 @@
 //      construction, and it makes the whole path exact.
 // Every score is the k-ordered fp32 fmaf chain (MFMA 32x32x2 f32 or v_fma), so all four steps agree bit for
 // bit with the dense path and with the CPU restatement used in the parity tests.
-#include <cstdlib>
-
+#include <mutex>
 #include <type_traits>
 
 #include "tgcn_internal.h"
@@ -52,7 +51,6 @@ struct FilterArgs {
     int S;              // item splits (gridDim.y)
     int items_per_split;  // multiple of kStage
     int cap2;
-    int debug_mode;  // 0 in production (TGCN_DEBUG_FILTER_MODE, dev only)
 };
 
 // stage `rows` rows x 4*DQ columns (zero-filled past n_rows / d) with the (k0,k2,k1,k3) group swizzle
@@ -184,14 +182,6 @@ __global__ __launch_bounds__(256) void k_score_filter(const FilterArgs a)
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[g & 1][q].y, b2.y, acc1, 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-        }
-        if (a.debug_mode == 1) {  // dev only: time the GEMM loop without the filter epilogue
-            asm volatile("" ::"v"(acc0), "v"(acc1));
-            if (more)
-                store_rows<DQ>(smem + (buf ^ 1) * kStage * ROW, nxt);
-            __syncthreads();
-            buf ^= 1;
-            continue;
         }
         // C/D layout: col (user) = lane & 31, row (item) = (reg & 3) + 8 * (reg >> 2) + 4 * h.  ~0.6 % of the scores
         // pass.  Rows past i_end exist only in the last stage of the last split: handled by a uniform branch so that
@@ -657,9 +647,7 @@ Plan make_plan(int B, int I, int d, int k)
     // with 16 384 users per call, 8 / 12 / 24 / 32 / 48 splits -> 0.60 / 0.58 / 0.65 / 0.66 / 0.65 T pairs/s (many short
     // workgroups keep the chip evenly loaded); 2048 users: 32 and 48 splits tie.
     const int max_S = max(1, I / (8 * kStage));   // at least 8 stages per split
-    int S = min(32, max_S);
-    if (const char *dbg = getenv("TGCN_DEBUG_SPLITS"))  // dev only
-        S = max(1, min(atoi(dbg), max_S));
+    const int S = min(32, max_S);
     p.items_per_split = (((I + S - 1) / S + kStage - 1) / kStage) * kStage;
     p.S = (I + p.items_per_split - 1) / p.items_per_split;
     p.cap2 = max(32, 1024 / (2 * p.S));
@@ -677,6 +665,30 @@ Plan make_plan(int B, int I, int d, int k)
     p.off_flags = o, o += align256((size_t)(B + 1) * sizeof(int));
     p.total = o;
     return p;
+}
+
+// > 64 KB of dynamic LDS needs hipFuncAttributeMaxDynamicSharedMemorySize on the kernel, per device (the attribute lives
+// with the device's copy of the code object).  Set once per device, thread-safe, and the outcome is kept: a device where
+// it failed reports the error on every call instead of faulting in the launch.
+int brute_lds_opt_in()
+{
+    constexpr int kMaxDevices = 64;
+    static std::once_flag once[kMaxDevices];
+    static hipError_t result[kMaxDevices];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+        set_error("hipGetDevice failed or device index >= %d", kMaxDevices);
+        return TGCN_ERR_HIP;
+    }
+    std::call_once(once[dev], [dev] {
+        result[dev] = hipFuncSetAttribute(reinterpret_cast<const void *>(k_brute_part), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          160 << 10);
+    });
+    if (result[dev] != hipSuccess) {
+        set_error("hipFuncSetAttribute(k_brute_part, MaxDynamicSharedMemorySize) on device %d: %s", dev, hipGetErrorString(result[dev]));
+        return TGCN_ERR_HIP;
+    }
+    return TGCN_OK;
 }
 
 template <int DQ>
@@ -748,11 +760,7 @@ extern "C" int tgcn_score_topk_f32(const float *U, const int64_t *user_ids, int3
     fa.logs = reinterpret_cast<float2 *>(ws + p.off_logs);
     fa.counts = reinterpret_cast<int *>(ws + p.off_counts);
     fa.B = B, fa.I = I, fa.d = d, fa.S = p.S, fa.items_per_split = p.items_per_split, fa.cap2 = p.cap2;
-    {
-        const char *dbg = getenv("TGCN_DEBUG_FILTER_MODE");
-        fa.debug_mode = dbg ? atoi(dbg) : 0;
-    }
-    if (d <= 128 && fa.debug_mode == 0) {
+    if (d <= 128) {
         const dim3 grid((B + kUsersPerWG - 1) / kUsersPerWG, p.S);
         if (d == 64)
             hipLaunchKernelGGL((k_score_filter16<true>), grid, dim3(256), 0, s, fa);
@@ -782,11 +790,8 @@ extern "C" int tgcn_score_topk_f32(const float *U, const int64_t *user_ids, int3
     size_t brute_lds = ((size_t)((d + 63) & ~63) + 2 * kBruteWaves * kWave) * sizeof(float);
     if (d <= kBruteTileMaxD && (d & 3) == 0)
         brute_lds += (size_t)kBruteWaves * kWave * (d + 1) * sizeof(float);
-    static bool lds_opt_in = false;   // > 64 KB of dynamic LDS needs the attribute once per process
-    if (!lds_opt_in) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_brute_part), hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
-        lds_opt_in = true;
-    }
+    if ((rc = brute_lds_opt_in()) != TGCN_OK)
+        return rc;
     hipLaunchKernelGGL(k_brute_part, dim3(kBruteSplits, 8), dim3(kBruteWaves * 64), brute_lds, s, ba);
     if ((rc = check_launch("k_brute_part")) != TGCN_OK)
         return rc;
