@@ -84,6 +84,17 @@ int tgcn_spmm_csr_f32(const int32_t *rowptr, const int32_t *colidx, const float 
                       float *acc_out, float acc_div, const tgcn_split_plan_t *plan, const int32_t *row_order,
                       uint32_t flags, tgcn_stream_t stream);
 
+/* The same product with the most referenced source rows resident in LDS (d in {64, 128, 256}).  `colidx_enc` is colidx with
+ * the entries that point at hot row hot_rows[s] replaced by ~s (negative); every other argument as in tgcn_spmm_csr_f32.
+ * A persistent 1024-thread workgroup copies X[hot_rows[0..n_hot)] into LDS (n_hot * d * 4 <= 160 KB; <= 80 KB keeps two
+ * workgroups per CU) and walks rows grid-stride with `workgroups` workgroups; entries with a negative id read LDS instead
+ * of L1/L2.  Same fmaf chain per row: bit-identical to tgcn_spmm_csr_f32.  Pays when gathers are skewed (Zipf-popular
+ * items: config 2's 320 hottest item rows carry 36 % of the user rows' entries).  Built by textgcn_amd.graph.hot_plan_arrays. */
+int tgcn_spmm_csr_hot_f32(const int32_t *rowptr, const int32_t *colidx_enc, const float *vals, int64_t n_rows,
+                          const float *X, int64_t n_src_rows, int32_t d, float *Y, const float *acc_in,
+                          float *acc_out, float acc_div, const tgcn_split_plan_t *plan, const int32_t *row_order,
+                          const int32_t *hot_rows, int32_t n_hot, int32_t workgroups, tgcn_stream_t stream);
+
 /* XCD-affine segmented form of the same product (d in {64, 128, 256}).  The plan holds its own copy of the
  * entries of the segmented rows, as streams: stream x of a row range keeps the entries whose column falls in column
  * blocks x, x+8, ... ordered by (block, row, column).  A row's run inside one block is a segment; streams are cut

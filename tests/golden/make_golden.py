@@ -473,6 +473,65 @@ def g7_ltr_pop(work, data, ckpt, ds, rng):
     save('g7_ltr_pop.npz', **out)
 
 
+# --------------------------------------------------------------------------- G8: training loss + gradient
+def g8_loss(work, data):
+    """get_loss (base_model.py:181-210) on a fixed batch: BPR + L2 values and dE0 by the reference's autograd, without
+    dropout and with the captured dropout mask of seed 123 (the G3 mask), for 1 and 2 negatives per row."""
+    from collections import defaultdict
+    out = {}
+    rng = np.random.default_rng(8)
+    for name, p, n_neg in (('nodrop', 0.0, 1), ('drop', 0.4, 1), ('drop2', 0.4, 2)):
+        args = run_args(['--model', 'lgcn', '--no_train', '-k', '5', '--dropout', str(p), '--neg_samples', str(n_neg)], data, work)
+        ds = TextGCN.BaseDataset(args)
+        model = TextGCN.BaseModel(args, ds)
+        set_weights(model, exact_embedding(ds.n_users, 64, 11), exact_embedding(ds.n_items, 64, 12))
+        b = 96
+        users = rng.integers(0, ds.n_users, b)
+        pos = np.array([rng.choice(ds.train_user_dict[u]) for u in users])
+        negs = rng.integers(0, ds.n_items, (b, n_neg))
+        batch = torch.from_numpy(np.concatenate([users[:, None], pos[:, None], negs], axis=1).astype(np.int64))
+        model._loss_values = defaultdict(float)
+        model.train()
+        model.training = True
+        model.zero_grad()
+        torch.manual_seed(123)          # the dropout draw of this step (base_model.py:82)
+        loss = model.get_loss(batch)
+        loss.backward()
+        out[f'{name}_batch'] = batch.numpy()
+        out[f'{name}_p'] = np.float64(p)
+        out[f'{name}_loss'] = np.float64(loss.item())
+        out[f'{name}_bpr'] = np.float64(float(model._loss_values['bpr']))
+        out[f'{name}_reg'] = np.float64(float(model._loss_values['reg']))
+        out[f'{name}_grad_user'] = model.embedding_user.weight.grad.numpy().copy()
+        out[f'{name}_grad_item'] = model.embedding_item.weight.grad.numpy().copy()
+        out[f'{name}_reg_lambda'] = np.float64(args.reg_lambda)
+    save('g8_loss.npz', **out)
+
+
+# --------------------------------------------------------------------------- G9: metrics with duplicate test rows
+def g9_metrics(work):
+    """utils.calculate_metrics (utils.py:36-63) on hand-made lists: duplicate items inside y_true (duplicate test rows),
+    lists of different lengths, users without a hit."""
+    import pandas as pd
+    from TextGCN.utils import calculate_metrics
+    rng = np.random.default_rng(9)
+    n, kmax, n_items = 40, 10, 60
+    y_true, y_pred = [], []
+    for u in range(n):
+        t = rng.integers(0, n_items, rng.integers(1, 9)).tolist()
+        if u % 3 == 0:
+            t = t + t[:2]                      # duplicate test rows of this user
+        y_true.append(t)
+        y_pred.append(rng.permutation(n_items)[:kmax].tolist())
+    ks = [1, 5, 10]
+    df = pd.DataFrame.from_dict({'user_id': list(range(n)), 'y_true': y_true, 'y_pred': y_pred, 'scores': [[0.0] * kmax] * n})
+    res = calculate_metrics(df, ['recall', 'precision', 'hit', 'ndcg', 'f1'], ks)
+    ptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum([len(t) for t in y_true], out=ptr[1:])
+    save('g9_metrics.npz', true_ptr=ptr, true_items=np.concatenate(y_true).astype(np.int64), y_pred=np.asarray(y_pred, dtype=np.int64),
+         ks=np.asarray(ks, dtype=np.int64), **{f'metric_{m}': np.asarray(v, dtype=np.float64) for m, v in res.items()})
+
+
 def main():
     work = tempfile.mkdtemp(prefix='tgcn_golden_')
     try:
@@ -481,7 +540,12 @@ def main():
         data60 = g2_synth(work, write=ONLY is None)
         if ONLY is None:
             g3_dropout(work, data60)
-        g4_ltr(work, data60)
+        if ONLY in (None, 'g4', 'g7'):
+            g4_ltr(work, data60)
+        if ONLY in (None, 'g8'):
+            g8_loss(work, data60)
+        if ONLY in (None, 'g9'):
+            g9_metrics(work)
         if ONLY is None:
             g5_medium(work)
             g6_builder(work)

@@ -80,8 +80,9 @@ def test_c4_row_partition_arithmetic(c4):
     for b, lo, hi in ((ub, 0, gr.n_users), (ib, gr.n_users, gr.n)):
         assert b[0] == lo and b[-1] == hi and np.all(np.diff(b) > 0)
         per = np.diff(gr.rowptr[b]).astype(np.float64)
-        # cuts fall between rows: a rank's share is off by at most one row, and the hottest item row is 8 % of a share
-        assert per.max() / per.mean() < 1.0 + 1.05 * gr.degrees()[lo:hi].max() / per.mean()
+        # cuts fall between rows (the weight is entries + 1 per row, so that empty rows spread too): a rank's share is off by
+        # at most one row's entries plus its row-count difference; the hottest item row alone is 8 % of a share
+        assert per.max() / per.mean() < 1.0 + max(1e-3, 1.1 * gr.degrees()[lo:hi].max() / per.mean())
         assert per.max() < 2 ** 31
     lay = BlockLayout(ib - gr.n_users, chunks=4)
     rows = lay.table_rows(np.arange(gr.n_items))

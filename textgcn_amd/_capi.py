@@ -33,6 +33,9 @@ _SIGNATURES = {
     'tgcn_last_error': (c_char_p, []),
     'tgcn_spmm_csr_f32': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p,
                                          c_void_p, c_void_p, c_float, POINTER(SplitPlanStruct), c_void_p, c_uint32, c_void_p]),
+    'tgcn_spmm_csr_hot_f32': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p,
+                                             c_void_p, c_void_p, c_float, POINTER(SplitPlanStruct), c_void_p, c_void_p, c_int32,
+                                             c_int32, c_void_p]),
     'tgcn_spmm_segmented_f32': (ctypes.c_int, [POINTER(SegmentPlanStruct), c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
                                                c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_float, c_uint32, c_void_p]),
     'tgcn_score_dense_f32': (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_int64,

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _capi
-from .graph import NormGraph, segment_plan_arrays, split_plan_arrays
+from .graph import NormGraph, hot_plan_arrays, segment_plan_arrays, split_plan_arrays
 
 DEFAULT_SPLIT_THRESHOLD = 1024
 L2_SHARE_BYTES = 3 << 20        # of an XCD's 4 MB L2 that a gathered table can count on next to the streaming traffic
@@ -42,7 +42,7 @@ class DeviceCSR:
     """CSR of a contiguous block of rows of A on one device (+ optional long-row split plan and segment plan)."""
 
     def __init__(self, rowptr, colidx, vals, n_src_rows, device, split_threshold=None, block_specs=None,
-                 order_rows=True, segment=None):
+                 order_rows=True, segment=None, hot_bytes=0):
         """block_specs: optional list of (row_begin, row_end, col_lo, col_hi) covering all rows once -- row ranges
         whose entries fall in one column range (user rows x item columns, item rows x user columns).
         segment: None (off), 'auto' (segment_blocks_auto per spec) or a list of block counts per spec: enables the
@@ -90,6 +90,22 @@ class DeviceCSR:
         self.segment_tile = SEGMENT_TILE_ENTRIES
         self.segment_min_row_len = SEGMENT_MIN_ROW_LEN
         self._segment_plans = {}
+        # hot source rows in LDS (tgcn_spmm_csr_hot_f32): LDS bytes per workgroup to spend on them, 0 = off
+        self.hot_bytes = int(hot_bytes)
+        self._hot_host_cols = np.asarray(colidx) if hot_bytes else None
+        self._hot_plans = {}
+
+    def hot_plan(self, d):
+        """(hot_rows, colidx_enc device tensors, share of hot entries, workgroups) for width d, or None."""
+        if not self.hot_bytes or d not in (64, 128, 256) or self.nnz == 0:
+            return None
+        if d not in self._hot_plans:
+            hot, enc, share = hot_plan_arrays(self._hot_host_cols, self.n_src_rows, self.hot_bytes // (4 * d))
+            cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+            wgs = cus * max(1, (160 << 10) // max(self.hot_bytes, 1))
+            self._hot_plans[d] = None if len(hot) == 0 else (torch.from_numpy(hot).to(self.device),
+                                                             torch.from_numpy(enc).to(self.device), share, int(wgs))
+        return self._hot_plans[d]
 
     @property
     def n_chunks(self):
@@ -207,6 +223,14 @@ def spmm(csr, x, y=None, acc_in=None, acc_out=None, acc_div=1.0, exact=False, va
         _capi.check(rc, 'tgcn_spmm_segmented_f32')
         return y if y is not None else acc_out
     plan = None if exact else csr.plan(d)
+    hot = csr.hot_plan(d) if variant == _capi.SPMM_AUTO else None
+    if hot is not None:
+        rc = _capi.lib().tgcn_spmm_csr_hot_f32(
+            _capi.ptr(csr.rowptr), _capi.ptr(hot[1]), _capi.ptr(vals), csr.n_rows, _capi.ptr(x), csr.n_src_rows, d,
+            _capi.ptr(y), _capi.ptr(acc_in), _capi.ptr(acc_out), float(acc_div), plan, _capi.ptr(csr.row_order),
+            _capi.ptr(hot[0]), hot[0].numel(), hot[3], _capi.current_stream(dev))
+        _capi.check(rc, 'tgcn_spmm_csr_hot_f32')
+        return y if y is not None else acc_out
     rc = _capi.lib().tgcn_spmm_csr_f32(
         _capi.ptr(csr.rowptr), _capi.ptr(csr.colidx), _capi.ptr(vals), csr.n_rows, _capi.ptr(x), csr.n_src_rows, d,
         _capi.ptr(y), _capi.ptr(acc_in), _capi.ptr(acc_out), float(acc_div), plan, _capi.ptr(csr.row_order),
