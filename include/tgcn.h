@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TGCN_ABI_VERSION 3
+#define TGCN_ABI_VERSION 4
 
 #define TGCN_OK 0
 #define TGCN_ERR_ARG (-1)         /* bad argument (null pointer, size, unsupported d/k ...) */
@@ -83,17 +83,6 @@ int tgcn_spmm_csr_f32(const int32_t *rowptr, const int32_t *colidx, const float 
                       const float *X, int64_t n_src_rows, int32_t d, float *Y, const float *acc_in,
                       float *acc_out, float acc_div, const tgcn_split_plan_t *plan, const int32_t *row_order,
                       uint32_t flags, tgcn_stream_t stream);
-
-/* The same product with the most referenced source rows resident in LDS (d in {64, 128, 256}).  `colidx_enc` is colidx with
- * the entries that point at hot row hot_rows[s] replaced by ~s (negative); every other argument as in tgcn_spmm_csr_f32.
- * A persistent 1024-thread workgroup copies X[hot_rows[0..n_hot)] into LDS (n_hot * d * 4 <= 160 KB; <= 80 KB keeps two
- * workgroups per CU) and walks rows grid-stride with `workgroups` workgroups; entries with a negative id read LDS instead
- * of L1/L2.  Same fmaf chain per row: bit-identical to tgcn_spmm_csr_f32.  Pays when gathers are skewed (Zipf-popular
- * items: config 2's 320 hottest item rows carry 36 % of the user rows' entries).  Built by textgcn_amd.graph.hot_plan_arrays. */
-int tgcn_spmm_csr_hot_f32(const int32_t *rowptr, const int32_t *colidx_enc, const float *vals, int64_t n_rows,
-                          const float *X, int64_t n_src_rows, int32_t d, float *Y, const float *acc_in,
-                          float *acc_out, float acc_div, const tgcn_split_plan_t *plan, const int32_t *row_order,
-                          const int32_t *hot_rows, int32_t n_hot, int32_t workgroups, tgcn_stream_t stream);
 
 /* XCD-affine segmented form of the same product (d in {64, 128, 256}).  The plan holds its own copy of the
  * entries of the segmented rows, as streams: stream x of a row range keeps the entries whose column falls in column
@@ -195,6 +184,38 @@ int tgcn_score_pairwise_f32(const float *U, const int64_t *users, const float *V
 int tgcn_score_candidates_f32(const float *U, const int64_t *users, const float *It, const int64_t *cand, int32_t B,
                               int32_t m, int32_t d, const int32_t *mask_rowptr, const int32_t *mask_items, float *out,
                               tgcn_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * N1: the pieces of one BPR training step around the propagation.
+ *
+ * Edge dropout as value masking on the fixed CSR.
+ *   replaces BaseModel._dropout_norm_matrix                        TextGCN/base_model.py:77-86
+ *   (torch.rand(nnz) on the CPU, index_select, new COO + coalesce -- a device sort -- and an H->D copy per mini-batch)
+ * Entry e is kept iff u_e < keep_prob (= 1 - p, base_model.py:82-83); a kept entry's value is scaled_vals[e] (the stored
+ * value / (1 - p), :84), a dropped one 0.  u_e = rand_u[e] when rand_u != NULL (e.g. the reference's own CPU stream, for
+ * parity), else a Philox4x32-10 draw keyed by (seed, e).  Because the draw is a function of e alone, the same launch also
+ * writes the transposed values vals_t[e] = vals[perm[e]] (the backward's matrix; the dropped matrix is not symmetric) and
+ * the copies in a segment plan's stream order, ent_val[s] = vals[ent_src[s]], ent_val_t[s] = vals_t[ent_src[s]], without a
+ * second pass.  Optional outputs may be NULL. */
+int tgcn_dropout_values_f32(const float *scaled_vals, const float *rand_u, uint64_t seed, float keep_prob,
+                            const int32_t *perm, const int32_t *ent_src, int64_t nnz, int64_t n_stream, float *vals,
+                            float *vals_t, float *ent_val, float *ent_val_t, tgcn_stream_t stream);
+
+/* BPR pairs: terms[j, r] = selu(s(u_r, n_jr) - s(u_r, p_r)), s = row dot product of the PROPAGATED tables, for b batch rows
+ * (users[r], pos[r], negs[j, r]), j < m; loss = sum(terms) / (b m).
+ *   replaces the gathers + score_pairwise + F.selu + mean          TextGCN/base_model.py:186-198 (:171)
+ *   and their autograd backward: d loss / d users_emb, d items_emb are ADDED (float atomics) into grad_users / grad_items,
+ *   which the caller zero-fills; every gradient is multiplied by grad_scale (the layer mean's 1 / (K + 1), folded in). */
+int tgcn_bpr_pairs_f32(const float *users_emb, const float *items_emb, const int64_t *users, const int64_t *pos,
+                       const int64_t *negs, int32_t b, int32_t m, int32_t d, float grad_scale, float *terms,
+                       float *grad_users, float *grad_items, tgcn_stream_t stream);
+
+/* L2 term: terms[r] = |E_u[users[r]]|^2 + |E_i[pos[r]]|^2 + sum_j |E_i[negs[j, r]]|^2 on the layer-0 tables; the
+ * reference's reg_loss is lambda / (2 b) * sum(terms)               TextGCN/base_model.py:200-210
+ * With gradient tables given, coef * row is ADDED to the row of every occurrence (coef = lambda / b). */
+int tgcn_reg_rows_f32(const float *e_users, const float *e_items, const int64_t *users, const int64_t *pos,
+                      const int64_t *negs, int32_t b, int32_t m, int32_t d, float coef, float *terms,
+                      float *grad_users, float *grad_items, tgcn_stream_t stream);
 
 /* (e) Multi-GPU exchange step of the row partition: all-gather of the freshly propagated row blocks.
  * The reference is single-device -- there is no call to replace (grep nccl|torch.distributed|all_gather in TextGCN/ -> 0

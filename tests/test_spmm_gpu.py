@@ -323,40 +323,3 @@ def test_segmented_xcd_affine_kernel(cuda, oracle, d, blocks, tile, min_len):
     full = prop.forward(e0d, 3, segmented=True).cpu().numpy()
     exact = prop.forward(e0d, 3, exact=True).cpu().numpy()
     assert normwise(full, exact) <= 5e-6
-
-
-@pytest.mark.parametrize('d', [64, 128, 256])
-@pytest.mark.parametrize('hot_bytes', [16 << 10, 80 << 10, 160 << 10])
-def test_hot_rows_in_lds_bit_exact(cuda, oracle, d, hot_bytes):
-    """tgcn_spmm_csr_hot_f32: the most referenced source rows are read from LDS (flat loads through the shared aperture),
-    every other entry from the table; order and values of each row's chain are unchanged -> bit-identical to the oracle,
-    with and without the long-row split, with the layer-sum epilogue, and with per-call values (dropout)."""
-    from textgcn_amd.propagate import DeviceCSR, spmm
-    gr = _random_graph(3000, 700, 60000, seed=11, zipf=1.0)
-    rng = np.random.default_rng(2)
-    x = rng.standard_normal((gr.n, d)).astype(np.float32)
-    idx, val = gr.to_coo()
-    ref = oracle.spmm_coo(idx, val, x)
-    xd = torch.from_numpy(x).to(cuda)
-    csr = DeviceCSR(gr.rowptr, gr.colidx, gr.vals, gr.n, cuda, hot_bytes=hot_bytes)
-    hp = csr.hot_plan(d)
-    assert hp is not None and 0 < hp[0].numel() <= hot_bytes // (4 * d) and 0 < hp[2] < 1
-    y = torch.empty((gr.n, d), device=cuda)
-    spmm(csr, xd, y=y, exact=True)
-    assert np.array_equal(bits(y.cpu().numpy()), bits(ref))
-    # fused layer-sum epilogue
-    acc = torch.empty_like(y)
-    spmm(csr, xd, y=None, acc_in=xd, acc_out=acc, acc_div=4.0, exact=True)
-    want = ((x + ref) / np.float32(4.0)).astype(np.float32)
-    assert np.array_equal(bits(acc.cpu().numpy()), bits(want))
-    # long-row split on the same launch: split rows to rounding, the rest exact, and identical to the plain kernel's split
-    csr_s = DeviceCSR(gr.rowptr, gr.colidx, gr.vals, gr.n, cuda, split_threshold=64, hot_bytes=hot_bytes)
-    plain = DeviceCSR(gr.rowptr, gr.colidx, gr.vals, gr.n, cuda, split_threshold=64)
-    y2, y3 = torch.empty_like(y), torch.empty_like(y)
-    spmm(csr_s, xd, y=y2)
-    spmm(plain, xd, y=y3)
-    assert torch.equal(y2, y3)
-    # per-call values on the same structure
-    v2 = torch.from_numpy((gr.vals * rng.integers(0, 2, gr.nnz)).astype(np.float32)).to(cuda)
-    spmm(csr, xd, y=y2, vals=v2, exact=True)
-    assert np.array_equal(bits(y2.cpu().numpy()), bits(oracle.spmm_coo(idx, v2.cpu().numpy(), x)))

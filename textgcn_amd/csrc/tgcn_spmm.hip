@@ -30,7 +30,6 @@
 //                             write piece sums; the other waves of the launch own one direct row each.
 //   k_spmm_seg_reduce<VEC>    adds a row's piece sums in column order and applies the epilogue.
 #include <climits>
-#include <mutex>
 
 #include "tgcn_internal.h"
 
@@ -253,93 +252,6 @@ __global__ __launch_bounds__(256) void k_spmm_group(const SpmmArgs a)
     if (valid && !is_long) {
         const float y[4] = {acc.x, acc.y, acc.z, acc.w};
         epilogue<4>(a, (size_t)row * D + gl * 4, y);
-    }
-}
-
-// ---- hot source rows resident in LDS (tgcn_spmm_csr_hot_f32) ------------------------------------------------------------
-// Item popularity is Zipf-like: a few hundred rows of the gathered table take a large share of all gathers (config 2: the
-// 320 most referenced rows are 36 % of the user rows' entries).  A persistent 1024-thread workgroup copies those rows of X
-// into LDS once (80 KB at d = 64, two workgroups per CU, 32 waves) and its 16 waves then walk rows / chunks grid-stride;
-// an entry whose (encoded) column id is negative reads its source row from LDS instead of through L1/L2.  The encoded
-// id is wave-uniform (v_readlane), so the choice is a scalar branch; order and values of the fmaf chain are unchanged, so
-// every output bit is the one k_spmm_wave produces.
-template <int VEC, int UNROLL>
-__device__ __forceinline__ void accumulate_wave_hot(const SpmmArgs &a, const float *hot, int beg, int end, int lane,
-                                                    float (&acc)[VEC])
-{
-    // `hot` is a GENERIC pointer into LDS: selecting between it and the global table per entry (a scalar select on the
-    // wave-uniform id) leaves one flat_load per entry, which the hardware routes to LDS or to L1/L2 by aperture -- no
-    // branch.  (With an if/else around a ds_read and a global_load hipcc waits for vmcnt(0) and lgkmcnt(0) in front of every
-    // load of the batch, i.e. one row gather in flight instead of 16.)
-    constexpr unsigned kRowShift = VEC == 1 ? 8 : VEC == 2 ? 9 : 10;  // log2(4 * d)
-    // both bases as wave-uniform 64-bit integers (the LDS one through the shared aperture): the per-entry choice is then an
-    // s_cselect_b64, not a branch around two address computations
-    const unsigned long long xg = reinterpret_cast<unsigned long long>(a.X);
-    const unsigned long long hg0 = reinterpret_cast<unsigned long long>(hot);
-    const unsigned long long hg = ((unsigned long long)(unsigned)uniform((int)(hg0 >> 32)) << 32) | (unsigned)uniform((int)hg0);
-    const unsigned lane_off = lane * VEC * 4;
-    for (int base = beg; base < end; base += kWave) {
-        const int n = min(kWave, end - base);  // uniform
-        int c = 0;
-        float v = 0.0f;
-        if (lane < n) {
-            c = a.colidx[base + lane];   // encoded: >= 0 column id, < 0: ~slot of a hot row
-            v = a.vals[base + lane];
-        }
-        for (int j = 0; j < n; j += UNROLL) {
-            float x[UNROLL][VEC];
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                const int cj = __builtin_amdgcn_readlane(c, min(j + u, n - 1));
-                const unsigned long long row = cj < 0 ? hg + ((unsigned long long)(unsigned)(~cj) << kRowShift)
-                                                      : xg + ((unsigned long long)(unsigned)cj << kRowShift);
-                load_vec<VEC>(reinterpret_cast<const float *>(row + lane_off), x[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                if (j + u < n) {
-                    const float vj = readlane_f(v, j + u);
-#pragma unroll
-                    for (int k = 0; k < VEC; ++k)
-                        acc[k] = fmaf(vj, x[u][k], acc[k]);
-                }
-            }
-        }
-    }
-}
-
-template <int VEC, int UNROLL>
-__global__ __launch_bounds__(1024) void k_spmm_hot(const SpmmArgs a, const int *__restrict__ hot_rows, int n_hot)
-{
-    extern __shared__ __attribute__((aligned(16))) float hot[];   // [n_hot][64 * VEC]
-    constexpr int d = 64 * VEC;
-    const int lane = lane_id();
-    const int w = uniform(threadIdx.x >> 6);
-    for (int r = w; r < n_hot; r += 16) {
-        float t[VEC];
-        load_vec<VEC>(a.X + (size_t)hot_rows[r] * d + lane * VEC, t);
-        store_vec<VEC>(hot + (size_t)r * d + lane * VEC, t);
-    }
-    __syncthreads();
-    const int n_work = a.n_chunks + a.row_waves;
-    const int stride = gridDim.x * 16;
-    for (int item = blockIdx.x * 16 + w; item < n_work; item += stride) {
-        float acc[VEC];
-#pragma unroll
-        for (int k = 0; k < VEC; ++k)
-            acc[k] = 0.0f;
-        if (item < a.n_chunks) {
-            accumulate_wave_hot<VEC, UNROLL>(a, hot, a.chunk_beg[item], a.chunk_end[item], lane, acc);
-            store_vec<VEC>(a.ws + (size_t)item * d + lane * VEC, acc);
-            continue;
-        }
-        const int row = a.row_order ? a.row_order[item - a.n_chunks] : item - a.n_chunks;
-        const int beg = a.rowptr[row];
-        const int end = a.rowptr[row + 1];
-        if (end - beg > a.threshold)
-            continue;  // long row: chunk items + k_spmm_long_reduce
-        accumulate_wave_hot<VEC, UNROLL>(a, hot, beg, end, lane, acc);
-        epilogue<VEC>(a, (size_t)row * d + lane * VEC, acc);
     }
 }
 
@@ -628,39 +540,6 @@ int launch_group(const SpmmArgs &a, int unroll, int grid, hipStream_t s)
     return check_launch("k_spmm_group");
 }
 
-// > 64 KB of dynamic LDS: opt in once per device and kernel instantiation (thread-safe; the outcome is kept)
-template <int VEC, int UNROLL>
-int hot_lds_opt_in()
-{
-    constexpr int kMaxDevices = 64;
-    static std::once_flag once[kMaxDevices];
-    static hipError_t result[kMaxDevices];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) {
-        set_error("hipGetDevice failed or device index >= %d", kMaxDevices);
-        return TGCN_ERR_HIP;
-    }
-    std::call_once(once[dev], [dev] {
-        result[dev] = hipFuncSetAttribute(reinterpret_cast<const void *>(k_spmm_hot<VEC, UNROLL>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 << 10);
-    });
-    if (result[dev] != hipSuccess) {
-        set_error("hipFuncSetAttribute(k_spmm_hot, MaxDynamicSharedMemorySize) on device %d: %s", dev, hipGetErrorString(result[dev]));
-        return TGCN_ERR_HIP;
-    }
-    return TGCN_OK;
-}
-
-template <int VEC, int UNROLL>
-int launch_hot(const SpmmArgs &a, const int *hot_rows, int n_hot, int grid, hipStream_t s)
-{
-    const int rc = hot_lds_opt_in<VEC, UNROLL>();
-    if (rc != TGCN_OK)
-        return rc;
-    hipLaunchKernelGGL((k_spmm_hot<VEC, UNROLL>), dim3(grid), dim3(1024), (size_t)n_hot * 64 * VEC * sizeof(float), s, a, hot_rows, n_hot);
-    return check_launch("k_spmm_hot");
-}
-
 }  // namespace
 }  // namespace tgcn
 
@@ -727,55 +606,6 @@ extern "C" int tgcn_spmm_csr_f32(const int32_t *rowptr, const int32_t *colidx, c
         const int grid = (a.row_waves + a.n_chunks + 3) / 4;
         rc = d == 64 ? launch_group<16>(a, unroll, grid, s) : d == 128 ? launch_group<32>(a, unroll, grid, s) : launch_group<64>(a, unroll, grid, s);
     }
-    if (rc != TGCN_OK)
-        return rc;
-    if (split) {
-        const int grid = (plan->n_long + 3) / 4;
-        if (d == 64)
-            hipLaunchKernelGGL((k_spmm_long_reduce<1>), dim3(grid), dim3(256), 0, s, a, plan->long_rows, plan->long_chunk_ptr, plan->n_long);
-        else if (d == 128)
-            hipLaunchKernelGGL((k_spmm_long_reduce<2>), dim3(grid), dim3(256), 0, s, a, plan->long_rows, plan->long_chunk_ptr, plan->n_long);
-        else
-            hipLaunchKernelGGL((k_spmm_long_reduce<4>), dim3(grid), dim3(256), 0, s, a, plan->long_rows, plan->long_chunk_ptr, plan->n_long);
-        rc = check_launch("k_spmm_long_reduce");
-    }
-    return rc;
-}
-
-extern "C" int tgcn_spmm_csr_hot_f32(const int32_t *rowptr, const int32_t *colidx_enc, const float *vals, int64_t n_rows,
-                                     const float *X, int64_t n_src_rows, int32_t d, float *Y, const float *acc_in,
-                                     float *acc_out, float acc_div, const tgcn_split_plan_t *plan, const int32_t *row_order,
-                                     const int32_t *hot_rows, int32_t n_hot, int32_t workgroups, tgcn_stream_t stream)
-{
-    TGCN_REQUIRE(n_rows >= 0 && n_rows < INT_MAX - 256, "n_rows out of range");
-    TGCN_REQUIRE(d == 64 || d == 128 || d == 256, "the hot-row kernel supports d in {64, 128, 256}");
-    TGCN_REQUIRE(n_src_rows >= 0 && n_src_rows < INT_MAX, "n_src_rows out of range");
-    if (n_rows == 0)
-        return TGCN_OK;
-    TGCN_REQUIRE(rowptr && X && colidx_enc && vals, "rowptr / colidx_enc / vals / X is NULL");
-    TGCN_REQUIRE(Y || acc_out, "both Y and acc_out are NULL: nothing to compute");
-    TGCN_REQUIRE(!acc_out || acc_in, "acc_out given without acc_in");
-    TGCN_REQUIRE(acc_div != 0.0f, "acc_div must be non-zero");
-    TGCN_REQUIRE(n_hot >= 0 && (n_hot == 0 || hot_rows), "hot_rows is NULL");
-    TGCN_REQUIRE((int64_t)n_hot * d * 4 <= (160 << 10), "hot rows exceed the 160 KB of LDS");
-    TGCN_REQUIRE(workgroups > 0 && workgroups <= 65535, "workgroups out of range");
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    SpmmArgs a;
-    a.rowptr = rowptr, a.colidx = colidx_enc, a.vals = vals, a.X = X, a.Y = Y;
-    a.acc_in = acc_in, a.acc_out = acc_out, a.acc_div = acc_div;
-    a.n_rows = (int)n_rows, a.d = d, a.row_waves = (int)n_rows, a.row_order = row_order;
-    a.threshold = INT_MAX, a.n_chunks = 0, a.chunk_beg = nullptr, a.chunk_end = nullptr, a.ws = nullptr;
-    const bool split = plan && plan->n_chunks > 0;
-    if (split) {
-        TGCN_REQUIRE(plan->threshold > 0, "plan->threshold must be positive");
-        TGCN_REQUIRE(plan->chunk_beg && plan->chunk_end && plan->long_rows && plan->long_chunk_ptr && plan->workspace,
-                     "split plan has NULL members");
-        TGCN_REQUIRE(plan->n_long > 0, "split plan has chunks but no long rows");
-        a.threshold = plan->threshold, a.n_chunks = plan->n_chunks;
-        a.chunk_beg = plan->chunk_beg, a.chunk_end = plan->chunk_end, a.ws = plan->workspace;
-    }
-    int rc = d == 64 ? launch_hot<1, 16>(a, hot_rows, n_hot, workgroups, s)
-                     : d == 128 ? launch_hot<2, 16>(a, hot_rows, n_hot, workgroups, s) : launch_hot<4, 8>(a, hot_rows, n_hot, workgroups, s);
     if (rc != TGCN_OK)
         return rc;
     if (split) {

@@ -159,24 +159,6 @@ def split_plan_arrays(rowptr, threshold):
     }
 
 
-def hot_plan_arrays(colidx, n_src_rows, n_hot):
-    """Host arrays for tgcn_spmm_csr_hot_f32 (include/tgcn.h): the `n_hot` most referenced source rows, by descending
-    reference count, and colidx with the entries that point at hot row s replaced by ~s.  Returns (hot_rows int32 [n_hot'],
-    colidx_enc int32 [nnz], share of the entries that are hot); n_hot' <= n_hot (rows never referenced are not taken)."""
-    colidx = np.asarray(colidx)
-    counts = np.bincount(colidx, minlength=int(n_src_rows))
-    n_hot = int(min(n_hot, np.count_nonzero(counts)))
-    if n_hot <= 0 or len(colidx) == 0:
-        return np.zeros(0, dtype=np.int32), colidx.astype(np.int32), 0.0
-    top = np.argpartition(-counts, n_hot - 1)[:n_hot]
-    hot = top[np.lexsort((top, -counts[top]))]            # by (count desc, id asc): deterministic
-    slot_of = np.full(int(n_src_rows), -1, dtype=np.int64)
-    slot_of[hot] = np.arange(n_hot)
-    s = slot_of[colidx]
-    enc = np.where(s >= 0, ~s, colidx.astype(np.int64)).astype(np.int32)
-    return hot.astype(np.int32), enc, float(counts[hot].sum() / len(colidx))
-
-
 def segment_plan_arrays(rowptr, colidx, vals, phases, tile_entries=256, n_classes=8, min_row_len=0):
     """Host arrays of a tgcn_segment_plan_t (XCD-affine column blocking, include/tgcn.h).
 

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _capi
-from .graph import NormGraph, hot_plan_arrays, segment_plan_arrays, split_plan_arrays
+from .graph import NormGraph, segment_plan_arrays, split_plan_arrays
 
 DEFAULT_SPLIT_THRESHOLD = 1024
 L2_SHARE_BYTES = 3 << 20        # of an XCD's 4 MB L2 that a gathered table can count on next to the streaming traffic
@@ -38,11 +38,22 @@ def segment_blocks_auto(rowptr, colidx, spec, d):
     return SEGMENT_CLASSES if hot < 0.5 * (b - a) else 0
 
 
+class EdgeValues:
+    """A per-call replacement of a DeviceCSR's stored values on the same structure (edge dropout, transposed values),
+    together with its copy in the segment plan's stream order.  The copy is made once -- by tgcn_dropout_values_f32 in the
+    same launch that draws the mask, or by the first spmm call that needs it -- and then reused by every layer of the
+    forward / backward that passes the same object."""
+
+    def __init__(self, vals, seg_vals=None):
+        self.vals = vals
+        self.seg_vals = seg_vals
+
+
 class DeviceCSR:
     """CSR of a contiguous block of rows of A on one device (+ optional long-row split plan and segment plan)."""
 
     def __init__(self, rowptr, colidx, vals, n_src_rows, device, split_threshold=None, block_specs=None,
-                 order_rows=True, segment=None, hot_bytes=0):
+                 order_rows=True, segment=None):
         """block_specs: optional list of (row_begin, row_end, col_lo, col_hi) covering all rows once -- row ranges
         whose entries fall in one column range (user rows x item columns, item rows x user columns).
         segment: None (off), 'auto' (segment_blocks_auto per spec) or a list of block counts per spec: enables the
@@ -90,22 +101,6 @@ class DeviceCSR:
         self.segment_tile = SEGMENT_TILE_ENTRIES
         self.segment_min_row_len = SEGMENT_MIN_ROW_LEN
         self._segment_plans = {}
-        # hot source rows in LDS (tgcn_spmm_csr_hot_f32): LDS bytes per workgroup to spend on them, 0 = off
-        self.hot_bytes = int(hot_bytes)
-        self._hot_host_cols = np.asarray(colidx) if hot_bytes else None
-        self._hot_plans = {}
-
-    def hot_plan(self, d):
-        """(hot_rows, colidx_enc device tensors, share of hot entries, workgroups) for width d, or None."""
-        if not self.hot_bytes or d not in (64, 128, 256) or self.nnz == 0:
-            return None
-        if d not in self._hot_plans:
-            hot, enc, share = hot_plan_arrays(self._hot_host_cols, self.n_src_rows, self.hot_bytes // (4 * d))
-            cus = torch.cuda.get_device_properties(self.device).multi_processor_count
-            wgs = cus * max(1, (160 << 10) // max(self.hot_bytes, 1))
-            self._hot_plans[d] = None if len(hot) == 0 else (torch.from_numpy(hot).to(self.device),
-                                                             torch.from_numpy(enc).to(self.device), share, int(wgs))
-        return self._hot_plans[d]
 
     @property
     def n_chunks(self):
@@ -134,9 +129,15 @@ class DeviceCSR:
         self.segment_min_row_len = int(min_row_len)
         self._segment_plans = {}
 
+    def segment_ent_src(self, d):
+        """int32 device tensor: the CSR entry each slot of the segment plan's streams copies (None: no plan at width d)."""
+        if self.segment_plan(d) is None:
+            return None
+        return self._segment_plans[d][0][2]['ent_src']
+
     def segment_plan(self, d, vals=None):
         """ctypes pointer to a tgcn_segment_plan_t for width d, or None when no row range is segmented at this width.
-        vals: per-call replacement of the stored values (same layout as self.vals)."""
+        vals: per-call replacement of the stored values (a tensor laid out as self.vals, or an EdgeValues)."""
         if self._segment_mode is None or not self._block_specs or d not in (64, 128, 256) or self.nnz == 0:
             return None
         if d not in self._segment_plans:
@@ -165,9 +166,15 @@ class DeviceCSR:
             return None
         if vals is None:
             return ctypes.byref(entry[0])
-        # per-call values (edge dropout, transposed values): the plan's streams get their own gathered copy
+        # per-call values (edge dropout, transposed values): the plan's streams get their own gathered copy, made once per
+        # EdgeValues object (K forward + K backward launches share it)
         st, dv = entry[0], entry[2]
-        ev = vals.index_select(0, dv['ent_src'])
+        if isinstance(vals, EdgeValues):
+            if vals.seg_vals is None:
+                vals.seg_vals = vals.vals.index_select(0, dv['ent_src'])
+            ev = vals.seg_vals
+        else:
+            ev = vals.index_select(0, dv['ent_src'])
         tmp = _capi.SegmentPlanStruct.from_buffer_copy(st)
         tmp.ent_val = ev.data_ptr()
         self._segment_keep = (tmp, ev)     # alive until the next call on this CSR (the launch is stream-ordered after the gather)
@@ -205,6 +212,9 @@ def spmm(csr, x, y=None, acc_in=None, acc_out=None, acc_div=1.0, exact=False, va
     if y is not None and y.data_ptr() == x.data_ptr():
         raise ValueError('y must not alias x')
     own_vals = vals is None
+    bundle = vals if isinstance(vals, EdgeValues) else None
+    if bundle is not None:
+        vals = bundle.vals
     if vals is None:
         vals = csr.vals
     elif vals.dtype != torch.float32 or vals.numel() != max(csr.nnz, 1) or vals.device != dev or not vals.is_contiguous():
@@ -212,7 +222,7 @@ def spmm(csr, x, y=None, acc_in=None, acc_out=None, acc_div=1.0, exact=False, va
     # the segment plan carries its own copy of the stored values: a per-call `vals` (dropout) is gathered into it
     seg = None
     if segmented is not False and not exact and variant == _capi.SPMM_AUTO:
-        seg = csr.segment_plan(d, None if own_vals else vals)
+        seg = csr.segment_plan(d, None if own_vals else (bundle or vals))
     if segmented is True and seg is None:
         raise ValueError('segmented=True but this CSR has no segment plan for the call (width, exact or variant)')
     if seg is not None:
@@ -223,14 +233,6 @@ def spmm(csr, x, y=None, acc_in=None, acc_out=None, acc_div=1.0, exact=False, va
         _capi.check(rc, 'tgcn_spmm_segmented_f32')
         return y if y is not None else acc_out
     plan = None if exact else csr.plan(d)
-    hot = csr.hot_plan(d) if variant == _capi.SPMM_AUTO else None
-    if hot is not None:
-        rc = _capi.lib().tgcn_spmm_csr_hot_f32(
-            _capi.ptr(csr.rowptr), _capi.ptr(hot[1]), _capi.ptr(vals), csr.n_rows, _capi.ptr(x), csr.n_src_rows, d,
-            _capi.ptr(y), _capi.ptr(acc_in), _capi.ptr(acc_out), float(acc_div), plan, _capi.ptr(csr.row_order),
-            _capi.ptr(hot[0]), hot[0].numel(), hot[3], _capi.current_stream(dev))
-        _capi.check(rc, 'tgcn_spmm_csr_hot_f32')
-        return y if y is not None else acc_out
     rc = _capi.lib().tgcn_spmm_csr_f32(
         _capi.ptr(csr.rowptr), _capi.ptr(csr.colidx), _capi.ptr(vals), csr.n_rows, _capi.ptr(x), csr.n_src_rows, d,
         _capi.ptr(y), _capi.ptr(acc_in), _capi.ptr(acc_out), float(acc_div), plan, _capi.ptr(csr.row_order),

@@ -20,8 +20,6 @@ def main():
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--segment-items', type=int, default=0, help='also time the item rows alone through the segmented kernel with this many column blocks')
     ap.add_argument('--tile', type=int, default=1024)
-    ap.add_argument('--hot', type=int, nargs='+', default=[0], help='LDS bytes per workgroup for hot source rows (0 = plain kernel)')
-    ap.add_argument('--parts', nargs='+', default=None)
     args = ap.parse_args()
     from textgcn_amd import propagate, synth
     from textgcn_amd.graph import NormGraph
@@ -33,17 +31,14 @@ def main():
     parts = {'users': (0, n_u), 'items': (n_u, g.n), 'all': (0, g.n)}
     if args.segment_items:
         parts = {'items': (n_u, g.n), 'items-segmented': (n_u, g.n)}
-    if args.parts:
-        parts = {k: v for k, v in parts.items() if k in args.parts}
-    ref = {}
-    for name, (r0, r1), hot_bytes in [(n, p, hb) for n, p in parts.items() for hb in args.hot]:
+    for name, (r0, r1) in parts.items():
         rp, ci, va = g.row_block(r0, r1)
         if name == 'items-segmented':
             csr = propagate.DeviceCSR(rp, ci, va, g.n, dev, split_threshold=propagate.DEFAULT_SPLIT_THRESHOLD,
                                       block_specs=[(0, r1 - r0, 0, n_u)], segment=[args.segment_items])
             csr.segment_tile = args.tile
         else:
-            csr = propagate.DeviceCSR(rp, ci, va, g.n, dev, split_threshold=propagate.DEFAULT_SPLIT_THRESHOLD, hot_bytes=hot_bytes)
+            csr = propagate.DeviceCSR(rp, ci, va, g.n, dev, split_threshold=propagate.DEFAULT_SPLIT_THRESHOLD)
         y = torch.empty((r1 - r0, d), device=dev)
         acc = torch.empty((r1 - r0, d), device=dev)
         e0 = x[r0:r1].contiguous()
@@ -64,12 +59,7 @@ def main():
                 b.record()
                 torch.cuda.synchronize()
                 us = a.elapsed_time(b) / args.steps * 1e3
-                hp = csr.hot_plan(d)
-                if name not in ref:
-                    ref[name] = y.clone()
                 print(json.dumps({'rows': name, 'n_rows': r1 - r0, 'entries': csr.nnz, 'unroll': un, 'epilogue': mode,
-                                  'hot_bytes': hot_bytes, 'hot_rows': 0 if hp is None else hp[0].numel(),
-                                  'hot_share': 0 if hp is None else round(hp[2], 3), 'bit_identical_to_first': bool(torch.equal(ref[name], y)),
                                   'us': round(us, 1), 'gather_TBs': round(csr.nnz * d * 4 / us / 1e6, 2)}), flush=True)
 
 
