@@ -386,6 +386,17 @@ def records_c3_c5(dev, want_c5=True, cpu=True):
     t1 = time.time()
     m.predict(users[:16384], with_scores=True)
     c3['scoring']['predict_wall_s_16384_users_incl_tolist'] = round(time.time() - t1, 3)
+    # evaluate() for EVERY user (one random relevant item each): representation + full-catalogue top-k + metrics on the device
+    from textgcn_amd.metrics import true_lists_csr
+    m.test_users = users
+    m._true_csr_host = true_lists_csr([[int(x)] for x in np.random.default_rng(3).integers(0, n_i, n_u)])
+    m._true_dev = None
+    m.evaluate()
+    torch.cuda.synchronize()
+    t1 = time.time()
+    m.evaluate()
+    torch.cuda.synchronize()
+    c3['scoring']['evaluate_wall_s_all_users'] = round(time.time() - t1, 4)
     ue, ie = fwd()
     if cpu:
         c3['cpu_baseline'], c3['verify'] = cpu_baseline_propagation(g, e0, K, gpu_out=torch.cat([ue, ie]), budget_s=4.0)

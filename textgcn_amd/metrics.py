@@ -56,18 +56,18 @@ def true_lists_csr(y_true):
     return ptr, items
 
 
-def ranking_metrics_device(true_ptr, true_items, pred, ks):
+def ranking_metrics_device(true_ptr, true_items, pred, ks, n_items):
     """The same numbers from device tensors: true_ptr int64 [n+1] / true_items int64 (CSR of the relevant lists, rows in
     the order of `pred`'s rows), pred int64 [n, kmax] ranked DISTINCT item ids per row (what a top-k returns; with distinct
-    predictions the reference's intersect1d / isin pair reduces to a membership test per position).  float64 on the
-    device; only the 5 x len(ks) means cross to the host."""
+    predictions the reference's intersect1d / isin pair reduces to a membership test per position); n_items bounds the ids.
+    float64 on the device; only the 5 x len(ks) means cross to the host."""
     import torch
     n, kmax = pred.shape
     if true_ptr.numel() != n + 1:
         raise ValueError('true_ptr and pred differ in the number of users')
     dev = pred.device
     n_true = (true_ptr[1:] - true_ptr[:-1]).to(torch.float64)
-    span = int(max(int(true_items.max()) if true_items.numel() else 0, int(pred.max()) if pred.numel() else 0)) + 1
+    span = int(n_items)
     rows_true = torch.repeat_interleave(torch.arange(n, device=dev), true_ptr[1:] - true_ptr[:-1], output_size=int(true_items.numel()))
     keys_true = torch.sort(rows_true * span + true_items)[0]
     keys_pred = torch.arange(n, device=dev)[:, None] * span + pred

@@ -24,11 +24,11 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from . import scoring
+from . import _capi, scoring
 from ._capi import resolve_device
 from .graph import NormGraph, train_mask_csr
-from .metrics import METRICS, early_stop, ranking_metrics
-from .propagate import DEFAULT_SPLIT_THRESHOLD, DeviceCSR, Propagator, spmm
+from .metrics import METRICS, early_stop, ranking_metrics_device, true_lists_csr
+from .propagate import DEFAULT_SPLIT_THRESHOLD, DeviceCSR, EdgeValues, Propagator, spmm
 
 
 class _Propagate(torch.autograd.Function):
@@ -46,26 +46,82 @@ class _Propagate(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad):
         model = ctx.model
-        eng = model._engine
-        K = model.n_layers
         grad = grad.contiguous()
-        if K == 0:
+        if model.n_layers == 0:
             return grad, None, None, None
-        ping, pong, _ = eng.buffers(grad.shape[1])
+        g0 = grad if model._single else grad / float(model.n_layers + 1)
+        return _backward_propagate(model, g0, ctx.vals_t), None, None, None
+
+
+def _backward_propagate(model, grad, vals_t):
+    """dE0 for d(out) = grad: sum_k (A^T)^k grad / (K + 1) in Horner form (g <- A^T g + g0), or (A^T)^K grad for --single.
+    `grad` must already carry the 1 / (K + 1) of the layer mean when scaled=True."""
+    eng = model._engine
+    K = model.n_layers
+    if K == 0:
+        return grad
+    ping, pong, _ = eng.buffers(grad.shape[1])
+    x = grad
+    for k in range(K):
+        y = torch.empty_like(grad) if k == K - 1 else (ping if k % 2 == 0 else pong)
         if model._single:
-            x = grad
-            for k in range(K):
-                y = torch.empty_like(grad) if k == K - 1 else (ping if k % 2 == 0 else pong)
-                spmm(eng.csr, x, y=y, exact=model.exact, vals=ctx.vals_t)
-                x = y
-            return x, None, None, None
-        g0 = grad / float(K + 1)
-        x = g0
-        for k in range(K):
-            y = torch.empty_like(grad) if k == K - 1 else (ping if k % 2 == 0 else pong)
-            spmm(eng.csr, x, y=None, acc_in=g0, acc_out=y, exact=model.exact, vals=ctx.vals_t)
-            x = y
-        return x, None, None, None
+            spmm(eng.csr, x, y=y, exact=model.exact, vals=vals_t)
+        else:
+            spmm(eng.csr, x, y=None, acc_in=grad, acc_out=y, exact=model.exact, vals=vals_t)
+        x = y
+    return x
+
+
+class _BprStep(torch.autograd.Function):
+    """get_loss (base_model.py:181-210) as ONE autograd node on the native path: K-layer propagation (tgcn_spmm_*), BPR
+    pairs with their gradient scatter (tgcn_bpr_pairs_f32), L2 term (tgcn_reg_rows_f32); backward = the transposed
+    propagation of the scattered gradient + the L2 rows.  No torch gather / elementwise op touches a [*, d] tensor."""
+
+    @staticmethod
+    def forward(ctx, wu, wi, model, cols):
+        lib = _capi.lib()
+        dev = model.device
+        stream = _capi.current_stream(dev)
+        e0 = model._e0_flat(wu, wi)
+        n_u, d, K = model.n_users, e0.shape[1], model.n_layers
+        drop = model._dropout_values() if (model.training and model.dropout > 0) else (None, None)
+        out = torch.empty_like(e0)
+        model._engine.forward(e0, K, single=model._single, exact=model.exact, out=out, vals=drop[0])
+        b, m = cols.shape[1], cols.shape[0] - 2
+        users, pos, negs = cols[0], cols[1], cols[2:]
+        grad = torch.zeros_like(e0)
+        terms = torch.empty((m, b), dtype=torch.float32, device=dev)
+        scale = 1.0 if (model._single or K == 0) else 1.0 / float(K + 1)
+        _capi.check(lib.tgcn_bpr_pairs_f32(_capi.ptr(out[:n_u]), _capi.ptr(out[n_u:]), _capi.ptr(users), _capi.ptr(pos), _capi.ptr(negs),
+                                           b, m, d, scale, _capi.ptr(terms), _capi.ptr(grad[:n_u]), _capi.ptr(grad[n_u:]), stream),
+                    'tgcn_bpr_pairs_f32')
+        reg_terms = torch.empty((b,), dtype=torch.float32, device=dev)
+        _capi.check(lib.tgcn_reg_rows_f32(_capi.ptr(e0[:n_u]), _capi.ptr(e0[n_u:]), _capi.ptr(users), _capi.ptr(pos), _capi.ptr(negs),
+                                          b, m, d, 0.0, _capi.ptr(reg_terms), None, None, stream), 'tgcn_reg_rows_f32')
+        bpr = terms.sum() / float(b * m)
+        reg = reg_terms.sum() * (model.reg_lambda / (2.0 * b))
+        ctx.model, ctx.grad, ctx.vals_t, ctx.cols, ctx.e0 = model, grad, drop[1], cols, e0
+        return bpr, reg
+
+    @staticmethod
+    def backward(ctx, g_bpr, g_reg):
+        model, grad, cols, e0 = ctx.model, ctx.grad, ctx.cols, ctx.e0
+        n_u, d = model.n_users, e0.shape[1]
+        b, m = cols.shape[1], cols.shape[0] - 2
+        # upstream factors (1.0 for `loss.backward()`): read once; the forward is long enqueued by now
+        s_bpr, s_reg = float(g_bpr), float(g_reg)
+        if s_bpr != 1.0:
+            grad = grad * s_bpr
+        de0 = _backward_propagate(model, grad, ctx.vals_t)
+        if de0 is grad:
+            de0 = grad.clone()
+        scratch = torch.empty((b,), dtype=torch.float32, device=model.device)
+        _capi.check(_capi.lib().tgcn_reg_rows_f32(_capi.ptr(e0[:n_u]), _capi.ptr(e0[n_u:]), _capi.ptr(cols[0]), _capi.ptr(cols[1]),
+                                                  _capi.ptr(cols[2:]), b, m, d, model.reg_lambda / b * s_reg, _capi.ptr(scratch),
+                                                  _capi.ptr(de0[:n_u]), _capi.ptr(de0[n_u:]), _capi.current_stream(model.device)),
+                    'tgcn_reg_rows_f32')
+        ctx.grad = None
+        return de0[:n_u], de0[n_u:], None, None
 
 
 class LightGCN(nn.Module):
@@ -136,6 +192,7 @@ class LightGCN(nn.Module):
             users = np.repeat(np.asarray(tud.index), [len(v) for v in tud.values])
             rp, items = train_mask_csr(users, np.concatenate([np.asarray(v) for v in tud.values]), self.n_users)
         self._mask_rowptr_host, self._mask_items_host = np.asarray(rp, dtype=np.int64), np.asarray(items, dtype=np.int32)
+        self._true_csr_host = true_lists_csr(self.true_test_lil)   # relevant lists of the test users, in test_users order
 
     def _init_embeddings(self, emb_size):
         """base_model.py:64-69; the two tables are views of ONE contiguous [N, d] buffer so the layer-0 matrix
@@ -153,6 +210,7 @@ class LightGCN(nn.Module):
         self.training = False
         self._engine_obj = None
         self._mask_dev = None
+        self._true_dev = None
         self._drop = None
 
     # ------------------------------------------------------------------ engine (device state, built lazily)
@@ -176,16 +234,19 @@ class LightGCN(nn.Module):
                               torch.from_numpy(self._mask_items_host).to(self.device))
         return self._mask_dev
 
+    def _e0_flat(self, wu, wi):
+        """detached [N, d] view of the two tables when they still share one buffer (no copy), else their concatenation"""
+        if (wu.is_contiguous() and wi.is_contiguous()
+                and wi.data_ptr() == wu.data_ptr() + wu.numel() * 4 and wu.untyped_storage().data_ptr() == wi.untyped_storage().data_ptr()):
+            return torch.as_strided(wu.detach(), (self.n_users + self.n_items, wu.shape[1]), (wu.shape[1], 1))
+        return torch.cat([wu.detach(), wi.detach()])
+
     def _e0(self):
         """[N, d] layer-0 matrix (base_model.py:88-91) without a copy when the tables still share storage."""
         wu, wi = self.embedding_user.weight, self.embedding_item.weight
-        if (wu.is_contiguous() and wi.is_contiguous()
-                and wi.data_ptr() == wu.data_ptr() + wu.numel() * 4 and wu.untyped_storage().data_ptr() == wi.untyped_storage().data_ptr()):
-            flat = torch.as_strided(wu.detach(), (self.n_users + self.n_items, wu.shape[1]), (wu.shape[1], 1))
-            if torch.is_grad_enabled() and (wu.requires_grad or wi.requires_grad):
-                return torch.cat([wu, wi])   # autograd needs the graph edge; forward cost is one copy
-            return flat
-        return torch.cat([wu, wi])
+        if torch.is_grad_enabled() and (wu.requires_grad or wi.requires_grad):
+            return torch.cat([wu, wi])   # autograd needs the graph edge; forward cost is one copy (get_loss avoids it)
+        return self._e0_flat(wu, wi)
 
     @property
     def embedding_matrix(self):
@@ -193,21 +254,35 @@ class LightGCN(nn.Module):
 
     # ------------------------------------------------------------------ dropout (base_model.py:77-86)
     def _dropout_values(self):
-        """Edge dropout as value masking on the fixed CSR: keep entry e iff rand[e] < 1 - p, kept values scaled
-        by 1/(1-p).  With dropout_rng='cpu' the uniform draw is torch.rand(nnz) on the CPU generator exactly as
-        base_model.py:82, so a seeded run drops the same edges as the reference (tests); the default draws on
-        the device.  Returns (vals, vals_transposed) device tensors."""
+        """Edge dropout as value masking on the fixed CSR (tgcn_dropout_values_f32): keep entry e iff u_e < 1 - p, kept
+        values scaled by 1/(1-p).  With dropout_rng='cpu' u is torch.rand(nnz) on the CPU generator exactly as
+        base_model.py:82, so a seeded run drops the same edges as the reference (tests); the default is a Philox draw on
+        the device keyed by a seed taken from torch's generator.  ONE launch writes the values, the transposed values
+        (the backward's matrix) and both copies in the segment plan's stream order.
+        Returns (EdgeValues forward, EdgeValues backward)."""
         g = self.graph
+        dev = self.device
         if self._drop is None:
             scaled = (g.vals / np.float32(1 - self.dropout)).astype(np.float32)
-            self._drop = (torch.from_numpy(scaled).to(self.device), torch.from_numpy(g.transpose_perm()).to(self.device))
+            self._drop = (torch.from_numpy(scaled).to(dev), torch.from_numpy(g.transpose_perm().astype(np.int32)).to(dev))
         scaled, perm = self._drop
+        nnz = max(g.nnz, 1)
+        rand_u, seed = None, 0
         if self.dropout_rng == 'cpu':
-            keep = (torch.rand(g.nnz) < (1 - self.dropout)).to(self.device)
+            rand_u = torch.rand(g.nnz).to(dev)
         else:
-            keep = torch.rand(g.nnz, device=self.device) < (1 - self.dropout)
-        vals = torch.where(keep, scaled, torch.zeros_like(scaled))
-        return vals, vals[perm]
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        ent_src = self._engine.csr.segment_ent_src(self.emb_size) if not self.exact else None
+        n_stream = 0 if ent_src is None else ent_src.numel()
+        vals, vals_t = torch.empty(nnz, dtype=torch.float32, device=dev), torch.empty(nnz, dtype=torch.float32, device=dev)
+        ev = ev_t = None
+        if n_stream:
+            ev, ev_t = torch.empty(n_stream, dtype=torch.float32, device=dev), torch.empty(n_stream, dtype=torch.float32, device=dev)
+        rc = _capi.lib().tgcn_dropout_values_f32(_capi.ptr(scaled), _capi.ptr(rand_u), seed, float(1 - self.dropout), _capi.ptr(perm),
+                                                 _capi.ptr(ent_src), g.nnz, n_stream, _capi.ptr(vals), _capi.ptr(vals_t), _capi.ptr(ev),
+                                                 _capi.ptr(ev_t), _capi.current_stream(dev))
+        _capi.check(rc, 'tgcn_dropout_values_f32')
+        return EdgeValues(vals, ev), EdgeValues(vals_t, ev_t)
 
     # ------------------------------------------------------------------ forward (base_model.py:93-106)
     @property
@@ -254,9 +329,25 @@ class LightGCN(nn.Module):
     # ------------------------------------------------------------------ losses (base_model.py:181-210)
     def get_loss(self, data):
         """data: [batch, 2 + n_neg] rows (user, positive, negatives...) -> BPR + L2 terms."""
+        if not hasattr(self, '_loss_values'):
+            self._loss_values = defaultdict(float)
         cols = data.to(self.device).t()
+        if self._native_loss():
+            bpr, reg = _BprStep.apply(self.embedding_user.weight, self.embedding_item.weight, self, cols.contiguous())
+            self._loss_values['bpr'] += bpr.detach()
+            self._loss_values['reg'] += reg.detach()
+            return bpr + reg
         users, pos, negs = cols[0], cols[1], list(cols[2:])
         return self.bpr_loss(users, pos, negs) + self.reg_loss(users, pos, negs)
+
+    def _native_loss(self):
+        """The fused step applies to the plain LightGCN loss: a subclass or instance that replaces a scoring / loss member
+        (LTRLinear rebinds score_pairwise, AdvSamplModel overrides get_loss) keeps the generic torch composition below."""
+        cls = type(self)
+        plain = all(name not in self.__dict__ and getattr(cls, name) is getattr(LightGCN, name)
+                    for name in ('score_pairwise', 'bpr_loss', 'reg_loss', 'representation'))
+        return (plain and self.device.type == 'cuda' and self.emb_size <= 512 and torch.is_grad_enabled()
+                and self.embedding_user.weight.requires_grad and self.embedding_item.weight.requires_grad)
 
     def bpr_loss(self, users, pos, negs):
         """mean over negatives of mean_b selu(s(u, neg) - s(u, pos))  (base_model.py:186-198)"""
@@ -312,27 +403,40 @@ class LightGCN(nn.Module):
     # ------------------------------------------------------------------ evaluate / predict (base_model.py:212-276)
     @torch.no_grad()
     def evaluate(self, epoch=None):
+        """base_model.py:212-233 without the list round trip: the top-k tensor `predict_tensors` leaves on the GPU goes
+        straight into the metric arithmetic (metrics.ranking_metrics_device); 5 x len(k) numbers cross to the host."""
         self.eval()
         self.training = False
-        predictions, _ = self.predict(self.test_users, with_scores=True)
-        results = ranking_metrics(self.true_test_lil, np.asarray(predictions), self.k)
+        _, idx = self.predict_tensors(self.test_users)
+        if self._true_dev is None:
+            self._true_dev = tuple(torch.from_numpy(a).to(self.device) for a in self._true_csr_host)
+        results = ranking_metrics_device(self._true_dev[0], self._true_dev[1], idx, self.k, self.n_items)
         self.logger.info(' ' * 11 + ''.join([f'@{i:<6}' for i in self.k]))
         for m in results:
             self.metrics_logger[m] = np.append(self.metrics_logger[m], [results[m]], axis=0)
             self.logger.info(f'{m:11}' + ' '.join([f'{j:.4f}' for j in results[m]]))
         return results
 
-    def _batch_mask(self, batch_users):
-        """device CSR (rowptr, items) of the train items of `batch_users` (host-side slicing of the mask CSR)."""
-        rp, it = self._mask_rowptr_host, self._mask_items_host
+    def _batch_mask(self, batch_users, ids=None):
+        """device CSR (rowptr int32 [B+1], items int32) of the train items of `batch_users`, cut out of the device mask CSR:
+        a contiguous id range is a view of it (no copy); any other list is one device gather.  The host only does O(B)
+        numpy arithmetic on the row pointers -- no per-user loop."""
+        rp = self._mask_rowptr_host
         cnt = rp[batch_users + 1] - rp[batch_users]
         rowptr = np.zeros(len(batch_users) + 1, dtype=np.int32)
         np.cumsum(cnt, out=rowptr[1:])
+        rowptr_dev = torch.from_numpy(rowptr).to(self.device)
+        _, items_dev = self._mask()
+        total = int(rowptr[-1])
+        if total == 0:
+            return rowptr_dev, items_dev[:1] if items_dev.numel() else torch.zeros(1, dtype=torch.int32, device=self.device)
         if len(batch_users) and np.all(np.diff(batch_users) == 1):
-            items = it[rp[batch_users[0]]:rp[batch_users[-1] + 1]]
-        else:
-            items = np.concatenate([it[rp[u]:rp[u + 1]] for u in batch_users]) if len(batch_users) else it[:0]
-        return torch.from_numpy(rowptr).to(self.device), torch.from_numpy(np.ascontiguousarray(items)).to(self.device)
+            return rowptr_dev, items_dev[int(rp[batch_users[0]]):int(rp[batch_users[-1] + 1])]
+        if ids is None:
+            ids = torch.from_numpy(batch_users).to(self.device)
+        starts = torch.from_numpy(rp[batch_users]).to(self.device)
+        shift = torch.repeat_interleave(starts - rowptr_dev[:-1].to(torch.int64), torch.from_numpy(cnt).to(self.device), output_size=total)
+        return rowptr_dev, items_dev[shift + torch.arange(total, device=self.device)]
 
     @torch.no_grad()
     def predict(self, users, save: bool = False, with_scores: bool = False):
@@ -367,7 +471,7 @@ class LightGCN(nn.Module):
         for n, j in enumerate(range(0, len(users), step)):
             batch = users[j:j + step]
             ids = torch.from_numpy(batch).to(self.device)
-            rp, it = self._batch_mask(batch)
+            rp, it = self._batch_mask(batch, ids)
             slot = n % len(streams)
             side = streams[slot]
             side.wait_stream(main)          # inputs (and the representation) are produced on the main stream
