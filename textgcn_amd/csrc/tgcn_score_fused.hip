@@ -416,10 +416,188 @@ struct SelectArgs {
 
 constexpr int kMaskCache = 512;  // train items per user cached in LDS for the membership test
 
-// One wave per user.  Lane l walks log segment l (+64, ...): every iteration offers one candidate from each
-// of up to 64 segments, so the loop length is the longest segment, not the number of segments.
+// ---- threshold from the strided sample: one wave per user ---------------------------------------------------------------
+// tau_u = the kTauRank-th largest of the user's sampled scores after its sampled train items are dropped.  The row is
+// staged in LDS (coalesced load, mask applied by the lanes that own the train items), read back VPL values per lane, and
+// the maximum is extracted kTauRank times (per-lane max, wave max, the owning lane retires one copy).  Replaces the
+// k_mask + k_topk pair on the sample (28 us for 2048 x 1563 -> ~4 us) and zeroes the fallback counter for this call.
+__device__ __forceinline__ float wave_max_f(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+template <int VPL>
+__global__ __launch_bounds__(256) void k_tau(const float *__restrict__ Ss, int m_ld, int B, int m, const int *__restrict__ mask_rowptr,
+                                             const int *__restrict__ mask_items, float *__restrict__ tau, int *__restrict__ flagged)
+{
+    extern __shared__ float srow[];   // [4][64 * VPL]
+    const int lane = lane_id();
+    const int w = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + w;
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        flagged[0] = 0;
+    float *row = srow + w * (kWave * VPL);
+    const bool ok = b < B;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int j = lane + kWave * i;
+        row[j] = (ok && j < m) ? Ss[(size_t)b * m_ld + j] : -INFINITY;
+    }
+    __syncthreads();
+    if (ok && mask_rowptr) {
+        const int mb = mask_rowptr[b], me = mask_rowptr[b + 1];
+        for (int e = mb + lane; e < me; e += kWave) {
+            const int it = mask_items[e];
+            if (it % kSampleStride == 0 && it / kSampleStride < m)
+                row[it / kSampleStride] = -INFINITY;
+        }
+    }
+    __syncthreads();
+    float x[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i)
+        x[i] = row[lane + kWave * i];
+    float t = -INFINITY;
+    for (int r = 0; r < kTauRank; ++r) {
+        float lm = x[0];
+#pragma unroll
+        for (int i = 1; i < VPL; ++i)
+            lm = fmaxf(lm, x[i]);
+        t = wave_max_f(lm);
+        const int owner = __ffsll((long long)__ballot(lm == t)) - 1;
+        if (lane == owner) {
+            bool done = false;
+#pragma unroll
+            for (int i = 0; i < VPL; ++i)
+                if (!done && x[i] == t) {
+                    x[i] = -INFINITY;
+                    done = true;
+                }
+        }
+    }
+    if (ok && lane == 0)
+        tau[b] = t;
+}
+
+// ---- exact selection from the logs ----------------------------------------------------------------------------------------
+// One wave per user.  (1) lane = log segment: counts -> exclusive prefix -> the segments' entries are copied, compacted, into
+// an LDS array (n ~ 320 of them); (2) train items are dropped (binary search in the user's sorted list); (3) the k-th
+// largest value is found by a bitwise binary search over order-preserving uint keys (32 steps of VPL ballots -- no serial
+// insertion chain); (4) the k winners ((value desc, item asc); ties at the k-th value are taken by ascending item) are packed
+// into lanes 0..k-1 and sorted by a 64-lane bitonic network.  A user with fewer than k unmasked candidates, an overflowed
+// log or more than kSelCap candidates is flagged for the exact fallback.
+constexpr int kSelCap = 1024;          // candidates per user held in LDS (8 KB per wave)
+constexpr int kSelVPL = kSelCap / kWave;
+
+__device__ __forceinline__ unsigned ordered_key(float v)
+{
+    const unsigned u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// bitonic sort of one (value, item) pair per lane, best first: (value desc, item asc)
+__device__ __forceinline__ void wave_sort_desc(float &v, int &i, int lane)
+{
+#pragma unroll
+    for (int size = 2; size <= kWave; size <<= 1) {
+#pragma unroll
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            const float ov = __shfl_xor(v, stride);
+            const int oi = __shfl_xor(i, stride);
+            const bool lower = (lane & stride) == 0;
+            const bool first_half = (lane & size) == 0;       // this block sorts best-first; the other half worst-first
+            const bool keep_better = lower == first_half;
+            const bool other_better = better(ov, oi, v, i);
+            if (other_better == keep_better) {
+                v = ov;
+                i = oi;
+            }
+        }
+    }
+}
+
+template <int VPL>
+__device__ __forceinline__ void select_from_lds(const float2 *__restrict__ cand, int n, int k, int lane, float &out_v, int &out_i,
+                                                float2 *__restrict__ pack)
+{
+    unsigned key[VPL];
+    int idx[VPL];
+#pragma unroll
+    for (int s = 0; s < VPL; ++s) {
+        const int j = lane + kWave * s;
+        const float2 t = j < n ? cand[j] : make_float2(-INFINITY, __int_as_float(INT_MAX));
+        idx[s] = __float_as_int(t.y);
+        key[s] = idx[s] == INT_MAX ? 0u : ordered_key(t.x);      // dropped / padding: below every real score (key >= 1)
+    }
+    // T = k-th largest key: the largest T with |{key >= T}| >= k
+    unsigned T = 0;
+    for (int bit = 31; bit >= 0; --bit) {
+        const unsigned c = T | (1u << bit);
+        int cnt = 0;
+#pragma unroll
+        for (int s = 0; s < VPL; ++s)
+            cnt += __popcll(__ballot(key[s] >= c));
+        if (cnt >= k)
+            T = c;
+    }
+    int above = 0;
+#pragma unroll
+    for (int s = 0; s < VPL; ++s)
+        above += __popcll(__ballot(key[s] > T));
+    // ties at T: the k - above smallest item ids among them.  I = the (k - above)-th smallest tied id (same search, on ids)
+    const int need = k - above;
+    unsigned I = 0xFFFFFFFFu;   // take every tie unless there are more than needed
+    int ties = 0;
+#pragma unroll
+    for (int s = 0; s < VPL; ++s)
+        ties += __popcll(__ballot(key[s] == T));
+    if (ties > need) {
+        // largest J with |{tied, ~id >= J}| >= need  <=>  smallest ids first (ids are non-negative: ~id order reverses them)
+        unsigned J = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+            const unsigned c = J | (1u << bit);
+            int cnt = 0;
+#pragma unroll
+            for (int s = 0; s < VPL; ++s)
+                cnt += __popcll(__ballot(key[s] == T && ~(unsigned)idx[s] >= c));
+            if (cnt >= need)
+                J = c;
+        }
+        I = ~J;   // ids <= I are taken
+    }
+    // pack the k winners into LDS slots 0..k-1 (any order), then one per lane
+    int base = 0;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int s = 0; s < VPL; ++s) {
+        const bool take = key[s] > T || (key[s] == T && (unsigned)idx[s] <= I);
+        const unsigned long long m = __ballot(take);
+        if (take)
+            pack[base + __popcll(m & lt)] = make_float2(__uint_as_float(key[s]), __int_as_float(idx[s]));
+        base += __popcll(m);
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's LDS writes before its reads
+    __builtin_amdgcn_wave_barrier();
+    float v = -INFINITY;
+    int i = INT_MAX;
+    if (lane < k) {
+        const float2 t = pack[lane];
+        const unsigned kk = __float_as_uint(t.x);
+        v = __uint_as_float((kk & 0x80000000u) ? (kk & 0x7FFFFFFFu) : ~kk);   // inverse of ordered_key
+        i = __float_as_int(t.y);
+    }
+    wave_sort_desc(v, i, lane);
+    out_v = v;
+    out_i = i;
+}
+
 __global__ __launch_bounds__(256) void k_select(const SelectArgs a)
 {
+    __shared__ float2 scand[4][kSelCap];
+    __shared__ float2 spack[4][kWave];
     __shared__ int smask[4][kMaskCache];
     const int lane = lane_id();
     const int w = threadIdx.x >> 6;
@@ -435,77 +613,75 @@ __global__ __launch_bounds__(256) void k_select(const SelectArgs a)
     if (cached)
         for (int j = lane; j < me - mb; j += kWave)
             smask[w][j] = a.mask_items[mb + j];
-    TopList e{-INFINITY, INT_MAX};
-    int n_valid = 0;
-    bool overflow = false;
-    const int n_seg = a.S * 2;
-    auto offer = [&](bool on, const float2 *__restrict__ lg, int j) {
-        float sv = -INFINITY;
-        int si = INT_MAX;
-        if (on) {
-            const float2 t = lg[j];
-            sv = t.x;
-            si = __float_as_int(t.y);
-            // a train item of this user: base_model.py:257-258 sets it to -inf
-            if (cached ? sorted_contains(smask[w], 0, me - mb, si) : sorted_contains(a.mask_items, mb, me, si))
-                on = false;
+    const int n_seg = a.S * 2;   // <= 64: one segment per lane
+    int cnt = lane < n_seg ? a.counts[(size_t)b * n_seg + lane] : 0;
+    bool overflow = __any(cnt > a.cap2);
+    cnt = min(cnt, a.cap2);
+    // exclusive prefix of the counts over lanes
+    int off = cnt;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const int t = __shfl_up(off, o);
+        if (lane >= o)
+            off += t;
+    }
+    const int n = __builtin_amdgcn_readlane(off, kWave - 1);
+    off -= cnt;
+    if (n > kSelCap)
+        overflow = true;
+    bool ok = !overflow;
+    float out_v = -INFINITY;
+    int out_i = INT_MAX;
+    if (ok) {
+        float2 *cand = scand[w];
+        const float2 *__restrict__ lg = a.logs + ((size_t)b * n_seg + min(lane, n_seg - 1)) * a.cap2;
+        int longest = cnt;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            longest = max(longest, __shfl_xor(longest, o));
+        for (int j0 = 0; j0 < longest; j0 += 8) {
+            float2 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                t[u] = lg[min(j0 + u, a.cap2 - 1)];   // in bounds; entries past cnt are ignored
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (j0 + u < cnt)
+                    cand[off + j0 + u] = t[u];
         }
-        n_valid += __popcll(__ballot(on));
-        list_offer(e, sv, si, on, a.k, lane);
-    };
-    if (n_seg >= 32) {
-        // many short segments: lane = segment, all segments advance together.  The first kPre candidates of every
-        // segment are fetched in one go (independent loads, one memory latency) before any is offered.
-        constexpr int kPre = 8;
-        for (int seg0 = 0; seg0 < n_seg; seg0 += kWave) {
-            const int seg = seg0 + lane;
-            int cnt = seg < n_seg ? a.counts[(size_t)b * n_seg + seg] : 0;
-            if (__any(cnt > a.cap2))
-                overflow = true;
-            cnt = min(cnt, a.cap2);
-            const float2 *__restrict__ lg = a.logs + ((size_t)b * n_seg + min(seg, n_seg - 1)) * a.cap2;
-            float2 pre[kPre];
-#pragma unroll
-            for (int j = 0; j < kPre; ++j)
-                pre[j] = lg[min(j, a.cap2 - 1)];   // always in bounds; entries past cnt are ignored below
-            int longest = cnt;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1)
-                longest = max(longest, __shfl_xor(longest, o));
-#pragma unroll
-            for (int j = 0; j < kPre; ++j) {
-                if (j >= longest)
-                    break;
-                bool on = j < cnt;
-                const float sv = pre[j].x;
-                const int si = __float_as_int(pre[j].y);
-                if (on && (cached ? sorted_contains(smask[w], 0, me - mb, si) : sorted_contains(a.mask_items, mb, me, si)))
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        // drop train items (base_model.py:257-258 sets them to -inf); count what is left
+        int n_valid = 0;
+        for (int j0 = 0; j0 < n; j0 += kWave) {
+            const int j = j0 + lane;
+            bool on = j < n;
+            if (on) {
+                const int si = __float_as_int(cand[j].y);
+                if (cached ? sorted_contains(smask[w], 0, me - mb, si) : sorted_contains(a.mask_items, mb, me, si)) {
+                    cand[j].y = __int_as_float(INT_MAX);
                     on = false;
-                n_valid += __popcll(__ballot(on));
-                list_offer(e, sv, si, on, a.k, lane);
+                }
             }
-            for (int j = kPre; j < longest; ++j)
-                offer(j < cnt, lg, j);
+            n_valid += __popcll(__ballot(on));
         }
-    } else {
-        // few long segments: the wave sweeps each segment 64 candidates at a time
-        for (int seg = 0; seg < n_seg; ++seg) {
-            int cnt = a.counts[(size_t)b * n_seg + seg];
-            if (cnt > a.cap2) {
-                overflow = true;
-                cnt = a.cap2;
-            }
-            const float2 *__restrict__ lg = a.logs + ((size_t)b * n_seg + seg) * a.cap2;
-            for (int j0 = 0; j0 < cnt; j0 += kWave)
-                offer(j0 + lane < cnt, lg, j0 + lane);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        ok = n_valid >= a.k;
+        if (ok) {
+            if (n <= 4 * kWave)
+                select_from_lds<4>(cand, n, a.k, lane, out_v, out_i, spack[w]);
+            else if (n <= 8 * kWave)
+                select_from_lds<8>(cand, n, a.k, lane, out_v, out_i, spack[w]);
+            else
+                select_from_lds<kSelVPL>(cand, n, a.k, lane, out_v, out_i, spack[w]);
         }
     }
-    const bool ok = !overflow && n_valid >= a.k;
     if (!ok && lane == 0)
         a.flagged[1 + atomicAdd(a.flagged, 1)] = b;
     if (ok && lane < a.k) {
-        a.out_val[(size_t)b * a.k + lane] = a.do_round ? round4(e.v) : e.v;
-        a.out_idx[(size_t)b * a.k + lane] = e.i;
+        a.out_val[(size_t)b * a.k + lane] = a.do_round ? round4(out_v) : out_v;
+        a.out_idx[(size_t)b * a.k + lane] = out_i;
     }
 }
 
@@ -516,7 +692,8 @@ struct BruteArgs {
     const int *__restrict__ mask_rowptr;
     const int *__restrict__ mask_items;
     const int *__restrict__ flagged;  // [1 + B]: count, rows
-    float2 *__restrict__ parts;      // [flag_cap][kBruteSplits][64] partial lists
+    float2 *parts;                   // [flag_cap][kBruteSplits][64] partial lists
+    int *done;                       // [flag_cap] arrival counters (zero on entry; the merging workgroup re-zeroes its own)
     int flag_cap;
     float *__restrict__ out_val;
     int64_t *__restrict__ out_idx;
@@ -600,33 +777,39 @@ __global__ __launch_bounds__(kBruteWaves * 64) void k_brute_part(const BruteArgs
             for (int o = 1; o < kBruteWaves; ++o)
                 list_offer(e, lv[o * kWave + lane], li[o * kWave + lane], lane < a.k && li[o * kWave + lane] != INT_MAX, a.k, lane);
             a.parts[((size_t)f * kBruteSplits + split) * kWave + lane] = make_float2(e.v, __int_as_float(e.i));
-        }
-    }
-}
-
-// one wave per flagged user: merge the kBruteSplits partial lists and write the result
-__global__ __launch_bounds__(64) void k_brute_merge(const BruteArgs a)
-{
-    const int lane = lane_id();
-    const int n_flagged = min(a.flagged[0], a.flag_cap);
-    for (int f = blockIdx.x; f < n_flagged; f += gridDim.x) {
-        const int b = a.flagged[1 + f];
-        TopList e{-INFINITY, INT_MAX};
-        for (int sidx = 0; sidx < kBruteSplits; ++sidx) {
-            const float2 t = a.parts[((size_t)f * kBruteSplits + sidx) * kWave + lane];
-            const int ti = __float_as_int(t.y);
-            list_offer(e, t.x, ti, lane < a.k && ti != INT_MAX, a.k, lane);
-        }
-        if (lane < a.k) {
-            a.out_val[(size_t)b * a.k + lane] = a.do_round ? round4(e.v) : e.v;
-            a.out_idx[(size_t)b * a.k + lane] = e.i;
+            // The workgroup whose arrival is the last of this user's kBruteSplits merges the partial lists (one launch
+            // instead of part + merge).  Hand-off: plain stores by this one wave -> agent release -> drained -> agent atomic
+            // add; the last arriver (told by the value its add returned) -> agent acquire -> plain loads
+            // (MI355X_MICROARCH.md, inter-workgroup visibility).  Placement-independent; no spin anywhere.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            int ticket = 0;
+            if (lane == 0)
+                ticket = atomicAdd(a.done + f, 1);
+            ticket = __builtin_amdgcn_readfirstlane(ticket);
+            if (ticket == kBruteSplits - 1) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                TopList t{-INFINITY, INT_MAX};
+                for (int sidx = 0; sidx < kBruteSplits; ++sidx) {
+                    const float2 q = a.parts[((size_t)f * kBruteSplits + sidx) * kWave + lane];
+                    const int qi = __float_as_int(q.y);
+                    list_offer(t, q.x, qi, lane < a.k && qi != INT_MAX, a.k, lane);
+                }
+                if (lane < a.k) {
+                    a.out_val[(size_t)b * a.k + lane] = a.do_round ? round4(t.v) : t.v;
+                    a.out_idx[(size_t)b * a.k + lane] = t.i;
+                }
+                if (lane == 0)
+                    a.done[f] = 0;
+            }
         }
     }
 }
 
 struct Plan {
     int S, items_per_split, cap2, m, m_ld;  // m = sampled items
-    size_t off_sample, off_tauv, off_taui, off_tau, off_logs, off_counts, off_parts, off_flags, total;
+    size_t off_sample, off_tauv, off_taui, off_tau, off_logs, off_counts, off_parts, off_flags, off_done, total;
     int flag_cap;
     bool small;
 };
@@ -663,6 +846,7 @@ Plan make_plan(int B, int I, int d, int k)
     p.flag_cap = B;   // every user may need the fallback (e.g. fully tied scores): 16 KB of partial lists each
     p.off_parts = o, o += align256((size_t)p.flag_cap * kBruteSplits * kWave * sizeof(float2));
     p.off_flags = o, o += align256((size_t)(B + 1) * sizeof(int));
+    p.off_done = o, o += align256((size_t)p.flag_cap * sizeof(int));   // contiguous with the flags: one memset covers both
     p.total = o;
     return p;
 }
@@ -748,15 +932,40 @@ extern "C" int tgcn_score_topk_f32(const float *U, const int64_t *user_ids, int3
     float *Ss = reinterpret_cast<float *>(ws + p.off_sample);
     float *tauv = reinterpret_cast<float *>(ws + p.off_tauv);
     int64_t *taui = reinterpret_cast<int64_t *>(ws + p.off_taui);
+    float *tau1 = reinterpret_cast<float *>(ws + p.off_tau);
+    int *flagged = reinterpret_cast<int *>(ws + p.off_flags);
+    int *done = reinterpret_cast<int *>(ws + p.off_done);
     if ((rc = launch_score_dense(U, user_ids, B, It, p.m, d, kSampleStride, Ss, p.m_ld, s)) != TGCN_OK)
         return rc;
-    if (mask_rowptr && (rc = launch_mask(Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, kSampleStride, s)) != TGCN_OK)
-        return rc;
-    if ((rc = launch_topk(Ss, p.m_ld, B, p.m, kTauRank, 0, tauv, taui, s)) != TGCN_OK)
-        return rc;
+    // the arrival counters of the fallback are left at zero by every call (the merging workgroup re-zeroes its own), but the
+    // workspace is the caller's and "nothing in it needs initialising": clear them with the flag word
+    if (hipMemsetAsync(flagged, 0, (size_t)(ws + p.off_done - reinterpret_cast<char *>(flagged)) + (size_t)p.flag_cap * sizeof(int), s) != hipSuccess)
+        return check_launch("hipMemsetAsync(flagged, done)");
+    const float *tau_ptr;
+    int tau_stride;
+    if (p.m <= 64 * kWave) {   // one wave per user: mask + rank-kTauRank selection in one launch
+        const dim3 grid((B + 3) / 4);
+        const int vpl = p.m <= 8 * kWave ? 8 : p.m <= 16 * kWave ? 16 : p.m <= 32 * kWave ? 32 : 64;
+        const size_t lds = (size_t)4 * kWave * vpl * sizeof(float);
+        switch (vpl) {
+            case 8: hipLaunchKernelGGL((k_tau<8>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, tau1, flagged); break;
+            case 16: hipLaunchKernelGGL((k_tau<16>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, tau1, flagged); break;
+            case 32: hipLaunchKernelGGL((k_tau<32>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, tau1, flagged); break;
+            default: hipLaunchKernelGGL((k_tau<64>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, tau1, flagged); break;
+        }
+        if ((rc = check_launch("k_tau")) != TGCN_OK)
+            return rc;
+        tau_ptr = tau1, tau_stride = 1;
+    } else {                   // very large catalogues (> 131 072 items): mask + workgroup-per-row top-k on the sample
+        if (mask_rowptr && (rc = launch_mask(Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, kSampleStride, s)) != TGCN_OK)
+            return rc;
+        if ((rc = launch_topk(Ss, p.m_ld, B, p.m, kTauRank, 0, tauv, taui, s)) != TGCN_OK)
+            return rc;
+        tau_ptr = tauv + (kTauRank - 1), tau_stride = kTauRank;
+    }
     // 2. filtered GEMM over all items
     FilterArgs fa;
-    fa.U = U, fa.user_ids = user_ids, fa.It = It, fa.tau = tauv + (kTauRank - 1), fa.tau_stride = kTauRank;
+    fa.U = U, fa.user_ids = user_ids, fa.It = It, fa.tau = tau_ptr, fa.tau_stride = tau_stride;
     fa.logs = reinterpret_cast<float2 *>(ws + p.off_logs);
     fa.counts = reinterpret_cast<int *>(ws + p.off_counts);
     fa.B = B, fa.I = I, fa.d = d, fa.S = p.S, fa.items_per_split = p.items_per_split, fa.cap2 = p.cap2;
@@ -778,14 +987,11 @@ extern "C" int tgcn_score_topk_f32(const float *U, const int64_t *user_ids, int3
         return rc;
 
     // 3. exact selection from the logs; 4. exact rescoring of flagged users
-    int *flagged = reinterpret_cast<int *>(ws + p.off_flags);
-    if (hipMemsetAsync(flagged, 0, sizeof(int), s) != hipSuccess)
-        return check_launch("hipMemsetAsync(flagged)");
     SelectArgs sa{fa.logs, fa.counts, mask_rowptr, mask_items, out_val, out_idx, flagged, B, p.S, p.cap2, k, round4};
     hipLaunchKernelGGL(k_select, dim3((B + 3) / 4), dim3(256), 0, s, sa);
     if ((rc = check_launch("k_select")) != TGCN_OK)
         return rc;
-    BruteArgs ba{U, user_ids, It, mask_rowptr, mask_items, flagged, reinterpret_cast<float2 *>(ws + p.off_parts), p.flag_cap,
+    BruteArgs ba{U, user_ids, It, mask_rowptr, mask_items, flagged, reinterpret_cast<float2 *>(ws + p.off_parts), done, p.flag_cap,
                  out_val, out_idx, B, I, d, k, round4};
     size_t brute_lds = ((size_t)((d + 63) & ~63) + 2 * kBruteWaves * kWave) * sizeof(float);
     if (d <= kBruteTileMaxD && (d & 3) == 0)
@@ -793,8 +999,5 @@ extern "C" int tgcn_score_topk_f32(const float *U, const int64_t *user_ids, int3
     if ((rc = brute_lds_opt_in()) != TGCN_OK)
         return rc;
     hipLaunchKernelGGL(k_brute_part, dim3(kBruteSplits, 8), dim3(kBruteWaves * 64), brute_lds, s, ba);
-    if ((rc = check_launch("k_brute_part")) != TGCN_OK)
-        return rc;
-    hipLaunchKernelGGL(k_brute_merge, dim3(64), dim3(64), 0, s, ba);
-    return check_launch("k_brute_merge");
+    return check_launch("k_brute_part");
 }

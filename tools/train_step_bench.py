@@ -25,7 +25,8 @@ def main():
                                user_mapping=pd.DataFrame({'remap_id': [0], 'org_id': ['u']}),
                                item_mapping=pd.DataFrame({'remap_id': [0], 'org_id': ['i']}))
     out = {}
-    for rng_mode in ('device', 'device-generic', 'cpu'):
+    modes = sys.argv[1:] or ['device', 'device-generic', 'cpu']
+    for rng_mode in modes:
         p = types.SimpleNamespace(k=[20, 40], emb_size=d, n_layers=K, device='cuda:0', load=None, batch_size=2048, quiet=True,
                                   dropout=0.4, dropout_rng=rng_mode.split('-')[0], lr=1e-3)
         m = LightGCN(p, ds)
