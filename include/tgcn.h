@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TGCN_ABI_VERSION 4
+#define TGCN_ABI_VERSION 5
 
 #define TGCN_OK 0
 #define TGCN_ERR_ARG (-1)         /* bad argument (null pointer, size, unsupported d/k ...) */
@@ -191,31 +191,37 @@ int tgcn_score_candidates_f32(const float *U, const int64_t *users, const float 
  * Edge dropout as value masking on the fixed CSR.
  *   replaces BaseModel._dropout_norm_matrix                        TextGCN/base_model.py:77-86
  *   (torch.rand(nnz) on the CPU, index_select, new COO + coalesce -- a device sort -- and an H->D copy per mini-batch)
- * Entry e is kept iff u_e < keep_prob (= 1 - p, base_model.py:82-83); a kept entry's value is scaled_vals[e] (the stored
- * value / (1 - p), :84), a dropped one 0.  u_e = rand_u[e] when rand_u != NULL (e.g. the reference's own CPU stream, for
- * parity), else a Philox4x32-10 draw keyed by (seed, e).  Because the draw is a function of e alone, the same launch also
- * writes the transposed values vals_t[e] = vals[perm[e]] (the backward's matrix; the dropped matrix is not symmetric) and
- * the copies in a segment plan's stream order, ent_val[s] = vals[ent_src[s]], ent_val_t[s] = vals_t[ent_src[s]], without a
- * second pass.  Optional outputs may be NULL. */
-int tgcn_dropout_values_f32(const float *scaled_vals, const float *rand_u, uint64_t seed, float keep_prob,
-                            const int32_t *perm, const int32_t *ent_src, int64_t nnz, int64_t n_stream, float *vals,
+ * Entry e is kept iff u_e < keep_prob (= 1 - p, base_model.py:82-83); a kept entry's value is stored_vals[e] / keep_prob (the
+ * reference's fp32 division, :84), a dropped one 0.  u_e = rand_u[e] when rand_u != NULL (e.g. the reference's own CPU stream,
+ * for parity), else a Philox4x32-10 draw keyed by (seed, e).  Because the draw is a function of e alone, the same launch also
+ * writes, in stream order and without a second pass:
+ *   vals_t[e]     = value of entry perm[e]  (the backward's matrix A^T on the same structure; the dropped matrix is not
+ *                   symmetric).  stored_vals_t[e] = stored_vals[perm[e]], or NULL when that equals stored_vals[e].
+ *   ent_val[s]    = value of entry ent_src[s]    -- a segment plan's stream order; ent_stored = the plan's own ent_val
+ *   ent_val_t[s]  = value of entry ent_src_t[s] (= perm[ent_src[s]]); ent_stored_t as stored_vals_t.
+ * Optional outputs (and the inputs only they need) may be NULL. */
+int tgcn_dropout_values_f32(const float *stored_vals, const float *stored_vals_t, const float *rand_u, uint64_t seed,
+                            float keep_prob, const int32_t *perm, const float *ent_stored, const float *ent_stored_t,
+                            const int32_t *ent_src, const int32_t *ent_src_t, int64_t nnz, int64_t n_stream, float *vals,
                             float *vals_t, float *ent_val, float *ent_val_t, tgcn_stream_t stream);
 
 /* BPR pairs: terms[j, r] = selu(s(u_r, n_jr) - s(u_r, p_r)), s = row dot product of the PROPAGATED tables, for b batch rows
  * (users[r], pos[r], negs[j, r]), j < m; loss = sum(terms) / (b m).
  *   replaces the gathers + score_pairwise + F.selu + mean          TextGCN/base_model.py:186-198 (:171)
- *   and their autograd backward: d loss / d users_emb, d items_emb are ADDED (float atomics) into grad_users / grad_items,
- *   which the caller zero-fills; every gradient is multiplied by grad_scale (the layer mean's 1 / (K + 1), folded in). */
+ *   and their autograd backward: with gradient tables given, d loss / d users_emb, d items_emb are ADDED (float atomics)
+ *   into grad_users / grad_items, which the caller zero-fills; every gradient is multiplied by grad_scale (the layer mean's
+ *   1 / (K + 1), folded in) and by *upstream, a DEVICE scalar (autograd's d L / d loss; NULL = 1) -- no host round trip.
+ * terms or the gradient pair may be NULL (values only / gradients only). */
 int tgcn_bpr_pairs_f32(const float *users_emb, const float *items_emb, const int64_t *users, const int64_t *pos,
-                       const int64_t *negs, int32_t b, int32_t m, int32_t d, float grad_scale, float *terms,
-                       float *grad_users, float *grad_items, tgcn_stream_t stream);
+                       const int64_t *negs, int32_t b, int32_t m, int32_t d, float grad_scale, const float *upstream,
+                       float *terms, float *grad_users, float *grad_items, tgcn_stream_t stream);
 
 /* L2 term: terms[r] = |E_u[users[r]]|^2 + |E_i[pos[r]]|^2 + sum_j |E_i[negs[j, r]]|^2 on the layer-0 tables; the
  * reference's reg_loss is lambda / (2 b) * sum(terms)               TextGCN/base_model.py:200-210
- * With gradient tables given, coef * row is ADDED to the row of every occurrence (coef = lambda / b). */
+ * With gradient tables given, coef * *upstream * row is ADDED to the row of every occurrence (coef = lambda / b). */
 int tgcn_reg_rows_f32(const float *e_users, const float *e_items, const int64_t *users, const int64_t *pos,
-                      const int64_t *negs, int32_t b, int32_t m, int32_t d, float coef, float *terms,
-                      float *grad_users, float *grad_items, tgcn_stream_t stream);
+                      const int64_t *negs, int32_t b, int32_t m, int32_t d, float coef, const float *upstream,
+                      float *terms, float *grad_users, float *grad_items, tgcn_stream_t stream);
 
 /* (e) Multi-GPU exchange step of the row partition: all-gather of the freshly propagated row blocks.
  * The reference is single-device -- there is no call to replace (grep nccl|torch.distributed|all_gather in TextGCN/ -> 0

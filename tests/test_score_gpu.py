@@ -279,3 +279,49 @@ def test_topk_beyond_64_takes_several_passes(cuda, b, i, d, k):
         for r in range(b):
             f = idx[r][fin[r]]
             assert f.unique().numel() == f.numel()                  # no item twice among the finite ones
+
+
+def _oracle_topk_rows(oracle, u, it, rp, items, rows, k):
+    """oracle top-k (k-ordered fmaf chains, mask, (value desc, index asc), round) of the selected batch rows"""
+    s = oracle.score_dense(u[rows], it)
+    sub_rp = np.zeros(len(rows) + 1, dtype=np.int64)
+    np.cumsum(rp[rows + 1] - rp[rows], out=sub_rp[1:])
+    sub_items = np.concatenate([items[rp[r]:rp[r + 1]] for r in rows]) if sub_rp[-1] else np.zeros(0, np.int64)
+    oracle.mask_train(s, sub_rp, sub_items)
+    return oracle.topk(s, k, round4=True)
+
+
+def test_fused_topk_at_config3_scoring_shape(cuda, oracle):
+    """BASELINE config 3's full-catalogue call as the model class issues it: 16 384 users x 60 000 items x d = 128
+    (k_score_filter32 + k_tau + k_select + fallback) against the unfused dense -> mask -> top-k path on the same device
+    buffers (bit for bit, all users) and against the CPU oracle on sampled users."""
+    rng = np.random.default_rng(33)
+    b, i, d, k = 16384, 60000, 128, 40
+    u = (rng.standard_normal((b, d)) * 0.1).astype(np.float32)
+    it = (rng.standard_normal((i, d)) * 0.1).astype(np.float32)
+    lists = [np.unique(rng.integers(0, i, size=rng.integers(1, 30))) for _ in range(b)]     # sorted, distinct train items
+    rp = np.zeros(b + 1, dtype=np.int64)
+    np.cumsum([len(t) for t in lists], out=rp[1:])
+    items = np.concatenate(lists)
+    v, idx = _fused_vs_dense(cuda, u, it, k, mask=(rp, items))
+    rows = rng.choice(b, size=48, replace=False)
+    rv, ri = _oracle_topk_rows(oracle, u, it, rp, items, rows, k)
+    assert np.array_equal(idx.cpu().numpy()[rows], ri)
+    assert np.array_equal(bits(v.cpu().numpy()[rows]), bits(rv))
+
+
+def test_scoring_at_config5_folded_width(cuda, oracle):
+    """BASELINE config 5's scoring call: the folded ltr_linear operands are 960 wide (d = 128 + 2 x 384 + bias column,
+    padded), 2048 users x 60 000 items.  Widths beyond 256 take the dense -> mask -> top-k route inside
+    tgcn_score_topk_f32: checked against the separate calls (bit for bit) and against the CPU oracle's k-ordered chain on
+    sampled users."""
+    rng = np.random.default_rng(55)
+    b, i, d, k = 2048, 60000, 960, 40
+    u = (rng.standard_normal((b, d)) * 0.05).astype(np.float32)
+    it = (rng.standard_normal((i, d)) * 0.05).astype(np.float32)
+    rp, items = _rand_mask(rng, b, i, 1, 30)
+    v, idx = _fused_vs_dense(cuda, u, it, k, mask=(rp, items))
+    rows = rng.choice(b, size=12, replace=False)
+    rv, ri = _oracle_topk_rows(oracle, u, it, rp, items, rows, k)
+    assert np.array_equal(idx.cpu().numpy()[rows], ri)
+    assert np.array_equal(bits(v.cpu().numpy()[rows]), bits(rv))

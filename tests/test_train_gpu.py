@@ -85,15 +85,24 @@ def test_dropout_values_kernel(cuda):
     u, i = synth.interactions(3000, 1200, 90000, seed=2)
     g = NormGraph.from_pairs(u, i, 3000, 1200)
     nnz = g.nnz
-    scaled = torch.from_numpy((g.vals / np.float32(0.6)).astype(np.float32)).to(cuda)
-    perm = torch.from_numpy(g.transpose_perm().astype(np.int32)).to(cuda)
+    stored = torch.from_numpy(g.vals).to(cuda)
+    scaled = torch.from_numpy((g.vals / np.float32(0.6)).astype(np.float32)).to(cuda)      # the reference's values / (1 - p)
+    perm_h = g.transpose_perm()
+    perm = torch.from_numpy(perm_h.astype(np.int32)).to(cuda)
+    assert np.array_equal(g.vals[perm_h], g.vals)                # symmetric values: stored_vals_t may be NULL
     rng = np.random.default_rng(0)
-    ent_src = torch.from_numpy(rng.integers(0, nnz, 50000).astype(np.int32)).to(cuda)
+    src_h = rng.integers(0, nnz, 50000)
+    ent_src = torch.from_numpy(src_h.astype(np.int32)).to(cuda)
+    ent_src_t = torch.from_numpy(perm_h[src_h].astype(np.int32)).to(cuda)
+    ent_stored = stored[ent_src.long()].contiguous()
     lib = _capi.lib()
 
-    def run(rand_u, seed):
+    def run(rand_u, seed, explicit_t=False):
         out = [torch.empty(nnz, device=cuda), torch.empty(nnz, device=cuda), torch.empty(50000, device=cuda), torch.empty(50000, device=cuda)]
-        rc = lib.tgcn_dropout_values_f32(_capi.ptr(scaled), _capi.ptr(rand_u), seed, 0.6, _capi.ptr(perm), _capi.ptr(ent_src), nnz, 50000,
+        st = stored[perm.long()].contiguous() if explicit_t else None
+        est = None if st is None else st[ent_src.long()].contiguous()
+        rc = lib.tgcn_dropout_values_f32(_capi.ptr(stored), _capi.ptr(st), _capi.ptr(rand_u), seed, 0.6, _capi.ptr(perm), _capi.ptr(ent_stored),
+                                         _capi.ptr(est), _capi.ptr(ent_src), _capi.ptr(ent_src_t), nnz, 50000,
                                          *[_capi.ptr(t) for t in out], _capi.current_stream(cuda))
         _capi.check(rc, 'tgcn_dropout_values_f32')
         return out
@@ -104,7 +113,7 @@ def test_dropout_values_kernel(cuda):
     assert torch.equal(vals[kept], scaled[kept])
     assert torch.equal(vals_t, vals[perm.long()])
     assert torch.equal(ev, vals[ent_src.long()]) and torch.equal(ev_t, vals_t[ent_src.long()])
-    again = run(None, 12345)
+    again = run(None, 12345, explicit_t=True)       # the general (non-symmetric values) form gives the same result here
     assert all(torch.equal(a, b) for a, b in zip((vals, vals_t, ev, ev_t), again))
     other = run(None, 12346)[0]
     assert 0.3 < float(((other != 0) == kept).float().mean()) < 0.7        # a different seed is a different mask (agreement ~ 0.52)

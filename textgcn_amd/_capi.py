@@ -8,7 +8,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_ui
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, '_lib', 'libtgcn.so')
 
-TGCN_ABI_VERSION = 4
+TGCN_ABI_VERSION = 5
 TGCN_COMM_ID_BYTES = 128
 SPMM_AUTO, SPMM_WAVE_PER_ROW, SPMM_GROUP_PER_ROW = 0, 1, 2
 
@@ -48,12 +48,12 @@ _SIGNATURES = {
     'tgcn_ltr_pack_items_f32': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
     'tgcn_score_candidates_f32': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p,
                                                  c_void_p, c_void_p, c_void_p]),
-    'tgcn_dropout_values_f32': (ctypes.c_int, [c_void_p, c_void_p, c_uint64, c_float, c_void_p, c_void_p, c_int64, c_int64, c_void_p,
-                                               c_void_p, c_void_p, c_void_p, c_void_p]),
+    'tgcn_dropout_values_f32': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                                               c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'tgcn_bpr_pairs_f32': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float,
-                                          c_void_p, c_void_p, c_void_p, c_void_p]),
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'tgcn_reg_rows_f32': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float,
-                                         c_void_p, c_void_p, c_void_p, c_void_p]),
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'tgcn_comm_unique_id': (ctypes.c_int, [c_void_p]),
     'tgcn_comm_init_rank': (ctypes.c_int, [POINTER(c_void_p), c_int32, c_int32, c_char_p]),
     'tgcn_comm_destroy': (ctypes.c_int, [c_void_p]),

@@ -59,11 +59,11 @@ struct FilterArgs {
 // load is unconditional and stays in flight across the MFMA block.  (Any `cond ? load : 0` form makes hipcc
 // branch around the load and wait for it inside the branch.)  Other widths need zeros in the K padding and take
 // the predicated path.
-template <int DQ, bool FULLK>
-__device__ __forceinline__ void load_rows(float4 (&v)[(kStage * DQ) / 256], const float *__restrict__ src,
+template <int DQ, bool FULLK, int ROWS = kStage>
+__device__ __forceinline__ void load_rows(float4 (&v)[(ROWS * DQ) / 256], const float *__restrict__ src,
                                           const int64_t *__restrict__ ids, int row0, int n_rows, int d)
 {
-    constexpr int N = (kStage * DQ) / 256;
+    constexpr int N = (ROWS * DQ) / 256;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         const int f = i * 256 + threadIdx.x;
@@ -84,10 +84,10 @@ __device__ __forceinline__ void load_rows(float4 (&v)[(kStage * DQ) / 256], cons
     }
 }
 
-template <int DQ>
-__device__ __forceinline__ void store_rows(float *__restrict__ dst, const float4 (&v)[(kStage * DQ) / 256])
+template <int DQ, int ROWS = kStage>
+__device__ __forceinline__ void store_rows(float *__restrict__ dst, const float4 (&v)[(ROWS * DQ) / 256])
 {
-    constexpr int N = (kStage * DQ) / 256;
+    constexpr int N = (ROWS * DQ) / 256;
     constexpr int ROW = 4 * DQ + 2;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
@@ -237,13 +237,15 @@ __global__ __launch_bounds__(256) void k_score_filter(const FilterArgs a)
 // three waves of a SIMD drift into lockstep -- they share the pipe, finish their blocks together and test together --
 // and the pipe idles through every epilogue (PMC: 58 % MFMA-busy, 63 % of the wave cycles waiting).  Costs a second
 // accumulator set (stages alternate between them).
-template <int DQ, bool FULLK>
+template <int DQ, bool FULLK, int ST>
 __device__ __forceinline__ void filter_pipelined(const FilterArgs &a)
 {
     static_assert(DQ == 16 || DQ == 32, "one test slot per MFMA pair (d <= 64) or per two pairs (d <= 128)");
+    static_assert(ST == kStage || ST == 2 * kStage, "an LDS stage holds one or two 64-item units");
+    constexpr int H = ST / kStage;            // 64-item units per LDS stage: one barrier per H units
     constexpr int kSlotsPerReg = (2 * DQ) / 32;
     constexpr int ROW = 4 * DQ + 2;
-    __shared__ __attribute__((aligned(16))) float smem[2 * kStage * ROW];
+    __shared__ __attribute__((aligned(16))) float smem[2 * ST * ROW];
     const int lane = lane_id();
     const int w = threadIdx.x >> 6;
     const int r32 = lane & 31;
@@ -279,9 +281,9 @@ __device__ __forceinline__ void filter_pipelined(const FilterArgs &a)
         return;
     }
 
-    float4 nxt[(kStage * DQ) / 256];
-    load_rows<DQ, FULLK>(nxt, a.It, nullptr, i_beg, i_end, a.d);
-    store_rows<DQ>(smem, nxt);
+    float4 nxt[(ST * DQ) / 256];
+    load_rows<DQ, FULLK, ST>(nxt, a.It, nullptr, i_beg, i_end, a.d);
+    store_rows<DQ, ST>(smem, nxt);
     __syncthreads();
     int buf = 0;
     const int cap2 = a.cap2;
@@ -294,14 +296,20 @@ __device__ __forceinline__ void filter_pipelined(const FilterArgs &a)
             ++cnt;
         }
     };
-    // one stage: c0/c1 <- scores of items [s0, s0 + 64); p0/p1 (items [s_prev, s_prev + 64), a full stage) are tested
-    // between the MFMAs when PREV
-    auto stage = [&](auto prev_tag, f32x16 &c0, f32x16 &c1, const f32x16 &p0, const f32x16 &p1, int s_prev, int s0) {
+    // one 64-item unit: c0/c1 <- scores of items [s0, s0 + 64), read from row `half * 64` of the current LDS stage; p0/p1
+    // (items [s_prev, s_prev + 64), a full unit) are tested between the MFMAs when PREV.  FIRST: the unit opens an LDS
+    // stage (the next stage's rows are requested from global memory); LAST: it closes one (those rows go to the other LDS
+    // buffer, barrier, swap).
+    auto unit = [&](auto prev_tag, auto first_tag, auto last_tag, f32x16 &c0, f32x16 &c1, const f32x16 &p0, const f32x16 &p1,
+                    int s_prev, int s0, int half) {
         constexpr bool PREV = decltype(prev_tag)::value;
-        const bool more = s0 + kStage < i_end;
-        if (more)
-            load_rows<DQ, FULLK>(nxt, a.It, nullptr, s0 + kStage, i_end, a.d);
-        const float *pi = smem + buf * kStage * ROW + r32 * ROW + 2 * h;
+        constexpr bool FIRST = decltype(first_tag)::value;
+        constexpr bool LAST = decltype(last_tag)::value;
+        const int stage0 = s0 - half * kStage;          // first item of this LDS stage
+        const bool more = stage0 + ST < i_end;
+        if (FIRST && more)
+            load_rows<DQ, FULLK, ST>(nxt, a.It, nullptr, stage0 + ST, i_end, a.d);
+        const float *pi = smem + (buf * ST + half * kStage) * ROW + r32 * ROW + 2 * h;
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             c0[r] = 0.0f, c1[r] = 0.0f;
@@ -325,7 +333,7 @@ __device__ __forceinline__ void filter_pipelined(const FilterArgs &a)
 #pragma unroll
             for (int q = 0; q < QB; ++q) {
                 const float2 b2 = bf[g * QB + q];
-                const int t0 = (g * QB + q) * 2;  // 2*DQ test slots per stage; one of every kSlotsPerReg is used
+                const int t0 = (g * QB + q) * 2;  // 2*DQ test slots per unit; one of every kSlotsPerReg is used
                 c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[g & 1][q].x, b2.x, c0, 0, 0, 0);
                 c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[g & 1][q].x, b2.x, c1, 0, 0, 0);
                 if constexpr (PREV) {
@@ -345,12 +353,14 @@ __device__ __forceinline__ void filter_pipelined(const FilterArgs &a)
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (more)
-            store_rows<DQ>(smem + (buf ^ 1) * kStage * ROW, nxt);
-        __syncthreads();
-        buf ^= 1;
+        if constexpr (LAST) {
+            if (more)
+                store_rows<DQ, ST>(smem + (buf ^ 1) * ST * ROW, nxt);
+            __syncthreads();
+            buf ^= 1;
+        }
     };
-    // the last stage of a split (possibly partial: rows past i_end) is tested after the loop
+    // the last unit of a split (possibly partial: rows past i_end) is tested after the loop
     auto test_last = [&](const f32x16 &p0, const f32x16 &p1, int s_prev) {
         const int lim = i_end - s_prev;
 #pragma unroll
@@ -367,9 +377,14 @@ __device__ __forceinline__ void filter_pipelined(const FilterArgs &a)
         }
     };
 
+    // units alternate between the accumulator sets A and B; with H = 2 the A units open an LDS stage and the B units close it
+    using T = std::true_type;
+    using F = std::false_type;
+    using OddFirst = std::integral_constant<bool, H == 1>;    // is a B unit the first of its stage?
+    using EvenLast = std::integral_constant<bool, H == 1>;    // is an A unit the last of its stage?
     f32x16 A0, A1, B0, B1;
     int s0 = i_beg;
-    stage(std::false_type{}, A0, A1, B0, B1, 0, s0);
+    unit(F{}, T{}, EvenLast{}, A0, A1, B0, B1, 0, s0, 0);
     for (;;) {
         int s_prev = s0;
         s0 += kStage;
@@ -377,14 +392,14 @@ __device__ __forceinline__ void filter_pipelined(const FilterArgs &a)
             test_last(A0, A1, s_prev);
             break;
         }
-        stage(std::true_type{}, B0, B1, A0, A1, s_prev, s0);
+        unit(T{}, OddFirst{}, T{}, B0, B1, A0, A1, s_prev, s0, H - 1);
         s_prev = s0;
         s0 += kStage;
         if (s0 >= i_end) {
             test_last(B0, B1, s_prev);
             break;
         }
-        stage(std::true_type{}, A0, A1, B0, B1, s_prev, s0);
+        unit(T{}, T{}, EvenLast{}, A0, A1, B0, B1, s_prev, s0, 0);
     }
     if (user_ok)
         a.counts[((size_t)user * a.S + split) * 2 + h] = cnt;
@@ -394,13 +409,20 @@ __device__ __forceinline__ void filter_pipelined(const FilterArgs &a)
 template <bool FULLK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_score_filter16(const FilterArgs a)
 {
-    filter_pipelined<16, FULLK>(a);
+    filter_pipelined<16, FULLK, kStage>(a);
+}
+
+// d <= 64 with 128-item LDS stages: one barrier per 128 MFMAs instead of per 64 (two workgroups per CU either way)
+template <bool FULLK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_score_filter16x2(const FilterArgs a)
+{
+    filter_pipelined<16, FULLK, 2 * kStage>(a);
 }
 
 template <bool FULLK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_score_filter32(const FilterArgs a)
 {
-    filter_pipelined<32, FULLK>(a);
+    filter_pipelined<32, FULLK, kStage>(a);
 }
 
 struct SelectArgs {
@@ -875,6 +897,9 @@ int brute_lds_opt_in()
     return TGCN_OK;
 }
 
+int g_filter_variant = 0;
+int filter_variant() { return g_filter_variant; }
+
 template <int DQ>
 int launch_filter(const FilterArgs &a, hipStream_t s)
 {
@@ -890,6 +915,9 @@ int launch_filter(const FilterArgs &a, hipStream_t s)
 }  // namespace tgcn
 
 using namespace tgcn;
+
+// development switch (not declared in tgcn.h): selects the filter kernel variant for A/B timing inside one process
+extern "C" void tgcn_dev_set_filter_variant(int v) { g_filter_variant = v; }
 
 extern "C" int64_t tgcn_score_topk_workspace_bytes(int32_t B, int32_t I, int32_t d, int32_t k)
 {
@@ -971,7 +999,9 @@ extern "C" int tgcn_score_topk_f32(const float *U, const int64_t *user_ids, int3
     fa.B = B, fa.I = I, fa.d = d, fa.S = p.S, fa.items_per_split = p.items_per_split, fa.cap2 = p.cap2;
     if (d <= 128) {
         const dim3 grid((B + kUsersPerWG - 1) / kUsersPerWG, p.S);
-        if (d == 64)
+        if (d == 64 && filter_variant() == 1)
+            hipLaunchKernelGGL((k_score_filter16x2<true>), grid, dim3(256), 0, s, fa);
+        else if (d == 64)
             hipLaunchKernelGGL((k_score_filter16<true>), grid, dim3(256), 0, s, fa);
         else if (d < 64)
             hipLaunchKernelGGL((k_score_filter16<false>), grid, dim3(256), 0, s, fa);

@@ -35,40 +35,47 @@ __device__ __forceinline__ unsigned philox_first(unsigned long long seed, unsign
 }
 
 struct DropArgs {
-    const float *__restrict__ scaled;     // [nnz] stored values / (1 - p)
-    const float *__restrict__ rand_u;     // [nnz] uniform draws, or NULL: Philox(seed, e)
+    const float *__restrict__ stored;       // [nnz] the matrix's stored values
+    const float *__restrict__ stored_t;     // [nnz] stored[perm[e]], or NULL when that equals stored[e] (symmetric values)
+    const float *__restrict__ rand_u;       // [nnz] uniform draws, or NULL: Philox(seed, e)
     unsigned long long seed;
     float keep_prob;
-    const int *__restrict__ perm;         // [nnz] transpose permutation (A^T).vals = vals[perm], or NULL
-    const int *__restrict__ ent_src;      // [n_stream] entry each segment-stream slot copies, or NULL
+    const int *__restrict__ perm;           // [nnz] transpose permutation (A^T).vals = vals[perm], or NULL
+    const float *__restrict__ ent_stored;   // [n_stream] the segment plan's own copy of the stored values
+    const float *__restrict__ ent_stored_t; // [n_stream] stored_t[ent_src[s]], or NULL (symmetric values)
+    const int *__restrict__ ent_src;        // [n_stream] entry each segment-stream slot copies
+    const int *__restrict__ ent_src_t;      // [n_stream] perm[ent_src[s]]
     int nnz, n_stream;
-    float *__restrict__ vals;             // [nnz]
-    float *__restrict__ vals_t;           // [nnz] or NULL
-    float *__restrict__ ev;               // [n_stream] or NULL
-    float *__restrict__ ev_t;             // [n_stream] or NULL
+    float *__restrict__ vals;               // [nnz]
+    float *__restrict__ vals_t;             // [nnz] or NULL
+    float *__restrict__ ev;                 // [n_stream] or NULL
+    float *__restrict__ ev_t;               // [n_stream] or NULL
 };
 
-__device__ __forceinline__ float dropped_value(const DropArgs &a, int e)
+// keep entry e iff u_e < 1 - p (base_model.py:82-83)
+__device__ __forceinline__ bool kept(const DropArgs &a, int e)
 {
-    // keep iff u < 1 - p (base_model.py:82-84), kept values already scaled by 1 / (1 - p)
     const float u = a.rand_u ? a.rand_u[e] : (float)(philox_first(a.seed, (unsigned)e) >> 8) * (1.0f / 16777216.0f);
-    return u < a.keep_prob ? a.scaled[e] : 0.0f;
+    return u < a.keep_prob;
 }
 
+// Every array is read and written in stream order (the only gather is rand_u[perm[e]] in the parity mode that replays a
+// host-drawn mask): kept values are stored / (1 - p) (base_model.py:84; the same IEEE fp32 division the reference does).
 __global__ __launch_bounds__(256) void k_dropout_values(const DropArgs a)
 {
     const int stride = gridDim.x * blockDim.x;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < a.nnz; e += stride) {
-        a.vals[e] = dropped_value(a, e);
+        const float s = a.stored[e];
+        a.vals[e] = kept(a, e) ? s / a.keep_prob : 0.0f;
         if (a.vals_t)
-            a.vals_t[e] = dropped_value(a, a.perm[e]);
+            a.vals_t[e] = kept(a, a.perm[e]) ? (a.stored_t ? a.stored_t[e] : s) / a.keep_prob : 0.0f;
     }
     if (a.ev) {
-        for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < a.n_stream; s += stride) {
-            const int src = a.ent_src[s];
-            a.ev[s] = dropped_value(a, src);
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < a.n_stream; i += stride) {
+            const float s = a.ent_stored[i];
+            a.ev[i] = kept(a, a.ent_src[i]) ? s / a.keep_prob : 0.0f;
             if (a.ev_t)
-                a.ev_t[s] = dropped_value(a, a.perm[src]);
+                a.ev_t[i] = kept(a, a.ent_src_t[i]) ? (a.ent_stored_t ? a.ent_stored_t[i] : s) / a.keep_prob : 0.0f;
         }
     }
 }
@@ -94,8 +101,9 @@ struct BprArgs {
     const int64_t *__restrict__ negs;      // [m, b]
     int b, m, d;
     float grad_scale;                      // multiplies every gradient written (1 / (K + 1) of the layer mean, folded in)
-    float *__restrict__ terms;             // [m, b] selu(s_neg - s_pos)
-    float *grad_users;                     // [U, d] zero-initialised by the caller; rows are ADDED to (float atomics)
+    const float *__restrict__ upstream;    // device scalar multiplying every gradient too (d L / d loss), or NULL (= 1)
+    float *__restrict__ terms;             // [m, b] selu(s_neg - s_pos), or NULL
+    float *grad_users;                     // [U, d] zero-initialised by the caller; rows are ADDED to (float atomics); or NULL
     float *grad_items;                     // [I, d]
 };
 
@@ -120,7 +128,8 @@ __global__ __launch_bounds__(256) void k_bpr_pairs(const BprArgs a)
         dot = fmaf(u[s], p[s], dot);
     }
     const float s_pos = wave_sum(dot);
-    const float inv = a.grad_scale / ((float)a.b * (float)a.m);
+    const float inv = a.grad_scale * (a.upstream ? *a.upstream : 1.0f) / ((float)a.b * (float)a.m);
+    const bool want_grad = a.grad_users != nullptr;
     float g_pos = 0.0f;
     for (int j = 0; j < a.m; ++j) {
         const size_t nr = (size_t)a.negs[(size_t)j * a.b + r] * a.d;
@@ -134,8 +143,10 @@ __global__ __launch_bounds__(256) void k_bpr_pairs(const BprArgs a)
         }
         const float x = wave_sum(dn) - s_pos;
         const float ex = expf(x);
-        if (lane == 0)
+        if (lane == 0 && a.terms)
             a.terms[(size_t)j * a.b + r] = x > 0.0f ? kSeluScale * x : kSeluScale * kSeluAlpha * (ex - 1.0f);
+        if (!want_grad)
+            continue;
         const float g = (x > 0.0f ? kSeluScale : kSeluScale * kSeluAlpha * ex) * inv;   // d loss / d s_neg ; d / d s_pos = -g
         g_pos -= g;
 #pragma unroll
@@ -147,6 +158,8 @@ __global__ __launch_bounds__(256) void k_bpr_pairs(const BprArgs a)
             }
         }
     }
+    if (!want_grad)
+        return;
 #pragma unroll
     for (int s = 0; s < kMaxSlabs; ++s) {
         const int c = s * kWave + lane;
@@ -163,7 +176,8 @@ struct RegArgs {
     const int64_t *__restrict__ users, *__restrict__ pos, *__restrict__ negs;
     int b, m, d;
     float coef;                            // lambda / b: gradient of lambda / (2 b) * |x|^2 is coef * x
-    float *__restrict__ terms;             // [b] squared norms of the 2 + m rows of batch row r
+    const float *__restrict__ upstream;    // device scalar multiplying the gradient too, or NULL (= 1)
+    float *__restrict__ terms;             // [b] squared norms of the 2 + m rows of batch row r, or NULL
     float *grad_users, *grad_items;        // NULL: values only
 };
 
@@ -174,6 +188,7 @@ __global__ __launch_bounds__(256) void k_reg_rows(const RegArgs a)
     if (r >= a.b)
         return;
     float sq = 0.0f;
+    const float coef = a.coef * (a.upstream ? *a.upstream : 1.0f);
     for (int t = 0; t < 2 + a.m; ++t) {
         const bool is_user = t == 0;
         const int64_t id = is_user ? a.users[r] : t == 1 ? a.pos[r] : a.negs[(size_t)(t - 2) * a.b + r];
@@ -183,11 +198,11 @@ __global__ __launch_bounds__(256) void k_reg_rows(const RegArgs a)
             const float v = row[c];
             sq = fmaf(v, v, sq);
             if (g)
-                atomicAdd(g + c, a.coef * v);
+                atomicAdd(g + c, coef * v);
         }
     }
     sq = wave_sum(sq);
-    if (lane == 0)
+    if (lane == 0 && a.terms)
         a.terms[r] = sq;
 }
 
@@ -196,19 +211,21 @@ __global__ __launch_bounds__(256) void k_reg_rows(const RegArgs a)
 
 using namespace tgcn;
 
-extern "C" int tgcn_dropout_values_f32(const float *scaled_vals, const float *rand_u, uint64_t seed, float keep_prob,
-                                       const int32_t *perm, const int32_t *ent_src, int64_t nnz, int64_t n_stream, float *vals,
+extern "C" int tgcn_dropout_values_f32(const float *stored_vals, const float *stored_vals_t, const float *rand_u, uint64_t seed,
+                                       float keep_prob, const int32_t *perm, const float *ent_stored, const float *ent_stored_t,
+                                       const int32_t *ent_src, const int32_t *ent_src_t, int64_t nnz, int64_t n_stream, float *vals,
                                        float *vals_t, float *ent_val, float *ent_val_t, tgcn_stream_t stream)
 {
     TGCN_REQUIRE(nnz >= 0 && nnz < INT32_MAX && n_stream >= 0 && n_stream < INT32_MAX, "nnz / n_stream out of range");
     TGCN_REQUIRE(keep_prob > 0.0f && keep_prob <= 1.0f, "keep_prob must be in (0, 1]");
     if (nnz == 0)
         return TGCN_OK;
-    TGCN_REQUIRE(scaled_vals && vals, "scaled_vals / vals is NULL");
+    TGCN_REQUIRE(stored_vals && vals, "stored_vals / vals is NULL");
     TGCN_REQUIRE(!vals_t || perm, "vals_t needs the transpose permutation");
-    TGCN_REQUIRE(!ent_val || ent_src, "ent_val needs ent_src");
-    TGCN_REQUIRE(!ent_val_t || (ent_val && perm), "ent_val_t needs ent_val and perm");
-    DropArgs a{scaled_vals, rand_u, seed, keep_prob, perm, ent_src, (int)nnz, ent_val ? (int)n_stream : 0, vals, vals_t, ent_val, ent_val_t};
+    TGCN_REQUIRE(!ent_val || (ent_src && ent_stored), "ent_val needs ent_src and ent_stored");
+    TGCN_REQUIRE(!ent_val_t || (ent_val && ent_src_t), "ent_val_t needs ent_val and ent_src_t");
+    DropArgs a{stored_vals, stored_vals_t, rand_u, seed, keep_prob, perm, ent_stored, ent_stored_t, ent_src, ent_src_t, (int)nnz,
+               ent_val ? (int)n_stream : 0, vals, vals_t, ent_val, ent_val_t};
     const int64_t work = nnz > n_stream ? nnz : n_stream;
     const int grid = (int)((work + 255) / 256 < 8192 ? (work + 255) / 256 : 8192);
     hipLaunchKernelGGL(k_dropout_values, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
@@ -216,29 +233,32 @@ extern "C" int tgcn_dropout_values_f32(const float *scaled_vals, const float *ra
 }
 
 extern "C" int tgcn_bpr_pairs_f32(const float *users_emb, const float *items_emb, const int64_t *users, const int64_t *pos,
-                                  const int64_t *negs, int32_t b, int32_t m, int32_t d, float grad_scale, float *terms,
-                                  float *grad_users, float *grad_items, tgcn_stream_t stream)
+                                  const int64_t *negs, int32_t b, int32_t m, int32_t d, float grad_scale, const float *upstream,
+                                  float *terms, float *grad_users, float *grad_items, tgcn_stream_t stream)
 {
     TGCN_REQUIRE(b >= 0 && m >= 1, "b / m out of range");
     TGCN_REQUIRE(d > 0 && d <= kMaxSlabs * kWave, "d out of range for the training kernels (<= 512)");
     if (b == 0)
         return TGCN_OK;
-    TGCN_REQUIRE(users_emb && items_emb && users && pos && negs && terms && grad_users && grad_items, "NULL pointer");
-    BprArgs a{users_emb, items_emb, users, pos, negs, b, m, d, grad_scale, terms, grad_users, grad_items};
+    TGCN_REQUIRE(users_emb && items_emb && users && pos && negs, "NULL pointer");
+    TGCN_REQUIRE(terms || grad_users, "neither terms nor gradients requested");
+    TGCN_REQUIRE((grad_users == nullptr) == (grad_items == nullptr), "give both gradient tables or neither");
+    BprArgs a{users_emb, items_emb, users, pos, negs, b, m, d, grad_scale, upstream, terms, grad_users, grad_items};
     hipLaunchKernelGGL(k_bpr_pairs, dim3((b + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return check_launch("k_bpr_pairs");
 }
 
 extern "C" int tgcn_reg_rows_f32(const float *e_users, const float *e_items, const int64_t *users, const int64_t *pos,
-                                 const int64_t *negs, int32_t b, int32_t m, int32_t d, float coef, float *terms,
-                                 float *grad_users, float *grad_items, tgcn_stream_t stream)
+                                 const int64_t *negs, int32_t b, int32_t m, int32_t d, float coef, const float *upstream,
+                                 float *terms, float *grad_users, float *grad_items, tgcn_stream_t stream)
 {
     TGCN_REQUIRE(b >= 0 && m >= 0 && d > 0, "b / m / d out of range");
     if (b == 0)
         return TGCN_OK;
-    TGCN_REQUIRE(e_users && e_items && users && pos && terms && (m == 0 || negs), "NULL pointer");
+    TGCN_REQUIRE(e_users && e_items && users && pos && (m == 0 || negs), "NULL pointer");
+    TGCN_REQUIRE(terms || grad_users, "neither terms nor gradients requested");
     TGCN_REQUIRE((grad_users == nullptr) == (grad_items == nullptr), "give both gradient tables or neither");
-    RegArgs a{e_users, e_items, users, pos, negs, b, m, d, coef, terms, grad_users, grad_items};
+    RegArgs a{e_users, e_items, users, pos, negs, b, m, d, coef, upstream, terms, grad_users, grad_items};
     hipLaunchKernelGGL(k_reg_rows, dim3((b + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return check_launch("k_reg_rows");
 }

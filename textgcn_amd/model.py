@@ -74,8 +74,9 @@ def _backward_propagate(model, grad, vals_t):
 
 class _BprStep(torch.autograd.Function):
     """get_loss (base_model.py:181-210) as ONE autograd node on the native path: K-layer propagation (tgcn_spmm_*), BPR
-    pairs with their gradient scatter (tgcn_bpr_pairs_f32), L2 term (tgcn_reg_rows_f32); backward = the transposed
-    propagation of the scattered gradient + the L2 rows.  No torch gather / elementwise op touches a [*, d] tensor."""
+    pair terms (tgcn_bpr_pairs_f32), L2 terms (tgcn_reg_rows_f32); backward = gradient scatter of the pairs into a zeroed
+    table, the transposed propagation of that table, and the L2 rows.  No torch gather / elementwise op touches a [*, d]
+    tensor, and autograd's upstream factor reaches the kernels as a device scalar (no host round trip)."""
 
     @staticmethod
     def forward(ctx, wu, wi, model, cols):
@@ -89,38 +90,36 @@ class _BprStep(torch.autograd.Function):
         model._engine.forward(e0, K, single=model._single, exact=model.exact, out=out, vals=drop[0])
         b, m = cols.shape[1], cols.shape[0] - 2
         users, pos, negs = cols[0], cols[1], cols[2:]
-        grad = torch.zeros_like(e0)
         terms = torch.empty((m, b), dtype=torch.float32, device=dev)
-        scale = 1.0 if (model._single or K == 0) else 1.0 / float(K + 1)
         _capi.check(lib.tgcn_bpr_pairs_f32(_capi.ptr(out[:n_u]), _capi.ptr(out[n_u:]), _capi.ptr(users), _capi.ptr(pos), _capi.ptr(negs),
-                                           b, m, d, scale, _capi.ptr(terms), _capi.ptr(grad[:n_u]), _capi.ptr(grad[n_u:]), stream),
-                    'tgcn_bpr_pairs_f32')
+                                           b, m, d, 1.0, None, _capi.ptr(terms), None, None, stream), 'tgcn_bpr_pairs_f32')
         reg_terms = torch.empty((b,), dtype=torch.float32, device=dev)
         _capi.check(lib.tgcn_reg_rows_f32(_capi.ptr(e0[:n_u]), _capi.ptr(e0[n_u:]), _capi.ptr(users), _capi.ptr(pos), _capi.ptr(negs),
-                                          b, m, d, 0.0, _capi.ptr(reg_terms), None, None, stream), 'tgcn_reg_rows_f32')
+                                          b, m, d, 0.0, None, _capi.ptr(reg_terms), None, None, stream), 'tgcn_reg_rows_f32')
         bpr = terms.sum() / float(b * m)
         reg = reg_terms.sum() * (model.reg_lambda / (2.0 * b))
-        ctx.model, ctx.grad, ctx.vals_t, ctx.cols, ctx.e0 = model, grad, drop[1], cols, e0
+        ctx.model, ctx.out, ctx.vals_t, ctx.cols, ctx.e0 = model, out, drop[1], cols, e0
         return bpr, reg
 
     @staticmethod
     def backward(ctx, g_bpr, g_reg):
-        model, grad, cols, e0 = ctx.model, ctx.grad, ctx.cols, ctx.e0
-        n_u, d = model.n_users, e0.shape[1]
+        model, out, cols, e0 = ctx.model, ctx.out, ctx.cols, ctx.e0
+        lib = _capi.lib()
+        stream = _capi.current_stream(model.device)
+        n_u, d, K = model.n_users, e0.shape[1], model.n_layers
         b, m = cols.shape[1], cols.shape[0] - 2
-        # upstream factors (1.0 for `loss.backward()`): read once; the forward is long enqueued by now
-        s_bpr, s_reg = float(g_bpr), float(g_reg)
-        if s_bpr != 1.0:
-            grad = grad * s_bpr
+        g_bpr = g_bpr.to(torch.float32).contiguous()
+        g_reg = g_reg.to(torch.float32).contiguous()
+        grad = torch.zeros_like(e0)
+        scale = 1.0 if (model._single or K == 0) else 1.0 / float(K + 1)     # the layer mean's factor, folded into the scatter
+        _capi.check(lib.tgcn_bpr_pairs_f32(_capi.ptr(out[:n_u]), _capi.ptr(out[n_u:]), _capi.ptr(cols[0]), _capi.ptr(cols[1]),
+                                           _capi.ptr(cols[2:]), b, m, d, scale, _capi.ptr(g_bpr), None, _capi.ptr(grad[:n_u]),
+                                           _capi.ptr(grad[n_u:]), stream), 'tgcn_bpr_pairs_f32')
         de0 = _backward_propagate(model, grad, ctx.vals_t)
-        if de0 is grad:
-            de0 = grad.clone()
-        scratch = torch.empty((b,), dtype=torch.float32, device=model.device)
-        _capi.check(_capi.lib().tgcn_reg_rows_f32(_capi.ptr(e0[:n_u]), _capi.ptr(e0[n_u:]), _capi.ptr(cols[0]), _capi.ptr(cols[1]),
-                                                  _capi.ptr(cols[2:]), b, m, d, model.reg_lambda / b * s_reg, _capi.ptr(scratch),
-                                                  _capi.ptr(de0[:n_u]), _capi.ptr(de0[n_u:]), _capi.current_stream(model.device)),
-                    'tgcn_reg_rows_f32')
-        ctx.grad = None
+        _capi.check(lib.tgcn_reg_rows_f32(_capi.ptr(e0[:n_u]), _capi.ptr(e0[n_u:]), _capi.ptr(cols[0]), _capi.ptr(cols[1]),
+                                          _capi.ptr(cols[2:]), b, m, d, model.reg_lambda / b, _capi.ptr(g_reg), None,
+                                          _capi.ptr(de0[:n_u]), _capi.ptr(de0[n_u:]), stream), 'tgcn_reg_rows_f32')
+        ctx.out = None
         return de0[:n_u], de0[n_u:], None, None
 
 
@@ -262,25 +261,38 @@ class LightGCN(nn.Module):
         Returns (EdgeValues forward, EdgeValues backward)."""
         g = self.graph
         dev = self.device
+        csr = self._engine.csr
         if self._drop is None:
-            scaled = (g.vals / np.float32(1 - self.dropout)).astype(np.float32)
-            self._drop = (torch.from_numpy(scaled).to(dev), torch.from_numpy(g.transpose_perm().astype(np.int32)).to(dev))
-        scaled, perm = self._drop
+            perm = g.transpose_perm()
+            sym = bool(np.array_equal(g.vals[perm], g.vals))    # (d_r a) d_c == (d_c a) d_r bit for bit unless edges repeat
+            self._drop = {'perm': torch.from_numpy(perm.astype(np.int32)).to(dev),
+                          'stored_t': None if sym else torch.from_numpy(g.vals[perm]).to(dev), 'plans': {}}
+        st = self._drop
         nnz = max(g.nnz, 1)
         rand_u, seed = None, 0
         if self.dropout_rng == 'cpu':
             rand_u = torch.rand(g.nnz).to(dev)
         else:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-        ent_src = self._engine.csr.segment_ent_src(self.emb_size) if not self.exact else None
+        d = self.emb_size
+        ent_src = csr.segment_ent_src(d) if not self.exact else None
         n_stream = 0 if ent_src is None else ent_src.numel()
+        ent_stored = ent_src_t = ent_stored_t = None
+        if n_stream:
+            if d not in st['plans']:    # static per plan: the transposed entry of every stream slot (+ its stored value)
+                src_t = st['perm'].index_select(0, ent_src.to(torch.int64))
+                st['plans'][d] = (src_t, None if st['stored_t'] is None else st['stored_t'].index_select(0, ent_src.to(torch.int64)))
+            ent_src_t, ent_stored_t = st['plans'][d]
+            ent_stored = csr._segment_plans[d][0][2]['ent_val']
         vals, vals_t = torch.empty(nnz, dtype=torch.float32, device=dev), torch.empty(nnz, dtype=torch.float32, device=dev)
         ev = ev_t = None
         if n_stream:
             ev, ev_t = torch.empty(n_stream, dtype=torch.float32, device=dev), torch.empty(n_stream, dtype=torch.float32, device=dev)
-        rc = _capi.lib().tgcn_dropout_values_f32(_capi.ptr(scaled), _capi.ptr(rand_u), seed, float(1 - self.dropout), _capi.ptr(perm),
-                                                 _capi.ptr(ent_src), g.nnz, n_stream, _capi.ptr(vals), _capi.ptr(vals_t), _capi.ptr(ev),
-                                                 _capi.ptr(ev_t), _capi.current_stream(dev))
+        rc = _capi.lib().tgcn_dropout_values_f32(_capi.ptr(csr.vals), _capi.ptr(st['stored_t']), _capi.ptr(rand_u), seed,
+                                                 float(1 - self.dropout), _capi.ptr(st['perm']), _capi.ptr(ent_stored),
+                                                 _capi.ptr(ent_stored_t), _capi.ptr(ent_src), _capi.ptr(ent_src_t), g.nnz, n_stream,
+                                                 _capi.ptr(vals), _capi.ptr(vals_t), _capi.ptr(ev), _capi.ptr(ev_t),
+                                                 _capi.current_stream(dev))
         _capi.check(rc, 'tgcn_dropout_values_f32')
         return EdgeValues(vals, ev), EdgeValues(vals_t, ev_t)
 
@@ -376,15 +388,17 @@ class LightGCN(nn.Module):
         for data in batches:
             self.optimizer.zero_grad()
             loss = self.get_loss(data)
-            if bool(loss.isnan()):
-                raise AssertionError(f'loss is NA at epoch {epoch}')   # base_model.py:123
+            is_nan = loss.isnan()          # read after the step is enqueued: the only host sync of the step
             loss.backward()
             self.optimizer.step()
+            if bool(is_nan):
+                raise AssertionError(f'loss is NA at epoch {epoch}')   # base_model.py:123
 
     def fit(self, batches):
         """Adam over all parameters; every `evaluate_every` epochs: log losses, evaluate, checkpoint, early stop.
         A run that is never stopped early writes a final checkpoint (the reference's for/else)."""
-        self.optimizer = torch.optim.Adam(self.parameters(), lr=self.lr)
+        # same update rule as the reference's torch.optim.Adam (base_model.py:110); `fused` = one launch per step on the GPU
+        self.optimizer = torch.optim.Adam(self.parameters(), lr=self.lr, fused=self.device.type == 'cuda')
         stopped = False
         for epoch in range(1, self.epochs + 1):
             self._train_epoch(batches, epoch)
