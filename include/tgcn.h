@@ -59,10 +59,9 @@ typedef struct tgcn_split_plan {
     float *workspace;              /* [n_chunks, d] fp32 scratch */
 } tgcn_split_plan_t;
 
-/* kernel selection for tgcn_spmm_csr_f32 (`flags & 0xff`); results are bit-identical across variants */
+/* kernel selection for tgcn_spmm_csr_f32 (`flags & 0xff`); bits 8..15 = row gathers in flight per wave (0: default) */
 #define TGCN_SPMM_AUTO 0
-#define TGCN_SPMM_WAVE_PER_ROW 1  /* one wave64 per row, lane = d/64 consecutive columns */
-#define TGCN_SPMM_GROUP_PER_ROW 2 /* d/4 lanes per row (float4 each), 256/d rows per wave; d in {32,64,128,256} */
+#define TGCN_SPMM_WAVE_PER_ROW 1  /* one wave64 per row, lane = d/64 consecutive columns (what AUTO selects) */
 
 /* K1 + K3: one LightGCN layer  Y = A . X  with the layer combination fused in.
  *   replaces torch.sparse.mm(norm_matrix, emb_matrix)              TextGCN/base_model.py:148

@@ -27,7 +27,7 @@ def _random_graph(n_u, n_i, nnz, seed, zipf=0.8):
     return NormGraph.from_pairs(u, i, n_u, n_i)
 
 
-VARIANTS = [(1, 4), (1, 8), (1, 16), (2, 2), (2, 4), (2, 8)]  # (variant, unroll)
+VARIANTS = [(0, 0), (1, 4), (1, 8), (1, 16)]  # (variant, row gathers in flight)
 
 
 @pytest.mark.parametrize('variant,unroll', VARIANTS)
@@ -57,7 +57,7 @@ def test_synth60_variants_bit_exact_vs_reference(golden, cuda, name):
     K = int(g[f'{name}_n_layers'])
     e0 = torch.from_numpy(g[f'{name}_layer0']).to(cuda)
     full = np.concatenate([g[f'{name}_users_emb'], g[f'{name}_items_emb']])
-    for variant in (0, 1, 2):
+    for variant in (0, 1):
         out, layers = prop.forward(e0, K, single=(name == 'single'), exact=True, keep_layers=True, variant=variant)
         for k in range(K + 1):
             assert np.array_equal(bits(layers[k].cpu().numpy()), bits(g[f'{name}_layer{k}'])), (variant, k)
@@ -96,7 +96,7 @@ def test_dropout_forward_vs_reference(golden, cuda, oracle):
 
 
 @pytest.mark.parametrize('d', [64, 128, 256, 32, 48, 100])
-@pytest.mark.parametrize('variant', [0, 1, 2])
+@pytest.mark.parametrize('variant', [0, 1])
 def test_random_graph_bit_exact_vs_oracle(cuda, oracle, d, variant):
     """Seeded Zipf graph with empty rows, rows of every small length and a few long ones."""
     from textgcn_amd.graph import NormGraph
@@ -146,7 +146,7 @@ def test_split_rows_deterministic_and_close(cuda, oracle, d, threshold):
     assert (deg > threshold).any() or threshold == 1024
     xd = torch.from_numpy(x).to(cuda)
     outs = []
-    for variant in (1, 2, 1):
+    for variant in (1, 0, 1):
         y = torch.empty((gr.n, d), device=cuda)
         spmm(csr, xd, y=y, variant=variant)
         outs.append(y.cpu().numpy())
@@ -238,22 +238,6 @@ def test_full_size_c3_properties(cuda, oracle):
     assert torch.equal(layers_split[1][short], layers[1][short])
     assert normwise(out_split.cpu().numpy(), out.cpu().numpy()) <= 1e-5
     assert torch.equal(prop.forward(e0d * 4.0, K, exact=True), out * 4.0)
-
-
-def test_hip_graph_replay_matches_eager(cuda):
-    """K launches captured into a HIP graph and replayed: same bits, and new inputs written into the captured
-    buffer are picked up."""
-    from textgcn_amd.propagate import Propagator
-    gr = _random_graph(2000, 900, 30000, seed=21)
-    prop = Propagator(gr, cuda, split_threshold=128)
-    e0 = torch.randn((gr.n, 64), device=cuda)
-    ref = prop.forward(e0, 3).clone()
-    out = prop.forward_graphed(e0, 3)
-    assert torch.equal(out, ref)
-    e0.mul_(2.0)                                 # same address, new contents
-    out2 = prop.forward_graphed(e0, 3)
-    assert torch.equal(out2, ref * 2.0)
-    assert len(prop._graphs) == 1
 
 
 def test_edge_cases_empty_and_isolated(cuda, oracle):

@@ -10,7 +10,7 @@ LIB_PATH = os.path.join(_HERE, '_lib', 'libtgcn.so')
 
 TGCN_ABI_VERSION = 5
 TGCN_COMM_ID_BYTES = 128
-SPMM_AUTO, SPMM_WAVE_PER_ROW, SPMM_GROUP_PER_ROW = 0, 1, 2
+SPMM_AUTO, SPMM_WAVE_PER_ROW = 0, 1
 
 
 class SplitPlanStruct(Structure):

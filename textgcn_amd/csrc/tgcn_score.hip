@@ -53,7 +53,18 @@ __device__ __forceinline__ void stage_tile(float *__restrict__ dst, const float 
     const int t = threadIdx.x;
     constexpr int N = (kTile * kKC / 4) / 256;
     float4 v[N];
-    // all loads first (one predicated load per element, no early waits), then the LDS writes
+    // source rows first (all id loads of a gathered tile in one batch), then all the row loads, then the LDS writes: written
+    // per element, the id fetch and its row fetch become N dependent round trips
+    int64_t srows[N];
+    if (ids) {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            srows[i] = ids[min(row0 + ((i * 256 + t) >> 4), n_rows - 1)];
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            srows[i] = (int64_t)min(row0 + ((i * 256 + t) >> 4), n_rows - 1) * row_mul;
+    }
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         const int f = i * 256 + t;
@@ -63,8 +74,7 @@ __device__ __forceinline__ void stage_tile(float *__restrict__ dst, const float 
         const int k = k0 + q * 4;
         // FULLK (d % 64 == 0): rows past the table are clamped, not zero-filled (their products are never stored),
         // so the loads are unconditional and overlap; other widths need zeros in the K padding (predicated path)
-        const int crow = min(row, n_rows - 1);
-        const int64_t srow = ids ? ids[crow] : (int64_t)crow * row_mul;
+        const int64_t srow = srows[i];
         const float *p = src + (size_t)srow * d;
         if constexpr (FULLK) {
             v[i] = *reinterpret_cast<const float4 *>(p + k);

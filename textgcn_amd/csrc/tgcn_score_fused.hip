@@ -64,14 +64,25 @@ __device__ __forceinline__ void load_rows(float4 (&v)[(ROWS * DQ) / 256], const 
                                           const int64_t *__restrict__ ids, int row0, int n_rows, int d)
 {
     constexpr int N = (ROWS * DQ) / 256;
+    // source rows first -- ALL the id loads of a gathered tile in one batch, then all the row loads: with the id fetch and
+    // its row fetch written per element, hipcc emits N dependent (id -> wait -> row -> wait) round trips (16 of them in the
+    // user-tile prologue of the filter kernels, ~10 % of a 2048-user launch)
+    int64_t srow[N];
+    if (ids) {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            srow[i] = ids[min(row0 + (i * 256 + (int)threadIdx.x) / DQ, n_rows - 1)];
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            srow[i] = min(row0 + (i * 256 + (int)threadIdx.x) / DQ, n_rows - 1);
+    }
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         const int f = i * 256 + threadIdx.x;
         const int r = f / DQ, q = f % DQ;
         const int row = row0 + r, k = q * 4;
-        const int crow = min(row, n_rows - 1);
-        const int64_t srow = ids ? ids[crow] : (int64_t)crow;
-        const float *p = src + (size_t)srow * d;
+        const float *p = src + (size_t)srow[i] * d;
         if constexpr (FULLK) {
             v[i] = *reinterpret_cast<const float4 *>(p + k);
         } else {
@@ -254,24 +265,27 @@ __device__ __forceinline__ void filter_pipelined(const FilterArgs &a)
     const int split = blockIdx.y;
     const int i_beg = split * a.items_per_split;
     const int i_end = min(a.I, i_beg + a.items_per_split);
-    {
-        float4 v[(kStage * DQ) / 256];
-        load_rows<DQ, FULLK>(v, a.U, a.user_ids, u0, a.B, a.d);
-        store_rows<DQ>(smem, v);
-        load_rows<DQ, FULLK>(v, a.U, a.user_ids, u0 + kStage, a.B, a.d);
-        store_rows<DQ>(smem + kStage * ROW, v);
-    }
-    __syncthreads();
+    // prologue: the 128-user tile (gathered through user_ids) and the first item stage are requested together -- one
+    // global round trip for the ids, one for all the rows -- then the users pass through LDS into registers
+    const int user = u0 + w * 32 + r32;
+    const bool user_ok = user < a.B;
+    float4 nxt[(ST * DQ) / 256];
     float2 bf[DQ];
+    {
+        float4 v[(kUsersPerWG * DQ) / 256];
+        load_rows<DQ, FULLK, kUsersPerWG>(v, a.U, a.user_ids, u0, a.B, a.d);
+        if (i_beg < i_end)
+            load_rows<DQ, FULLK, ST>(nxt, a.It, nullptr, i_beg, i_end, a.d);
+        store_rows<DQ, kUsersPerWG>(smem, v);
+    }
+    const float tau = user_ok ? a.tau[(size_t)user * a.tau_stride] : INFINITY;
+    __syncthreads();
     {
         const float *pu = smem + (w * 32 + r32) * ROW + 2 * h;
 #pragma unroll
         for (int q = 0; q < DQ; ++q)
             bf[q] = *reinterpret_cast<const float2 *>(pu + q * 4);
     }
-    const int user = u0 + w * 32 + r32;
-    const bool user_ok = user < a.B;
-    const float tau = user_ok ? a.tau[(size_t)user * a.tau_stride] : INFINITY;
     float2 *__restrict__ log = a.logs + ((size_t)(user_ok ? user : 0) * a.S + split) * 2 * a.cap2 + (size_t)h * a.cap2;
     int cnt = 0;
     __syncthreads();
@@ -280,9 +294,6 @@ __device__ __forceinline__ void filter_pipelined(const FilterArgs &a)
             a.counts[((size_t)user * a.S + split) * 2 + h] = 0;
         return;
     }
-
-    float4 nxt[(ST * DQ) / 256];
-    load_rows<DQ, FULLK, ST>(nxt, a.It, nullptr, i_beg, i_end, a.d);
     store_rows<DQ, ST>(smem, nxt);
     __syncthreads();
     int buf = 0;

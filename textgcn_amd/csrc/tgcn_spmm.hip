@@ -19,10 +19,6 @@
 //                             The row's (col, val) pairs are loaded 64 at a time, coalesced, and
 //                             broadcast with v_readlane into SGPRs: per entry one scalar address
 //                             computation, one 256*VEC-byte coalesced row load, VEC v_fma.
-//   k_spmm_group<G,UNROLL>    G = d/4 lanes per row, float4 per lane, 64/G rows per wave: short rows
-//                             (the common case: mean degree 10..100) keep all 64 lanes loading 16 B
-//                             each and 4x (d=64) more rows in flight per CU.  Broadcast inside a group
-//                             is ds_bpermute (__shfl with width G).
 //   k_spmm_generic            any d: wave per row, 64-column slabs.
 //   k_spmm_long_reduce<VEC>   adds the chunk sums of split rows and applies the epilogue.
 //   k_spmm_seg<VEC,UNROLL>    XCD-affine column blocking: tile waves walk per-class entry streams (the workgroups of
@@ -190,69 +186,6 @@ __global__ __launch_bounds__(256) void k_spmm_wave(const SpmmArgs a)
         acc[k] = 0.0f;
     accumulate_wave<VEC, UNROLL>(a, beg, end, lane, acc);
     epilogue<VEC>(a, (size_t)row * a.d + lane * VEC, acc);
-}
-
-// G lanes per row, float4 per lane (d == 4*G), R = 64/G rows per wave.
-template <int G, int UNROLL>
-__global__ __launch_bounds__(256) void k_spmm_group(const SpmmArgs a)
-{
-    constexpr int R = kWave / G;
-    constexpr int D = 4 * G;
-    constexpr int VEC = D / kWave;  // for the chunk waves (wave-per-chunk layout)
-    const int lane = lane_id();
-    const int wave = uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (wave < a.n_chunks) {
-        chunk_wave<VEC, 8>(a, wave, lane);
-        return;
-    }
-    if (wave - a.n_chunks >= a.row_waves)
-        return;
-    const int gl = lane & (G - 1);
-    const int row = (wave - a.n_chunks) * R + lane / G;
-    const bool valid = row < a.n_rows;
-    int beg = 0, end = 0;
-    if (valid) {
-        beg = a.rowptr[row];
-        end = a.rowptr[row + 1];
-    }
-    const bool is_long = (end - beg) > a.threshold;
-    if (is_long)
-        end = beg;
-    const float *__restrict__ Xl = a.X + gl * 4;
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int base = beg; base < end; base += G) {
-        const int n = min(G, end - base);  // uniform inside a group
-        int c = 0;
-        float v = 0.0f;
-        if (gl < n) {
-            c = a.colidx[base + gl];
-            v = a.vals[base + gl];
-        }
-        for (int j = 0; j < n; j += UNROLL) {
-            float4 x[UNROLL];
-            float vv[UNROLL];
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                const int jj = min(j + u, n - 1);
-                const int cj = __shfl(c, jj, G);
-                vv[u] = __shfl(v, jj, G);
-                x[u] = *reinterpret_cast<const float4 *>(Xl + (size_t)cj * D);
-            }
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                if (j + u < n) {
-                    acc.x = fmaf(vv[u], x[u].x, acc.x);
-                    acc.y = fmaf(vv[u], x[u].y, acc.y);
-                    acc.z = fmaf(vv[u], x[u].z, acc.z);
-                    acc.w = fmaf(vv[u], x[u].w, acc.w);
-                }
-            }
-        }
-    }
-    if (valid && !is_long) {
-        const float y[4] = {acc.x, acc.y, acc.z, acc.w};
-        epilogue<4>(a, (size_t)row * D + gl * 4, y);
-    }
 }
 
 // XCD-affine segmented launch (tgcn_spmm_segmented_f32).  Waves [0, n_tiles) walk one tile each of the plan's
@@ -529,17 +462,6 @@ int launch_wave(const SpmmArgs &a, int unroll, int grid, hipStream_t s)
     return check_launch("k_spmm_wave");
 }
 
-template <int G>
-int launch_group(const SpmmArgs &a, int unroll, int grid, hipStream_t s)
-{
-    switch (unroll) {
-        case 2: hipLaunchKernelGGL((k_spmm_group<G, 2>), dim3(grid), dim3(256), 0, s, a); break;
-        case 8: hipLaunchKernelGGL((k_spmm_group<G, 8>), dim3(grid), dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL((k_spmm_group<G, 4>), dim3(grid), dim3(256), 0, s, a); break;
-    }
-    return check_launch("k_spmm_group");
-}
-
 }  // namespace
 }  // namespace tgcn
 
@@ -562,16 +484,12 @@ extern "C" int tgcn_spmm_csr_f32(const int32_t *rowptr, const int32_t *colidx, c
     TGCN_REQUIRE(acc_div != 0.0f, "acc_div must be non-zero");
     hipStream_t s = static_cast<hipStream_t>(stream);
 
-    int variant = flags & 0xff;
+    const int variant = flags & 0xff;
     const int unroll = (flags >> 8) & 0xff;
     const bool vec_ok = (d == 64 || d == 128 || d == 256);
-    // measured on MI355X (profiles/r01_spmm_variants.md): the gather is cache-bandwidth bound; wave-per-row with
-    // 16 row loads in flight is as fast as or faster than the group layout on every graph tried
-    if (variant == TGCN_SPMM_AUTO)
-        variant = TGCN_SPMM_WAVE_PER_ROW;
-    if (variant == TGCN_SPMM_GROUP_PER_ROW && !vec_ok)
-        variant = TGCN_SPMM_WAVE_PER_ROW;
-    TGCN_REQUIRE(variant == TGCN_SPMM_WAVE_PER_ROW || variant == TGCN_SPMM_GROUP_PER_ROW, "unknown kernel variant");
+    // one kernel shape: a wave per row with 16 row loads in flight.  (A 16-lane-group-per-row layout was measured within 5 %
+    // on every graph tried and never ahead -- profiles/r01_spmm_variants.md -- and was removed.)
+    TGCN_REQUIRE(variant == TGCN_SPMM_AUTO || variant == TGCN_SPMM_WAVE_PER_ROW, "unknown kernel variant");
 
     SpmmArgs a;
     a.rowptr = rowptr, a.colidx = colidx, a.vals = vals, a.X = X, a.Y = Y;
@@ -596,15 +514,10 @@ extern "C" int tgcn_spmm_csr_f32(const int32_t *rowptr, const int32_t *colidx, c
         hipLaunchKernelGGL(k_spmm_generic, dim3(grid), dim3(256), 0, s, a);
         return check_launch("k_spmm_generic");
     }
-    if (variant == TGCN_SPMM_WAVE_PER_ROW) {
-        a.row_waves = a.n_rows;
+    a.row_waves = a.n_rows;
+    {
         const int grid = (a.row_waves + a.n_chunks + 3) / 4;
         rc = d == 64 ? launch_wave<1>(a, unroll, grid, s) : d == 128 ? launch_wave<2>(a, unroll, grid, s) : launch_wave<4>(a, unroll, grid, s);
-    } else {
-        const int rows_per_wave = 256 / d;  // 64 / (d/4)
-        a.row_waves = (a.n_rows + rows_per_wave - 1) / rows_per_wave;
-        const int grid = (a.row_waves + a.n_chunks + 3) / 4;
-        rc = d == 64 ? launch_group<16>(a, unroll, grid, s) : d == 128 ? launch_group<32>(a, unroll, grid, s) : launch_group<64>(a, unroll, grid, s);
     }
     if (rc != TGCN_OK)
         return rc;

@@ -258,8 +258,6 @@ class Propagator:
         self.csr = DeviceCSR(graph.rowptr, graph.colidx, graph.vals, graph.n, self.device, split_threshold,
                              block_specs=specs, segment=segment)
         self._buf = {}
-        self._graphs = {}
-        self._graph_out = {}
 
     def buffers(self, d):
         if d not in self._buf:
@@ -302,24 +300,3 @@ class Propagator:
                 layers.append(y)
             x = y
         return (out, layers) if keep_layers else out
-
-    def forward_graphed(self, e0, n_layers, single=False, exact=False, out=None):
-        """The same K launches captured once into a HIP graph and replayed (torch.cuda.CUDAGraph): for graphs small
-        enough that a layer takes microseconds, the forward is launch-bound and replay removes the per-launch host
-        cost.  The C ABI is capture-safe (no allocation, no synchronisation).  e0 / out must keep their addresses
-        between calls; the captured graph is cached per (e0, out, K, mode)."""
-        n = self.graph.n
-        _check_dense(e0, 'e0', self.device, n)
-        if out is None:
-            out = self._graph_out.setdefault((e0.shape[1],), torch.empty_like(e0))
-        key = (e0.data_ptr(), out.data_ptr(), e0.shape[1], n_layers, single, exact)
-        g = self._graphs.get(key)
-        if g is None:
-            self.forward(e0, n_layers, single=single, exact=exact, out=out)      # warm-up: buffers, plans, lazy module load
-            torch.cuda.synchronize(self.device)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self.forward(e0, n_layers, single=single, exact=exact, out=out)
-            self._graphs[key] = g
-        g.replay()
-        return out

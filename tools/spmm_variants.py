@@ -21,7 +21,7 @@ def main():
     ap.add_argument('--zipf', type=float, default=0.8)
     ap.add_argument('--rounds', type=int, default=10)
     ap.add_argument('--thresholds', type=int, nargs='*', default=[0, 512, 2048, 8192])
-    ap.add_argument('--variants', type=str, nargs='*', default=['1:4', '1:8', '1:16', '2:2', '2:4', '2:8'])
+    ap.add_argument('--variants', type=str, nargs='*', default=['1:4', '1:8', '1:16'])
     args = ap.parse_args()
     n_u, n_i, nnz, d, K = synth.CONFIGS[args.config]
     t0 = time.time()
