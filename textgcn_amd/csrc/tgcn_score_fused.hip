@@ -39,6 +39,15 @@ constexpr int kUsersPerWG = 128;   // 4 waves x 32 users
 constexpr int kStage = 64;         // items per LDS stage (2 MFMA sub-tiles of 32)
 constexpr int kSmallI = 8192;      // below this the dense path (score -> mask -> top-k) is used
 
+#ifdef TGCN_FILTER_PROBE
+// diagnostic build only (tools/filter_probe.py compiles its own copy with -DTGCN_FILTER_PROBE; never in libtgcn.so): per
+// workgroup, shader-clock stamps around the phases of the filter kernel.  The values go to a buffer nothing else reads.
+__device__ unsigned long long g_probe[4 * 16384];
+#define TGCN_PROBE(slot) do { if (threadIdx.x == 0) g_probe[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) % 16384 * 4 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TGCN_PROBE(slot) do { } while (0)
+#endif
+
 struct FilterArgs {
     const float *__restrict__ U;
     const int64_t *__restrict__ user_ids;
@@ -267,16 +276,25 @@ __device__ __forceinline__ void filter_pipelined(const FilterArgs &a)
     const int i_end = min(a.I, i_beg + a.items_per_split);
     // prologue: the 128-user tile (gathered through user_ids) and the first item stage are requested together -- one
     // global round trip for the ids, one for all the rows -- then the users pass through LDS into registers
+    TGCN_PROBE(0);
     const int user = u0 + w * 32 + r32;
     const bool user_ok = user < a.B;
     float4 nxt[(ST * DQ) / 256];
     float2 bf[DQ];
-    {
+    if constexpr (DQ <= 16) {
         float4 v[(kUsersPerWG * DQ) / 256];
         load_rows<DQ, FULLK, kUsersPerWG>(v, a.U, a.user_ids, u0, a.B, a.d);
         if (i_beg < i_end)
             load_rows<DQ, FULLK, ST>(nxt, a.It, nullptr, i_beg, i_end, a.d);
         store_rows<DQ, kUsersPerWG>(smem, v);
+    } else {   // d = 128: the tile in two halves (64 VGPRs of staging at once would spill)
+        float4 v[(kStage * DQ) / 256];
+        load_rows<DQ, FULLK>(v, a.U, a.user_ids, u0, a.B, a.d);
+        store_rows<DQ>(smem, v);
+        load_rows<DQ, FULLK>(v, a.U, a.user_ids, u0 + kStage, a.B, a.d);
+        if (i_beg < i_end)
+            load_rows<DQ, FULLK, ST>(nxt, a.It, nullptr, i_beg, i_end, a.d);
+        store_rows<DQ>(smem + kStage * ROW, v);
     }
     const float tau = user_ok ? a.tau[(size_t)user * a.tau_stride] : INFINITY;
     __syncthreads();
@@ -296,6 +314,7 @@ __device__ __forceinline__ void filter_pipelined(const FilterArgs &a)
     }
     store_rows<DQ, ST>(smem, nxt);
     __syncthreads();
+    TGCN_PROBE(1);
     int buf = 0;
     const int cap2 = a.cap2;
 
@@ -347,20 +366,24 @@ __device__ __forceinline__ void filter_pipelined(const FilterArgs &a)
                 const int t0 = (g * QB + q) * 2;  // 2*DQ test slots per unit; one of every kSlotsPerReg is used
                 c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[g & 1][q].x, b2.x, c0, 0, 0, 0);
                 c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[g & 1][q].x, b2.x, c1, 0, 0, 0);
+#if !defined(TGCN_FILTER_PROBE) || TGCN_FILTER_PROBE != 2      // probe build 2: the GEMM loop without its tests
                 if constexpr (PREV) {
                     if (t0 % kSlotsPerReg == 0) {  // folded: the loops are fully unrolled
                         const int reg = t0 / kSlotsPerReg, r = reg & 15;
                         test(reg < 16 ? p0[r] : p1[r], s_prev + (reg < 16 ? 0 : 32) + (r & 3) + 8 * (r >> 2) + 4 * h);
                     }
                 }
+#endif
                 c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[g & 1][q].y, b2.y, c0, 0, 0, 0);
                 c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[g & 1][q].y, b2.y, c1, 0, 0, 0);
+#if !defined(TGCN_FILTER_PROBE) || TGCN_FILTER_PROBE != 2
                 if constexpr (PREV) {
                     if ((t0 + 1) % kSlotsPerReg == 0) {
                         const int reg = (t0 + 1) / kSlotsPerReg, r = reg & 15;
                         test(reg < 16 ? p0[r] : p1[r], s_prev + (reg < 16 ? 0 : 32) + (r & 3) + 8 * (r >> 2) + 4 * h);
                     }
                 }
+#endif
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -412,22 +435,23 @@ __device__ __forceinline__ void filter_pipelined(const FilterArgs &a)
         }
         unit(T{}, T{}, EvenLast{}, A0, A1, B0, B1, s_prev, s0, 0);
     }
+    TGCN_PROBE(2);
+#ifdef TGCN_FILTER_PROBE
+    if (threadIdx.x == 0)   // where it ran: HW_ID (cu / sh / se) and the XCC id
+        g_probe[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) % 16384 * 4 + 3] =
+            ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+#endif
     if (user_ok)
         a.counts[((size_t)user * a.S + split) * 2 + h] = cnt;
 }
 
-// register budgets: d <= 64 fits 3 waves per SIMD (168 VGPRs), d <= 128 two
+// register budgets: two waves per SIMD (two workgroups per CU) for both widths.  A 2048-user call is 512 workgroups = exactly
+// two per CU (measured placement: 256 CUs x 2), so a third resident workgroup buys nothing there and the 168-VGPR cap it
+// needs made the d <= 64 kernel spill.
 template <bool FULLK>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_score_filter16(const FilterArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_score_filter16(const FilterArgs a)
 {
     filter_pipelined<16, FULLK, kStage>(a);
-}
-
-// d <= 64 with 128-item LDS stages: one barrier per 128 MFMAs instead of per 64 (two workgroups per CU either way)
-template <bool FULLK>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_score_filter16x2(const FilterArgs a)
-{
-    filter_pipelined<16, FULLK, 2 * kStage>(a);
 }
 
 template <bool FULLK>
@@ -908,9 +932,6 @@ int brute_lds_opt_in()
     return TGCN_OK;
 }
 
-int g_filter_variant = 0;
-int filter_variant() { return g_filter_variant; }
-
 template <int DQ>
 int launch_filter(const FilterArgs &a, hipStream_t s)
 {
@@ -927,8 +948,12 @@ int launch_filter(const FilterArgs &a, hipStream_t s)
 
 using namespace tgcn;
 
-// development switch (not declared in tgcn.h): selects the filter kernel variant for A/B timing inside one process
-extern "C" void tgcn_dev_set_filter_variant(int v) { g_filter_variant = v; }
+#ifdef TGCN_FILTER_PROBE
+extern "C" int tgcn_probe_read(void *host, int64_t bytes)
+{
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_probe), (size_t)bytes) == hipSuccess ? 0 : -2;
+}
+#endif
 
 extern "C" int64_t tgcn_score_topk_workspace_bytes(int32_t B, int32_t I, int32_t d, int32_t k)
 {
@@ -1010,9 +1035,7 @@ extern "C" int tgcn_score_topk_f32(const float *U, const int64_t *user_ids, int3
     fa.B = B, fa.I = I, fa.d = d, fa.S = p.S, fa.items_per_split = p.items_per_split, fa.cap2 = p.cap2;
     if (d <= 128) {
         const dim3 grid((B + kUsersPerWG - 1) / kUsersPerWG, p.S);
-        if (d == 64 && filter_variant() == 1)
-            hipLaunchKernelGGL((k_score_filter16x2<true>), grid, dim3(256), 0, s, fa);
-        else if (d == 64)
+        if (d == 64)
             hipLaunchKernelGGL((k_score_filter16<true>), grid, dim3(256), 0, s, fa);
         else if (d < 64)
             hipLaunchKernelGGL((k_score_filter16<false>), grid, dim3(256), 0, s, fa);
