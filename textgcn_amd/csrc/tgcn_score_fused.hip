@@ -76,22 +76,11 @@ __device__ __forceinline__ void load_rows(float4 (&v)[(ROWS * DQ) / 256], const 
     // source rows first -- ALL the id loads of a gathered tile in one batch, then all the row loads: with the id fetch and
     // its row fetch written per element, hipcc emits N dependent (id -> wait -> row -> wait) round trips (16 of them in the
     // user-tile prologue of the filter kernels, ~10 % of a 2048-user launch)
-    int64_t srow[N];
-    if (ids) {
-#pragma unroll
-        for (int i = 0; i < N; ++i)
-            srow[i] = ids[min(row0 + (i * 256 + (int)threadIdx.x) / DQ, n_rows - 1)];
-    } else {
-#pragma unroll
-        for (int i = 0; i < N; ++i)
-            srow[i] = min(row0 + (i * 256 + (int)threadIdx.x) / DQ, n_rows - 1);
-    }
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
+    auto fetch = [&](int i, size_t srow) {
         const int f = i * 256 + threadIdx.x;
         const int r = f / DQ, q = f % DQ;
         const int row = row0 + r, k = q * 4;
-        const float *p = src + (size_t)srow[i] * d;
+        const float *p = src + srow * d;
         if constexpr (FULLK) {
             v[i] = *reinterpret_cast<const float4 *>(p + k);
         } else {
@@ -101,6 +90,19 @@ __device__ __forceinline__ void load_rows(float4 (&v)[(ROWS * DQ) / 256], const 
             v[i].z = (ok && k + 2 < d) ? p[k + 2] : 0.0f;
             v[i].w = (ok && k + 3 < d) ? p[k + 3] : 0.0f;
         }
+    };
+    if (ids) {
+        int64_t srow[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            srow[i] = ids[min(row0 + (i * 256 + (int)threadIdx.x) / DQ, n_rows - 1)];
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            fetch(i, (size_t)srow[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            fetch(i, (size_t)min(row0 + (i * 256 + (int)threadIdx.x) / DQ, n_rows - 1));
     }
 }
 
@@ -281,13 +283,8 @@ __device__ __forceinline__ void filter_pipelined(const FilterArgs &a)
     const bool user_ok = user < a.B;
     float4 nxt[(ST * DQ) / 256];
     float2 bf[DQ];
-    if constexpr (DQ <= 16) {
-        float4 v[(kUsersPerWG * DQ) / 256];
-        load_rows<DQ, FULLK, kUsersPerWG>(v, a.U, a.user_ids, u0, a.B, a.d);
-        if (i_beg < i_end)
-            load_rows<DQ, FULLK, ST>(nxt, a.It, nullptr, i_beg, i_end, a.d);
-        store_rows<DQ, kUsersPerWG>(smem, v);
-    } else {   // d = 128: the tile in two halves (64 VGPRs of staging at once would spill)
+    {   // the tile in two 64-row halves (one batch of id loads and one of row loads each): a 128-row staging array costs the
+        // d <= 64 kernel its third wave per SIMD (spills at the 168-register budget)
         float4 v[(kStage * DQ) / 256];
         load_rows<DQ, FULLK>(v, a.U, a.user_ids, u0, a.B, a.d);
         store_rows<DQ>(smem, v);
@@ -445,11 +442,11 @@ __device__ __forceinline__ void filter_pipelined(const FilterArgs &a)
         a.counts[((size_t)user * a.S + split) * 2 + h] = cnt;
 }
 
-// register budgets: two waves per SIMD (two workgroups per CU) for both widths.  A 2048-user call is 512 workgroups = exactly
-// two per CU (measured placement: 256 CUs x 2), so a third resident workgroup buys nothing there and the 168-VGPR cap it
-// needs made the d <= 64 kernel spill.
+// register budgets: d <= 64 fits 3 waves per SIMD (168 VGPRs), d <= 128 two.  A 2048-user call alone is 512 workgroups = two
+// per CU (measured placement: 256 CUs x 2); the third slot is what lets the filter launches of consecutive calls on different
+// streams overlap, and a SIMD with three waves keeps its matrix pipe busier than one with two (16 384-user calls: 0.60).
 template <bool FULLK>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_score_filter16(const FilterArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_score_filter16(const FilterArgs a)
 {
     filter_pipelined<16, FULLK, kStage>(a);
 }
