@@ -1,22 +1,30 @@
 #!/bin/bash
 # Collect the round's profile evidence on the GPU box (run from the repo root):
-#     bash tools/profile_round.sh gpurun_out/final
+#     bash tools/profile_round.sh gpurun_out/prof
 # then, back in the build container:
-#     python tools/summarize_profiles.py --round r01 --kt gpurun_out/final/kt --pmc gpurun_out/final/pmc
-# One kernel-trace pass of the default bench.py run, then one PMC pass per counter set (each in its own run, as
-# MI355X_MICROARCH.md prescribes) of the bench and of the known-traffic calibration launch.
+#     python tools/summarize_profiles.py --round r02 --kt gpurun_out/prof/kt --pmc gpurun_out/prof/pmc_c2 --workload c2   (and c3, c4)
+# One kernel-trace pass of the default bench.py run, then one PMC pass per counter set and workload (each in its own run, as
+# MI355X_MICROARCH.md prescribes) and of the known-traffic calibration launch.
 set -o pipefail
-out=${1:-gpurun_out/final}
+out=${1:-gpurun_out/prof}
+workloads=${2:-"c2 c3 c4"}
 root=$(pwd)
-mkdir -p "$out/pmc"
+mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$root" || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -- python bench.py --no-cpu-baseline > "$out/kt.log" 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -- python bench.py --steps 20 --warmup 5 > "$out/kt.log" 2>&1 || exit 1
 echo "kernel trace done"
-for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
-    name=${c// /_}
-    # shellcheck disable=SC2086
-    rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$out/pmc/bench_$name" -- python bench.py --steps 5 --warmup 2 --no-scoring --no-cpu-baseline > "$out/pmc/bench_$name.log" 2>&1 || exit 1
-    # shellcheck disable=SC2086
-    rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$out/pmc/cal_$name" -- python tools/pmc_calibrate.py > "$out/pmc/cal_$name.log" 2>&1 || exit 1
-    echo "pmc $name done"
+for wl in $workloads; do
+    mkdir -p "$out/pmc_$wl"
+    steps=5; [ "$wl" = c4 ] && steps=2
+    for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+        name=${c// /_}
+        # shellcheck disable=SC2086
+        rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$out/pmc_$wl/bench_$name" -- python bench.py --workload $wl --sub none --steps $steps --warmup 1 --no-scoring --no-cpu-baseline > "$out/pmc_$wl/bench_$name.log" 2>&1 || exit 1
+        echo "pmc $wl $name done"
+    done
 done
+mkdir -p "$out/pmc_c2"
+for c in "FETCH_SIZE" "WRITE_SIZE"; do
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$out/pmc_c2/cal_$c" -- python tools/pmc_calibrate.py > "$out/pmc_c2/cal_$c.log" 2>&1 || exit 1
+done
+echo "calibration done"

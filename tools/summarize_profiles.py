@@ -13,11 +13,22 @@ import argparse
 import collections
 import csv
 import glob
+import hashlib
 import json
 import os
 import shutil
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+SPMM_SOURCES = ('textgcn_amd/csrc/tgcn_spmm.hip', 'textgcn_amd/propagate.py', 'textgcn_amd/graph.py')   # as bench.py
+
+
+def spmm_sources_sha16():
+    h = hashlib.sha256()
+    for f in SPMM_SOURCES:
+        h.update(open(os.path.join(ROOT, f), 'rb').read())
+    return h.hexdigest()[:16]
 
 
 def short(name):
@@ -88,7 +99,9 @@ def main():
                    'fetch_size_kib_raw': fetch_kib, 'write_size_kib_raw': write_kib, 'kernels': spmm,
                    'correction': "FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B), WRITE_SIZE x1; the counters sit on "
                                  "the L2's memory side, so Infinity-Cache hits are included (this is L2-miss traffic)",
-                   'calibration': cal, 'round': args.round}
+                   'calibration': cal, 'round': args.round,
+                   # bench.py withholds the figure when the SpMM sources no longer hash to this
+                   'sources_sha16': spmm_sources_sha16()}
         hits = summary.get('bench_TCC_HIT_sum_TCC_MISS_sum', {}).get(k)
         if hits:
             h, m = hits['TCC_HIT_sum']['mean'], hits['TCC_MISS_sum']['mean']
@@ -98,7 +111,7 @@ def main():
         cur[args.workload] = traffic
         json.dump(cur, open(tf, 'w'), indent=1)
         print(json.dumps(traffic, indent=1))
-    json.dump(summary, open(os.path.join(prof, f'{args.round}_pmc.json'), 'w'), indent=1)
+    json.dump(summary, open(os.path.join(prof, f'{args.round}_pmc_{args.workload}.json'), 'w'), indent=1)
 
 
 if __name__ == '__main__':
