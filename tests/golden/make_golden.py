@@ -532,6 +532,25 @@ def g9_metrics(work):
          ks=np.asarray(ks, dtype=np.int64), **{f'metric_{m}': np.asarray(v, dtype=np.float64) for m, v in res.items()})
 
 
+# --------------------------------------------------------------------------- G10: --reshuffle
+def g10_reshuffle(work, data):
+    """BaseDataset with --reshuffle (dataset.py:40-44,63-87) on the synth-60x40 files: the re-split train / test rows."""
+    import pandas as pd
+    args = run_args(['--model', 'lgcn', '--no_train', '-k', '5', '--reshuffle', '--seed', '0'], data, work)
+    ds = TextGCN.BaseDataset(args)
+    folder = os.path.join(data, 'reshuffle_0')
+    tr = pd.read_table(os.path.join(folder, 'train.tsv'), dtype=str)
+    te = pd.read_table(os.path.join(folder, 'test.tsv'), dtype=str)
+    src_tr = pd.read_table(os.path.join(data, 'train.tsv'), dtype=str)
+    src_te = pd.read_table(os.path.join(data, 'test.tsv'), dtype=str)
+    save('g10_reshuffle.npz', in_train_user=src_tr['user_id'].values.astype('U16'), in_train_item=src_tr['asin'].values.astype('U16'),
+         in_test_user=src_te['user_id'].values.astype('U16'), in_test_item=src_te['asin'].values.astype('U16'),
+         train_user=tr['user_id'].values.astype('U16'), train_item=tr['asin'].values.astype('U16'),
+         test_user=te['user_id'].values.astype('U16'), test_item=te['asin'].values.astype('U16'),
+         n_users=np.int64(ds.n_users), n_items=np.int64(ds.n_items))
+    shutil.rmtree(folder, ignore_errors=True)
+
+
 def main():
     work = tempfile.mkdtemp(prefix='tgcn_golden_')
     try:
@@ -546,6 +565,8 @@ def main():
             g8_loss(work, data60)
         if ONLY in (None, 'g9'):
             g9_metrics(work)
+        if ONLY in (None, 'g10'):
+            g10_reshuffle(work, data60)
         if ONLY is None:
             g5_medium(work)
             g6_builder(work)

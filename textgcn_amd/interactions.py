@@ -25,14 +25,39 @@ def _read_pairs(path):
     return df.sort_values(by=['user_id', 'asin'], kind='stable').reset_index(drop=True)
 
 
+def reshuffle_train_test(path, seed, train_size=0.8, logger=None):
+    """`--reshuffle` (TextGCN/dataset.py:63-87): pool train.tsv + test.tsv, keep users with at least 3 rows, split 80/20
+    stratified by user (sklearn train_test_split, random_state = seed), sort, drop test rows whose item never occurs in the new
+    train split, and write both files to <path>/reshuffle_<seed>/ (reused by later runs, dataset.py:41-44).  Returns the
+    folder."""
+    from sklearn.model_selection import train_test_split
+    folder = os.path.join(path, f'reshuffle_{seed}')
+    if logger:
+        logger.info('reshuffling train-test')
+    os.makedirs(folder, exist_ok=True)
+    df = pd.concat([pd.read_table(os.path.join(path, 'train.tsv'), dtype=str), pd.read_table(os.path.join(path, 'test.tsv'), dtype=str)])
+    sizes = df.groupby('user_id').size()
+    df = df[df['user_id'].isin(sizes[sizes >= 3].index)]
+    train, test = train_test_split(df, stratify=df['user_id'], train_size=train_size, random_state=seed)
+    train = train.sort_values(by=['user_id', 'asin']).reset_index(drop=True)
+    test = test.sort_values(by=['user_id', 'asin']).reset_index(drop=True)
+    test = test[test['asin'].isin(train['asin'].unique())]
+    train.to_csv(os.path.join(folder, 'train.tsv'), sep='\t', index=False)
+    test.to_csv(os.path.join(folder, 'test.tsv'), sep='\t', index=False)
+    return folder
+
+
 class InteractionData(Dataset):
-    def __init__(self, params=None, folder=None, k=None, neg_samples=1, seed=0, logger=None):
+    def __init__(self, params=None, folder=None, k=None, neg_samples=1, seed=0, logger=None, reshuffle=None):
         folder = folder if folder is not None else params.data
         self.path = folder
         self.logger = logger if logger is not None else getattr(params, 'logger', None)
         self.neg_samples = getattr(params, 'neg_samples', neg_samples)
         self.seed = getattr(params, 'seed', seed)
         k = k if k is not None else getattr(params, 'k', None)
+        if reshuffle if reshuffle is not None else getattr(params, 'reshuffle', False):   # dataset.py:40-44
+            sub = os.path.join(folder, f'reshuffle_{self.seed}')
+            folder = sub if os.path.exists(os.path.join(sub, 'train.tsv')) else reshuffle_train_test(folder, self.seed, logger=self.logger)
 
         train = _read_pairs(os.path.join(folder, 'train.tsv'))
         test = _read_pairs(os.path.join(folder, 'test.tsv'))
