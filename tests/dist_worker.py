@@ -49,6 +49,8 @@ def main():
     ap.add_argument('--balance', default='nnz')
     ap.add_argument('--chunks', type=int, default=1)
     ap.add_argument('--collective', default='torch')
+    ap.add_argument('--sample', type=int, default=0, help='save only this many seeded sample rows of each table (large graphs)')
+    ap.add_argument('--graph-seed', type=int, default=1)
     args = ap.parse_args()
 
     from textgcn_amd import synth
@@ -61,7 +63,7 @@ def main():
                                 device_id=torch.device('cuda', 0))
     else:
         dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{args.port}', rank=args.rank, world_size=args.world)
-    u, i = synth.interactions(args.n_users, args.n_items, args.nnz, seed=1)
+    u, i = synth.interactions(args.n_users, args.n_items, args.nnz, seed=args.graph_seed)
     g = NormGraph.from_pairs(u, i, args.n_users, args.n_items)
     e0 = synth.embeddings(g.n, args.d, seed=2)
     if args.mode == 'cpu':
@@ -75,10 +77,21 @@ def main():
         sp = ShardedPropagator(g, args.rank, args.world, 'cuda:0', split_threshold=64, balance=args.balance, chunks=args.chunks)
     eu, ei = sp.local_e0(e0)
     users_local, items_full = sp.forward(eu, ei, args.layers, single=args.single, exact=(args.mode == 'cpu'))
-    users_full = sp.gather_users(users_local)
-    if args.rank == 0:
-        np.savez(args.out, users=users_full.cpu().numpy(), items=sp.items_in_order(items_full).cpu().numpy(),
-                 nnz_local=sp.nnz_local, user_bounds=sp.lay_u.bounds, item_bounds=sp.lay_i.bounds)
+    if args.sample:      # large graphs: seeded sample rows of rank 0's own users and of the gathered item table
+        rng = np.random.default_rng(123)
+        u0, u1 = sp.user_range()
+        su = np.sort(rng.choice(u1 - u0, size=min(args.sample, u1 - u0), replace=False))
+        si = np.sort(rng.choice(args.n_items, size=min(args.sample, args.n_items), replace=False))
+        if args.rank == 0:
+            dev = users_local.device
+            items_rows = items_full[torch.from_numpy(sp.lay_i.table_rows(si)).to(dev)]
+            np.savez(args.out, users=users_local[torch.from_numpy(su).to(dev)].cpu().numpy(), items=items_rows.cpu().numpy(),
+                     user_rows=su + u0, item_rows=si, nnz_local=sp.nnz_local, user_bounds=sp.lay_u.bounds, item_bounds=sp.lay_i.bounds)
+    else:
+        users_full = sp.gather_users(users_local)
+        if args.rank == 0:
+            np.savez(args.out, users=users_full.cpu().numpy(), items=sp.items_in_order(items_full).cpu().numpy(),
+                     nnz_local=sp.nnz_local, user_bounds=sp.lay_u.bounds, item_bounds=sp.lay_i.bounds)
     sp.close()
     dist.barrier()
     dist.destroy_process_group()

@@ -89,3 +89,24 @@ def test_c4_row_partition_arithmetic(c4):
     assert rows.max() < lay.n_pad and len(np.unique(rows)) == gr.n_items
     assert lay.n_pad <= 1.1 * gr.n_items                          # padding to the largest block costs < 10 %
     assert (lay.n_pad + BlockLayout(ub, chunks=4).n_pad) * d * 4 < 2 ** 32   # 32-bit byte offsets of the segmented kernel not needed, but fit
+
+
+def test_c4_two_rank_sharded_forward_equals_single_gpu(cuda, c4, tmp_path):
+    """Config 4 itself through the sharded path: two ranks on the one GPU (gloo staged through the host -- the rehearsal
+    form; the driver's 8-GPU run uses RCCL), nnz-balanced blocks, 4 row chunks per block as bench.py uses.  Sampled rows of
+    rank 0's users and of the gathered item table must carry the single-GPU bits."""
+    from test_dist_cpu import run_ranks
+    from textgcn_amd.propagate import Propagator
+    gr, e0, d, K = c4
+    out = str(tmp_path / 'r0.npz')
+    # the worker draws E0 with seed 2; the graph is synth seed 0 as in the fixture
+    run_ranks(2, 'gpu', out, extra=('--n-users', str(gr.n_users), '--n-items', str(gr.n_items), '--nnz', '100000000', '--graph-seed', '0',
+                                    '--balance', 'nnz', '--chunks', '4', '--sample', '2000'))
+    got = np.load(out)
+    from textgcn_amd import synth
+    e0w = synth.embeddings(gr.n, d, seed=2).to(cuda)
+    ref = Propagator(gr, cuda, split_threshold=64, segment=None).forward(e0w, K)
+    ur = torch.from_numpy(got['user_rows']).to(cuda)
+    ir = torch.from_numpy(got['item_rows'] + gr.n_users).to(cuda)
+    assert np.array_equal(bits(got['users']), bits(ref[ur].cpu().numpy()))
+    assert np.array_equal(bits(got['items']), bits(ref[ir].cpu().numpy()))

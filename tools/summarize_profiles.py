@@ -41,9 +41,17 @@ def pmc_table(d):
     files = glob.glob(os.path.join(d, '*', '*counter_collection.csv')) + glob.glob(os.path.join(d, '*counter_collection.csv'))
     files = [max(files, key=os.path.getmtime)] if files else []   # gpurun merges successive runs into one directory: newest only
     for f in files:
-        for r in csv.DictReader(open(f)):
-            if 'tgcn' in r['Kernel_Name']:
-                out[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
+        rows = [r for r in csv.DictReader(open(f)) if 'tgcn' in r['Kernel_Name']]
+        # bench.py also launches the one-wave-per-row kernel for its live random-row-rate probe (a small grid): the layer
+        # launches of a workload are the dispatches with the largest grid of that kernel
+        biggest = collections.defaultdict(int)
+        for r in rows:
+            biggest[short(r['Kernel_Name'])] = max(biggest[short(r['Kernel_Name'])], int(r['Grid_Size']))
+        for r in rows:
+            k = short(r['Kernel_Name'])
+            if k.startswith('k_spmm_wave') and int(r['Grid_Size']) != biggest[k]:
+                continue
+            out[k][r['Counter_Name']].append(float(r['Counter_Value']))
     return {k: {c: {'n': len(v), 'mean': sum(v) / len(v), 'min': min(v), 'max': max(v)} for c, v in cs.items()}
             for k, cs in out.items()}
 
