@@ -76,3 +76,22 @@ def test_c_abi_rejects_bad_arguments_with_message(built_lib):
     rc = lib.tgcn_score_topk_f32(None, None, 4, None, 100, 64, None, None, 10, 0, None, None, None, 0, None)
     assert rc == -1
     assert lib.tgcn_ltr_folded_width(128, 384) == 960 and lib.tgcn_ltr_folded_width(64, 384) == 896
+    # training-step entries
+    rc = lib.tgcn_dropout_values_f32(None, None, None, 1, 1.5, None, None, None, None, None, 10, 0, None, None, None, None, None)
+    assert rc == -1 and b'keep_prob' in lib.tgcn_last_error()
+    rc = lib.tgcn_dropout_values_f32(None, None, None, 1, 0.6, None, None, None, None, None, 10, 0, None, None, None, None, None)
+    assert rc == -1 and b'NULL' in lib.tgcn_last_error()
+    assert lib.tgcn_dropout_values_f32(None, None, None, 1, 0.6, None, None, None, None, None, 0, 0, None, None, None, None, None) == 0
+    rc = lib.tgcn_bpr_pairs_f32(None, None, None, None, None, 8, 1, 1024, 1.0, None, None, None, None, None)
+    assert rc == -1 and b'd out of range' in lib.tgcn_last_error()
+    rc = lib.tgcn_bpr_pairs_f32(None, None, None, None, None, 8, 0, 64, 1.0, None, None, None, None, None)
+    assert rc == -1
+    assert lib.tgcn_bpr_pairs_f32(None, None, None, None, None, 0, 1, 64, 1.0, None, None, None, None, None) == 0
+    rc = lib.tgcn_reg_rows_f32(None, None, None, None, None, 8, 1, 64, 0.1, None, None, None, None, None)
+    assert rc == -1
+    # collective entries: argument checks come before RCCL is touched
+    rc = lib.tgcn_allgather_rows(None, None, None, 4, 64, None)
+    assert rc == -1 and b'comm is NULL' in lib.tgcn_last_error()
+    rc = lib.tgcn_comm_init_rank(None, 2, 0, None)
+    assert rc == -1
+    assert lib.tgcn_comm_destroy(None) == 0

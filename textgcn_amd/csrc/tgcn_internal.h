@@ -50,6 +50,8 @@ __device__ __forceinline__ float readlane_f(float v, int lane)
 // launchers shared between translation units (arguments already validated by the caller)
 int launch_score_dense(const float *U, const int64_t *user_ids, int B, const float *It, int I, int d, int item_mul, float *S,
                        int64_t lds, hipStream_t stream);
+int launch_score_dense_filter(const float *U, const int64_t *user_ids, int B, const float *It, int I, int d, const float *tau,
+                              int tau_stride, void *logs, int *counts, int S, int items_per_split, int cap2, hipStream_t stream);
 int launch_topk(const float *S, int64_t lds, int B, int I, int k, int do_round, float *out_val, int64_t *out_idx,
                 hipStream_t stream);
 int launch_mask(float *S, int64_t lds, int B, int I, const int *mask_rowptr, const int *mask_items, int item_div,

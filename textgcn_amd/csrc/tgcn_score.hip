@@ -154,6 +154,107 @@ __global__ __launch_bounds__(256) void k_score_dense(const DenseArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
+// dense scores with a threshold epilogue instead of the store (wide operands: the folded ltr_linear GEMM, K = 960).
+// Same tile loop as k_score_dense -- 128 users x 128 items per workgroup, K in chunks of 64 through LDS -- but a workgroup
+// walks ALL the tiles of one item split, and a finished tile's scores are compared with the users' thresholds in registers:
+// a passing (score, item) goes to the user's log of this split, at a position drawn from an LDS counter (0.6 % of the scores
+// pass, so the atomics are rare; log order is immaterial to the selection).  The [B, I] matrix (491 MB per 2048-user batch
+// at config 5) is neither written nor read back.  Logs / counts have the layout k_select reads: [B][S][2][cap2], a split's
+// log filling half 0 then half 1.
+struct DenseFilterArgs {
+    const float *__restrict__ U;
+    const int64_t *__restrict__ user_ids;
+    const float *__restrict__ It;
+    const float *__restrict__ tau;
+    int tau_stride;
+    float2 *__restrict__ logs;
+    int *__restrict__ counts;
+    int B, I, d, S, items_per_split, cap2;
+};
+
+template <bool FULLK>
+__global__ __launch_bounds__(256) void k_score_dense_filter(const DenseFilterArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float smem[2 * kTile * kLdsRow];
+    __shared__ int scnt[kTile];
+    float *ldsU = smem;
+    float *ldsI = smem + kTile * kLdsRow;
+    const int lane = lane_id();
+    const int w = threadIdx.x >> 6;
+    const int r32 = lane & 31;
+    const int h = lane >> 5;
+    const int split = blockIdx.x;
+    const int u0 = blockIdx.y * kTile;
+    const int i_beg = split * a.items_per_split;
+    const int i_end = min(a.I, i_beg + a.items_per_split);
+    if (threadIdx.x < kTile)
+        scnt[threadIdx.x] = 0;
+    // C/D layout: col = lane & 31 (item), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) (user): 16 users per lane
+    float tau_r[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int user = u0 + w * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        tau_r[r] = user < a.B ? a.tau[(size_t)user * a.tau_stride] : INFINITY;
+    }
+    const int cap = 2 * a.cap2;
+    bool first = true;
+    for (int i0 = i_beg; i0 < i_end; i0 += kTile) {
+        f32x16 acc[4];
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                acc[n][r] = 0.0f;
+        for (int k0 = 0; k0 < a.d; k0 += kKC) {
+            if (!first)
+                __syncthreads();
+            first = false;
+            stage_tile<FULLK>(ldsU, a.U, a.user_ids, u0, a.B, k0, a.d);
+            stage_tile<FULLK>(ldsI, a.It, nullptr, i0, a.I, k0, a.d);
+            __syncthreads();
+            const float *pu = ldsU + (w * 32 + r32) * kLdsRow + 2 * h;
+            const float *pi = ldsI + r32 * kLdsRow + 2 * h;
+#pragma unroll 4
+            for (int q = 0; q < kKC / 4; ++q) {
+                const float2 a2 = *reinterpret_cast<const float2 *>(pu + q * 4);
+                float2 b2[4];
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    b2[n] = *reinterpret_cast<const float2 *>(pi + n * 32 * kLdsRow + q * 4);
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.x, b2[n].x, acc[n], 0, 0, 0);
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.y, b2[n].y, acc[n], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int item = i0 + n * 32 + r32;
+            if (item < i_end) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (acc[n][r] > tau_r[r]) {   // tau = +inf for rows past B
+                        const int ul = w * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        const int pos = atomicAdd(&scnt[ul], 1);
+                        if (pos < cap)
+                            a.logs[((size_t)(u0 + ul) * a.S + split) * cap + pos] = make_float2(acc[n][r], __int_as_float(item));
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < kTile && u0 + threadIdx.x < a.B) {
+        const int c = scnt[threadIdx.x];
+        int *out = a.counts + ((size_t)(u0 + threadIdx.x) * a.S + split) * 2;
+        out[0] = min(c, a.cap2);
+        out[1] = c <= a.cap2 ? 0 : (c <= cap ? c - a.cap2 : a.cap2 + 1);   // beyond both halves: reported as an overflow
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // train-item mask: one wave per user row
 // item_div > 1: S holds a strided item sample (column c = item c * item_div); other items are skipped
 __global__ __launch_bounds__(256) void k_mask(float *__restrict__ S, int64_t lds, int B, int I,
@@ -333,6 +434,20 @@ int tgcn::launch_score_dense(const float *U, const int64_t *user_ids, int B, con
     else
         hipLaunchKernelGGL(k_score_dense<false>, grid, dim3(256), 0, stream, a);
     return check_launch("k_score_dense");
+}
+
+int tgcn::launch_score_dense_filter(const float *U, const int64_t *user_ids, int B, const float *It, int I, int d, const float *tau,
+                                    int tau_stride, void *logs, int *counts, int S, int items_per_split, int cap2, hipStream_t stream)
+{
+    TGCN_REQUIRE(items_per_split > 0 && items_per_split % kTile == 0, "items_per_split must be a positive multiple of 128");
+    DenseFilterArgs a{U, user_ids, It, tau, tau_stride, static_cast<float2 *>(logs), counts, B, I, d, S, items_per_split, cap2};
+    const dim3 grid(S, (B + kTile - 1) / kTile);
+    TGCN_REQUIRE(grid.y <= 65535, "B too large for one launch (max 65535*128 rows)");
+    if (d % kKC == 0)
+        hipLaunchKernelGGL(k_score_dense_filter<true>, grid, dim3(256), 0, stream, a);
+    else
+        hipLaunchKernelGGL(k_score_dense_filter<false>, grid, dim3(256), 0, stream, a);
+    return check_launch("k_score_dense_filter");
 }
 
 int tgcn::launch_topk(const float *S, int64_t lds, int B, int I, int k, int do_round, float *out_val, int64_t *out_idx,

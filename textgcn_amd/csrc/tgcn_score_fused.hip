@@ -874,7 +874,7 @@ Plan make_plan(int B, int I, int d, int k)
 {
     (void)k;
     Plan p{};
-    p.small = I <= kSmallI || d > 256;
+    p.small = I <= kSmallI;
     if (p.small) {
         p.off_sample = 0;  // the [B, I] score matrix
         p.total = align256((size_t)B * I * sizeof(float));
@@ -885,7 +885,8 @@ Plan make_plan(int B, int I, int d, int k)
     // workgroups keep the chip evenly loaded); 2048 users: 32 and 48 splits tie.
     const int max_S = max(1, I / (8 * kStage));   // at least 8 stages per split
     const int S = min(32, max_S);
-    p.items_per_split = (((I + S - 1) / S + kStage - 1) / kStage) * kStage;
+    const int gran = d > 256 ? 128 : kStage;   // wide operands walk 128-item tiles (k_score_dense_filter)
+    p.items_per_split = (((I + S - 1) / S + gran - 1) / gran) * gran;
     p.S = (I + p.items_per_split - 1) / p.items_per_split;
     p.cap2 = max(32, 1024 / (2 * p.S));
     p.m = (I + kSampleStride - 1) / kSampleStride;
@@ -1042,7 +1043,8 @@ extern "C" int tgcn_score_topk_f32(const float *U, const int64_t *user_ids, int3
             hipLaunchKernelGGL((k_score_filter32<false>), grid, dim3(256), 0, s, fa);
         rc = check_launch("k_score_filter16/32");
     } else {
-        rc = d <= 64 ? launch_filter<16>(fa, s) : d <= 128 ? launch_filter<32>(fa, s) : launch_filter<64>(fa, s);
+        rc = d <= 64 ? launch_filter<16>(fa, s) : d <= 128 ? launch_filter<32>(fa, s) : d <= 256 ? launch_filter<64>(fa, s)
+            : launch_score_dense_filter(U, user_ids, B, It, I, d, tau_ptr, tau_stride, fa.logs, fa.counts, p.S, p.items_per_split, p.cap2, s);
     }
     if (rc != TGCN_OK)
         return rc;
