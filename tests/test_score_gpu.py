@@ -325,3 +325,20 @@ def test_scoring_at_config5_folded_width(cuda, oracle):
     rv, ri = _oracle_topk_rows(oracle, u, it, rp, items, rows, k)
     assert np.array_equal(idx.cpu().numpy()[rows], ri)
     assert np.array_equal(bits(v.cpu().numpy()[rows]), bits(rv))
+
+
+def test_fused_topk_very_large_catalogue(cuda):
+    """Catalogues beyond 131 072 items (config 4 has 2 M): the threshold comes from the mask + workgroup-per-row top-k on the
+    sample instead of k_tau, and the fallback bookkeeping is cleared by a memset.  Same contract: equal to the dense path."""
+    rng = np.random.default_rng(77)
+    b, i, d, k = 300, 200_000, 64, 40
+    u = (rng.standard_normal((b, d)) * 0.1).astype(np.float32)
+    it = (rng.standard_normal((i, d)) * 0.1).astype(np.float32)
+    _fused_vs_dense(cuda, u, it, k, mask=_rand_mask(rng, b, i, 0, 60))
+    # a user with nearly everything masked -> flagged -> exact fallback with the last-arriver merge on this path too
+    cnt = rng.integers(0, 40, size=b)
+    cnt[0] = i - 25
+    rp = np.zeros(b + 1, dtype=np.int64)
+    np.cumsum(cnt, out=rp[1:])
+    items = np.concatenate([np.sort(rng.choice(i, size=c, replace=False)) for c in cnt])
+    _fused_vs_dense(cuda, u, it, k, mask=(rp, items))

@@ -485,14 +485,19 @@ __device__ __forceinline__ float wave_max_f(float v)
 
 template <int VPL>
 __global__ __launch_bounds__(256) void k_tau(const float *__restrict__ Ss, int m_ld, int B, int m, const int *__restrict__ mask_rowptr,
-                                             const int *__restrict__ mask_items, float *__restrict__ tau, int *__restrict__ flagged)
+                                             const int *__restrict__ mask_items, float *__restrict__ tau, int *__restrict__ flagged,
+                                             int *__restrict__ done)
 {
     extern __shared__ float srow[];   // [4][64 * VPL]
     const int lane = lane_id();
     const int w = threadIdx.x >> 6;
     const int b = blockIdx.x * 4 + w;
+    // this call's fallback bookkeeping starts from zero: the flag count and one arrival counter per user (the workspace is
+    // the caller's and arrives uninitialised); saves the memset node in front of every call
     if (blockIdx.x == 0 && threadIdx.x == 0)
         flagged[0] = 0;
+    if (b < B && lane == 0)
+        done[b] = 0;
     float *row = srow + w * (kWave * VPL);
     const bool ok = b < B;
 #pragma unroll
@@ -999,10 +1004,6 @@ extern "C" int tgcn_score_topk_f32(const float *U, const int64_t *user_ids, int3
     int *done = reinterpret_cast<int *>(ws + p.off_done);
     if ((rc = launch_score_dense(U, user_ids, B, It, p.m, d, kSampleStride, Ss, p.m_ld, s)) != TGCN_OK)
         return rc;
-    // the arrival counters of the fallback are left at zero by every call (the merging workgroup re-zeroes its own), but the
-    // workspace is the caller's and "nothing in it needs initialising": clear them with the flag word
-    if (hipMemsetAsync(flagged, 0, (size_t)(ws + p.off_done - reinterpret_cast<char *>(flagged)) + (size_t)p.flag_cap * sizeof(int), s) != hipSuccess)
-        return check_launch("hipMemsetAsync(flagged, done)");
     const float *tau_ptr;
     int tau_stride;
     if (p.m <= 64 * kWave) {   // one wave per user: mask + rank-kTauRank selection in one launch
@@ -1010,15 +1011,18 @@ extern "C" int tgcn_score_topk_f32(const float *U, const int64_t *user_ids, int3
         const int vpl = p.m <= 8 * kWave ? 8 : p.m <= 16 * kWave ? 16 : p.m <= 32 * kWave ? 32 : 64;
         const size_t lds = (size_t)4 * kWave * vpl * sizeof(float);
         switch (vpl) {
-            case 8: hipLaunchKernelGGL((k_tau<8>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, tau1, flagged); break;
-            case 16: hipLaunchKernelGGL((k_tau<16>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, tau1, flagged); break;
-            case 32: hipLaunchKernelGGL((k_tau<32>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, tau1, flagged); break;
-            default: hipLaunchKernelGGL((k_tau<64>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, tau1, flagged); break;
+            case 8: hipLaunchKernelGGL((k_tau<8>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, tau1, flagged, done); break;
+            case 16: hipLaunchKernelGGL((k_tau<16>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, tau1, flagged, done); break;
+            case 32: hipLaunchKernelGGL((k_tau<32>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, tau1, flagged, done); break;
+            default: hipLaunchKernelGGL((k_tau<64>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, tau1, flagged, done); break;
         }
         if ((rc = check_launch("k_tau")) != TGCN_OK)
             return rc;
         tau_ptr = tau1, tau_stride = 1;
     } else {                   // very large catalogues (> 131 072 items): mask + workgroup-per-row top-k on the sample
+        // the fallback's flag count and arrival counters start from zero (the workspace arrives uninitialised)
+        if (hipMemsetAsync(flagged, 0, (size_t)(ws + p.off_done - reinterpret_cast<char *>(flagged)) + (size_t)p.flag_cap * sizeof(int), s) != hipSuccess)
+            return check_launch("hipMemsetAsync(flagged, done)");
         if (mask_rowptr && (rc = launch_mask(Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, kSampleStride, s)) != TGCN_OK)
             return rc;
         if ((rc = launch_topk(Ss, p.m_ld, B, p.m, kTauRank, 0, tauv, taui, s)) != TGCN_OK)
