@@ -458,6 +458,28 @@ def records_c3_c5(dev, want_c5=True, cpu=True):
     return out
 
 
+def record_train_step(dev, u, i, graph, n_u, n_i, d, K, steps=10):
+    """One BPR training step through the MODEL CLASS as `fit` issues it (get_loss -> backward -> fused Adam), dropout 0.4 drawn
+    on the device: SURVEY.md §8(f) N1.  Wall time per step (the step has one host sync, the NaN check)."""
+    from textgcn_amd.model import LightGCN
+    ds = _model_dataset(u, i, n_u, n_i, graph)
+    p = types.SimpleNamespace(k=[20, 40], emb_size=d, n_layers=K, device=dev, load=None, batch_size=2048, quiet=True, dropout=0.4,
+                              lr=1e-3)
+    m = LightGCN(p, ds)
+    m.optimizer = torch.optim.Adam(m.parameters(), lr=1e-3, fused=True)
+    rng = np.random.default_rng(0)
+    batch = torch.from_numpy(np.stack([rng.integers(0, n_u, 2048), rng.integers(0, n_i, 2048), rng.integers(0, n_i, 2048)], axis=1))
+    m._train_epoch([batch] * 3, 0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    m._train_epoch([batch] * steps, 0)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    return {'metric': 'BPR training step: dropout values + K-layer forward + pair loss + transposed backward + Adam, batch 2048',
+            'ms_per_step': ms, 'steps': steps, 'native_loss_node': bool(m._native_loss()),
+            'through': 'textgcn_amd.LightGCN._train_epoch (get_loss -> backward -> optimizer.step, as fit() does)'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -471,7 +493,7 @@ def main():
     ap.add_argument('--score-batch-size', type=int, default=2048, help='users per scoring call (reference batch_size = 2048)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-scoring', action='store_true')
-    ap.add_argument('--sub', default=None, help="comma list of sub-records at N = 1: c4,c3,c5 (default: all for the default "
+    ap.add_argument('--sub', default=None, help="comma list of sub-records at N = 1: c4,c3,c5,train (default: all for the default "
                                                 "workload, none otherwise); 'none' to skip")
     ap.add_argument('--chunks', type=int, default=None, help='row chunks per block for the pipelined all-gather (N > 1)')
     ap.add_argument('--balance', default='nnz', choices=['nnz', 'rows'])
@@ -636,8 +658,10 @@ def main():
 
     # ---------------- the other single-GPU configurations (N = 1)
     if world == 1:
-        sub = args.sub if args.sub is not None else ('c4,c3,c5' if default_wl else 'none')
+        sub = args.sub if args.sub is not None else ('c4,c3,c5,train' if default_wl else 'none')
         sub = [] if sub == 'none' else [s.strip() for s in sub.split(',') if s.strip()]
+        if 'train' in sub:
+            result['training'] = record_train_step(dev, u, i, graph, n_u, n_i, d, K)
         del prop, e0d, out
         if not args.no_scoring:
             del ue, ie
