@@ -151,3 +151,30 @@ class InteractionData(Dataset):
             self._draw_epoch()
         self._served += 1
         return torch.from_numpy(self._epoch[idx])
+
+    def batches(self, batch_size, shuffle=True):
+        """What `fit()` iterates over (main.py:35 builds `DataLoader(dataset, batch_size, shuffle=True)` and hands it to
+        `model.fit`, main.py:40) without the per-sample Python round trip of a DataLoader over `__getitem__`: a re-iterable
+        whose every pass draws a fresh epoch of triples (same sampler contract) and yields [batch, 2 + neg_samples] int64
+        tensors cut from it in one piece.  On config 2 a DataLoader batch costs ~10 ms of host time against a 1.4 ms
+        training step."""
+        return _EpochBatches(self, int(batch_size), bool(shuffle))
+
+
+class _EpochBatches:
+    def __init__(self, data, batch_size, shuffle):
+        self.data, self.batch_size, self.shuffle = data, batch_size, shuffle
+
+    def __len__(self):
+        return -(-self.data.iterable_len // self.batch_size)
+
+    def __iter__(self):
+        d = self.data
+        d._draw_epoch()
+        rows = d._epoch
+        d._served = d.iterable_len          # the epoch is consumed here, not through __getitem__
+        if self.shuffle:
+            rows = rows[d._rng.permutation(len(rows))]
+        table = torch.from_numpy(np.ascontiguousarray(rows))
+        for j in range(0, len(table), self.batch_size):
+            yield table[j:j + self.batch_size]
