@@ -497,6 +497,9 @@ def main():
                                                 "workload, none otherwise); 'none' to skip")
     ap.add_argument('--chunks', type=int, default=None, help='row chunks per block for the pipelined all-gather (N > 1)')
     ap.add_argument('--balance', default='nnz', choices=['nnz', 'rows'])
+    ap.add_argument('--force-sharded', action='store_true',
+                    help='N = 1 only: run the N > 1 code path (row blocks, chunked RCCL all-gathers on a 1-rank communicator, '
+                         'per-rank scoring, all-reduced timing) on the one GPU -- a rehearsal of the multi-GPU run, not a headline')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -514,9 +517,12 @@ def main():
     dev_index = 0 if rehearsal else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
         import torch.distributed as dist
-        if rehearsal:
+        if world == 1 and 'RANK' not in os.environ:      # --force-sharded from a plain `python bench.py`
+            dist.init_process_group(backend='nccl', init_method='tcp://127.0.0.1:29531', rank=0, world_size=1, device_id=dev)
+        elif rehearsal:
             dist.init_process_group(backend='gloo')
         else:
             dist.init_process_group(backend='nccl', device_id=dev)
@@ -525,7 +531,7 @@ def main():
     from textgcn_amd.graph import NormGraph, train_mask_csr
 
     default_wl = args.workload is None
-    wl = args.workload or ('c2' if world == 1 else 'c4')
+    wl = args.workload or ('c4' if sharded else 'c2')
     n_u, n_i, nnz, d, K = synth.CONFIGS[wl]
     wl_name = f'{wl}: U={n_u} I={n_i} nnz={nnz} d={d} K={K}'
     t0 = time.time()
@@ -535,7 +541,7 @@ def main():
     build_s = time.time() - t0
     thr = args.split_threshold or propagate.DEFAULT_SPLIT_THRESHOLD
 
-    if world == 1:
+    if not sharded:
         prop = propagate.Propagator(graph, dev, split_threshold=thr, segment=None if args.no_segment else 'auto')
         e0d = e0.to(dev)
         out = torch.empty_like(e0d)
@@ -546,7 +552,8 @@ def main():
     else:
         from textgcn_amd.dist import ShardedPropagator
         chunks = args.chunks or (4 if graph.nnz >= 50_000_000 else 1)
-        sp = ShardedPropagator(graph, rank, world, dev, split_threshold=thr, balance=args.balance, chunks=chunks)
+        sp = ShardedPropagator(graph, rank, world, dev, split_threshold=thr, balance=args.balance, chunks=chunks,
+                               force_collective=args.force_sharded)
         eu, ei = sp.local_e0(e0)
 
         def step():
@@ -555,7 +562,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if sharded:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -569,40 +576,40 @@ def main():
 
     t_dev, t_wall = time_steps(step, args.steps, args.warmup, barrier)
     t = max(t_wall, t_dev)
-    if world > 1:
+    if sharded:
         t = reduce_max_sum([t])[0][0]
     value = args.steps * K * graph.nnz / t
     seg_note = 'none'
-    if world == 1 and not args.exact and prop.csr.segment_blocks and any(prop.csr.segment_blocks):
+    if not sharded and not args.exact and prop.csr.segment_blocks and any(prop.csr.segment_blocks):
         seg_note = (f'user rows x{prop.csr.segment_blocks[0]}, item rows x{prop.csr.segment_blocks[1]} column blocks, '
                     f'{prop.csr.segment_tile}-entry tiles (tgcn_spmm_segmented_f32)')
 
     # ---------------- roofline of the dominant kernel (one SpMM layer launch on this rank)
-    if world == 1 and not args.exact and not args.no_segment:
+    if not sharded and not args.exact and not args.no_segment:
         traffic, tsrc = load_traffic(wl)    # the PMC pass was taken on the default path of the workload
     else:
         traffic, tsrc = None, 'no PMC pass for this mode'
-    roofline = spmm_roofline(nnz_local, n_rows_local, n_src, d, K, t_dev, args.steps, traffic, tsrc, dev, gather=(world == 1))
-    if world > 1:
+    roofline = spmm_roofline(nnz_local, n_rows_local, n_src, d, K, t_dev, args.steps, traffic, tsrc, dev, gather=not sharded)
+    if sharded:
         roofline['note'] = 'per rank: this rank\'s row blocks, launch time includes waiting for the all-gathered tables'
 
     result = {
         'metric': 'propagated edges/sec (3-layer SpMM, d=64)', 'value': value, 'unit': 'edges/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': t / args.steps * 1e3, 'higher_is_better': True,
-        'scaling': 'strong' if world > 1 else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'scaling': 'strong' if sharded else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': wl_name, 'nnz_A': graph.nnz, 'n_nodes': graph.n, 'max_degree': int(graph.degrees().max()),
                    'mode': 'exact (one fmaf chain per row)' if args.exact else f'one-wave-per-row kernel: rows > {thr} entries split in chunks',
                    'parity_of_this_mode': 'bit-identical to the reference CPU forward' if args.exact else
                    'rows cut by the long-row split / XCD segments are summed piecewise: normwise <= 1e-5 vs the exact chain '
                    '(tests), bar 1e-4; all other rows bit-identical',
                    'xcd_segments': seg_note,
-                   'sharding': 'none' if world == 1 else (f'row-sharded x{world} ({args.balance}-balanced blocks padded to the largest, '
+                   'sharding': 'none' if not sharded else (f'row-sharded x{world} ({args.balance}-balanced blocks padded to the largest, '
                                                           f'{sp.lay_u.chunks} row chunk(s) per block), RCCL all-gather per chunk and layer '
                                                           f'(users || item half-step)'),
                    'graph_build_s': round(build_s, 1)},
         'roofline': roofline,
     }
-    if world > 1:
+    if sharded:
         result['config']['scaling_note'] = 'fixed total work (BASELINE config 4) split over the ranks; N = 1 of the same workload: ' \
                                            'bench.py --gpus 1 reports it as the sub-record c4_1gpu'
 
@@ -611,7 +618,7 @@ def main():
     if not args.no_scoring:
         k_top = 40
         bsz = args.score_batch_size
-        if world == 1:
+        if not sharded:
             ue, ie = out[:n_u], out[n_u:]
             users_all = np.arange(n_u)
         else:
@@ -626,7 +633,7 @@ def main():
         ts, keep = scoring_region(ue, ie, batches, k_top, dev, barrier)
         first_topk = keep[0]
         pairs = sum(int(bt[0].numel()) for bt in batches) * n_i
-        if world > 1:
+        if sharded:
             mx, sm = reduce_max_sum([ts, float(pairs)])
             ts, pairs = mx[0], sm[1]
         flops = 2.0 * d * pairs
@@ -638,7 +645,7 @@ def main():
         }
         # the model class scores 16384 users per call (LightGCN.predict_chunk); same kernels, fewer launches
         big = min(16384, len(users_all))
-        if world == 1 and big > bsz:
+        if not sharded and big > bsz:
             n_big = max(1, min(4, len(users_all) // big))
             bb = [batch_masks(users_all[b * big:(b + 1) * big], mrp, mit, dev) for b in range(n_big)]
             tb, _ = scoring_region(ue, ie, bb, k_top, dev, barrier)
@@ -648,7 +655,7 @@ def main():
                                                 'mfma_frac': round(2.0 * d * pb / tb / 1e12 / MFMA_F32_PEAK_TF, 4)}
 
     # ---------------- CPU baseline beside it + verification of the timed outputs (rank 0, N = 1 only; outside the timed regions)
-    if world == 1 and not args.no_cpu_baseline:
+    if not sharded and not args.no_cpu_baseline:
         if graph.nnz <= 30_000_000:
             result['cpu_baseline'], result['verify'] = cpu_baseline_propagation(graph, e0, K, gpu_out=out)
         if not args.no_scoring:
@@ -657,7 +664,7 @@ def main():
                 ue[bt[0]].cpu(), ie.cpu(), bt[1].cpu().numpy(), bt[2].cpu().numpy(), 40, gpu_topk=first_topk)
 
     # ---------------- the other single-GPU configurations (N = 1)
-    if world == 1:
+    if not sharded:
         sub = args.sub if args.sub is not None else ('c4,c3,c5,train' if default_wl else 'none')
         sub = [] if sub == 'none' else [s.strip() for s in sub.split(',') if s.strip()]
         if 'train' in sub:
@@ -676,7 +683,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if sharded:
         sp.close()
         torch.distributed.destroy_process_group()
 

@@ -74,3 +74,22 @@ def test_bench_two_rank_rehearsal(cuda, tmp_path):
     assert len(lines) == 1
     r = json.loads(lines[0])
     assert r['n_gpus'] == 2 and r['value'] > 0 and r['scaling'] == 'strong' and 'roofline' in r and r['scoring']['value'] > 0
+
+
+def test_bench_sharded_path_on_one_rank_rccl(cuda):
+    """bench.py --force-sharded: the N > 1 branch of the benchmark (process group on backend nccl, ShardedPropagator with the
+    chunked in-place all-gathers, barrier + all-reduced timing, per-rank scoring) with a 1-rank RCCL communicator on the one
+    GPU -- everything the driver's multi-GPU launch executes except a second rank."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--force-sharded', '--workload', 'small', '--steps', '2',
+           '--warmup', '1', '--score-batches', '1', '--chunks', '3', '--no-cpu-baseline']
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert r['n_gpus'] == 1 and r['scaling'] == 'strong' and 'row-sharded x1' in r['config']['sharding'] and '3 row chunk' in r['config']['sharding']
+    assert r['value'] > 0 and r['scoring']['value'] > 0 and r['roofline']['frac'] > 0
