@@ -497,6 +497,9 @@ def main():
                                                 "workload, none otherwise); 'none' to skip")
     ap.add_argument('--chunks', type=int, default=None, help='row chunks per block for the pipelined all-gather (N > 1)')
     ap.add_argument('--balance', default='nnz', choices=['nnz', 'rows'])
+    ap.add_argument('--shard', default='rows', choices=['rows', 'features'],
+                    help="N > 1: 'rows' = 1-D row partition with per-layer RCCL all-gathers (the north-star design, default); "
+                         "'features' = every rank holds all rows and d/N columns: no per-layer exchange, one all-gather at the end")
     ap.add_argument('--force-sharded', action='store_true',
                     help='N = 1 only: run the N > 1 code path (row blocks, chunked RCCL all-gathers on a 1-rank communicator, '
                          'per-rank scoring, all-reduced timing) on the one GPU -- a rehearsal of the multi-GPU run, not a headline')
@@ -550,15 +553,23 @@ def main():
             prop.forward(e0d, K, exact=args.exact, out=out)
         n_rows_local, n_src, nnz_local = graph.n, graph.n, graph.nnz
     else:
-        from textgcn_amd.dist import ShardedPropagator
+        from textgcn_amd.dist import ColumnShardedPropagator, ShardedPropagator
         chunks = args.chunks or (4 if graph.nnz >= 50_000_000 else 1)
-        sp = ShardedPropagator(graph, rank, world, dev, split_threshold=thr, balance=args.balance, chunks=chunks,
-                               force_collective=args.force_sharded)
-        eu, ei = sp.local_e0(e0)
+        if args.shard == 'features':
+            sp = ColumnShardedPropagator(graph, d, rank, world, dev, split_threshold=thr, force_collective=args.force_sharded)
+            e_cols = sp.local_e0(e0)
 
-        def step():
-            sp.forward(eu, ei, K, exact=args.exact)
-        n_rows_local, n_src, nnz_local = sp.bu + sp.bi, sp.n_pad, sp.nnz_local
+            def step():      # the K layers on this rank's columns + the one all-gather that assembles the d columns everywhere
+                return sp.assemble(sp.forward(e_cols, K, exact=args.exact))
+            n_rows_local, n_src, nnz_local = graph.n, graph.n, graph.nnz
+        else:
+            sp = ShardedPropagator(graph, rank, world, dev, split_threshold=thr, balance=args.balance, chunks=chunks,
+                                   force_collective=args.force_sharded)
+            eu, ei = sp.local_e0(e0)
+
+            def step():
+                sp.forward(eu, ei, K, exact=args.exact)
+            n_rows_local, n_src, nnz_local = sp.bu + sp.bi, sp.n_pad, sp.nnz_local
 
     def barrier():
         torch.cuda.synchronize()
@@ -589,7 +600,8 @@ def main():
         traffic, tsrc = load_traffic(wl)    # the PMC pass was taken on the default path of the workload
     else:
         traffic, tsrc = None, 'no PMC pass for this mode'
-    roofline = spmm_roofline(nnz_local, n_rows_local, n_src, d, K, t_dev, args.steps, traffic, tsrc, dev, gather=not sharded)
+    d_local = sp.dl if (sharded and args.shard == 'features') else d
+    roofline = spmm_roofline(nnz_local, n_rows_local, n_src, d_local, K, t_dev, args.steps, traffic, tsrc, dev, gather=not sharded)
     if sharded:
         roofline['note'] = 'per rank: this rank\'s row blocks, launch time includes waiting for the all-gathered tables'
 
@@ -603,9 +615,11 @@ def main():
                    'rows cut by the long-row split / XCD segments are summed piecewise: normwise <= 1e-5 vs the exact chain '
                    '(tests), bar 1e-4; all other rows bit-identical',
                    'xcd_segments': seg_note,
-                   'sharding': 'none' if not sharded else (f'row-sharded x{world} ({args.balance}-balanced blocks padded to the largest, '
-                                                          f'{sp.lay_u.chunks} row chunk(s) per block), RCCL all-gather per chunk and layer '
-                                                          f'(users || item half-step)'),
+                   'sharding': 'none' if not sharded else (
+                       f'feature-sharded x{world}: all rows, {sp.dl} of {d} columns per rank, no per-layer exchange, one RCCL all-gather of '
+                       f'the combined table per forward' if args.shard == 'features' else
+                       f'row-sharded x{world} ({args.balance}-balanced blocks padded to the largest, {sp.lay_u.chunks} row chunk(s) per '
+                       f'block), RCCL all-gather per chunk and layer (users || item half-step)'),
                    'graph_build_s': round(build_s, 1)},
         'roofline': roofline,
     }
@@ -621,6 +635,11 @@ def main():
         if not sharded:
             ue, ie = out[:n_u], out[n_u:]
             users_all = np.arange(n_u)
+        elif args.shard == 'features':    # every rank holds the whole combined table; users are split evenly for scoring
+            full = step()
+            per = -(-n_u // world)
+            users_all = np.arange(rank * per, min((rank + 1) * per, n_u))
+            ue, ie = full[users_all[0]:users_all[-1] + 1], full[n_u:]
         else:
             ue, itab = sp.forward(eu, ei, K, exact=args.exact)
             ie = sp.items_in_order(itab)

@@ -51,6 +51,7 @@ def main():
     ap.add_argument('--collective', default='torch')
     ap.add_argument('--sample', type=int, default=0, help='save only this many seeded sample rows of each table (large graphs)')
     ap.add_argument('--graph-seed', type=int, default=1)
+    ap.add_argument('--shard', choices=['rows', 'features'], default='rows')
     args = ap.parse_args()
 
     from textgcn_amd import synth
@@ -66,6 +67,16 @@ def main():
     u, i = synth.interactions(args.n_users, args.n_items, args.nnz, seed=args.graph_seed)
     g = NormGraph.from_pairs(u, i, args.n_users, args.n_items)
     e0 = synth.embeddings(g.n, args.d, seed=2)
+    if args.shard == 'features':      # column partition: no per-layer exchange, one all-gather at the end
+        from textgcn_amd.dist import ColumnShardedPropagator
+        dev = 'cuda:0' if args.mode != 'nccl' else 'cuda'
+        cp = ColumnShardedPropagator(g, args.d, args.rank, args.world, dev, split_threshold=64, force_collective=(args.mode == 'nccl'))
+        full = cp.assemble(cp.forward(cp.local_e0(e0), args.layers, single=args.single))
+        if args.rank == 0:
+            np.savez(args.out, users=full[:args.n_users].cpu().numpy(), items=full[args.n_users:].cpu().numpy())
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if args.mode == 'cpu':
         sp = ShardedPropagator(g, args.rank, args.world, 'cpu', local_spmm=oracle_spmm, split_threshold=None,
                                balance=args.balance, chunks=args.chunks)

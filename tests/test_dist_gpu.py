@@ -93,3 +93,45 @@ def test_bench_sharded_path_on_one_rank_rccl(cuda):
     r = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
     assert r['n_gpus'] == 1 and r['scaling'] == 'strong' and 'row-sharded x1' in r['config']['sharding'] and '3 row chunk' in r['config']['sharding']
     assert r['value'] > 0 and r['scoring']['value'] > 0 and r['roofline']['frac'] > 0
+
+
+@pytest.mark.parametrize('d,world', [(64, 2), (64, 4), (64, 8), (128, 4), (256, 8)])
+def test_column_partition_is_bit_identical(cuda, oracle, d, world):
+    """The feature partition without any process group: every 'rank' computes its d / P columns of the K-layer forward on the
+    whole graph (d / P in {8, 16, 32}: the narrow kernels); the concatenation must carry the bits of the full-width forward and
+    of the oracle -- the product is independent per column."""
+    from textgcn_amd import synth
+    from textgcn_amd.dist import ColumnShardedPropagator
+    from textgcn_amd.graph import NormGraph
+    from textgcn_amd.propagate import Propagator
+    u, i = synth.interactions(1500, 600, 30000, seed=6, zipf=1.0)
+    g = NormGraph.from_pairs(u, i, 1500, 600)
+    e0 = synth.embeddings(g.n, d, seed=3)
+    K = 3
+    for exact in (True, False):
+        thr = None if exact else 48
+        ref = Propagator(g, cuda, split_threshold=thr, segment=None).forward(e0.to(cuda), K, exact=exact)
+        parts = []
+        for r in range(world):
+            cp = ColumnShardedPropagator(g, d, r, world, cuda, split_threshold=thr)
+            parts.append(cp.forward(cp.local_e0(e0), K, exact=exact))
+        got = torch.cat(parts, dim=1)
+        assert torch.equal(got, ref), (exact, (got != ref).sum().item())
+    idx, val = g.to_coo()
+    want, _ = oracle.propagate(idx, val, e0.numpy(), K)
+    cp = ColumnShardedPropagator(g, d, world - 1, world, cuda, split_threshold=None)
+    out = cp.forward(cp.local_e0(e0), K, exact=True).cpu().numpy()
+    assert np.array_equal(bits(out), bits(np.ascontiguousarray(want[:, cp.cols])))
+
+
+@pytest.mark.parametrize('mode,world', [('gpu', 2), ('nccl', 1)])
+def test_column_partition_assemble_collective(cuda, tmp_path, mode, world):
+    """the one collective of the feature partition (all-gather + column interleave): two gloo ranks on the GPU, and the RCCL
+    call itself on a 1-rank communicator"""
+    out = str(tmp_path / 'r0.npz')
+    n_u, n_i, nnz = 2030, 970, 40000
+    run_ranks(world, mode, out, extra=('--n-users', str(n_u), '--n-items', str(n_i), '--nnz', str(nnz), '--shard', 'features'))
+    got = np.load(out)
+    ref = _single_gpu_reference(cuda, n_u, n_i, nnz)
+    assert np.array_equal(bits(got['users']), bits(ref[:n_u]))
+    assert np.array_equal(bits(got['items']), bits(ref[n_u:]))

@@ -188,6 +188,93 @@ __global__ __launch_bounds__(256) void k_spmm_wave(const SpmmArgs a)
     epilogue<VEC>(a, (size_t)row * a.d + lane * VEC, acc);
 }
 
+// ---- narrow tables (d in {8, 16, 32}) ---------------------------------------------------------------------------------------
+// The feature (column) partition of the multi-GPU path (dist.ColumnShardedPropagator) leaves a rank d / P columns of every
+// table.  G = d / 4 lanes own one work item -- a row, or one chunk of a long row -- with a float4 per lane, 64 / G items per
+// wave; the item's (col, val) pairs are loaded G at a time by its lanes and broadcast with width-G shuffles.  Every output
+// element is still the sequential fmaf chain over the row's entries in column order: bit-identical to the wide kernels on
+// the same columns.  Row gathers are 4d bytes (128 B at d = 32: one cache line; below that the fabric over-fetches).
+template <int G, int UNROLL>
+__global__ __launch_bounds__(256) void k_spmm_narrow(const SpmmArgs a)
+{
+    static_assert(UNROLL <= G, "a group holds G (col, val) pairs at a time");
+    constexpr int D = 4 * G;
+    const int lane = lane_id();
+    const int gl = lane & (G - 1);
+    const long long item = ((long long)blockIdx.x * 256 + threadIdx.x) / G;
+    const long long n_items = (long long)a.n_chunks + a.n_rows;
+    const bool valid = item < n_items;
+    int beg = 0, end = 0, row = -1;
+    if (valid) {
+        if (item < a.n_chunks) {
+            beg = a.chunk_beg[item];
+            end = a.chunk_end[item];
+        } else {
+            row = (int)(item - a.n_chunks);
+            beg = a.rowptr[row];
+            end = a.rowptr[row + 1];
+            if (end - beg > a.threshold) {   // long row: its chunks are other items of this launch, then k_spmm_narrow_reduce
+                end = beg;
+                row = -2;
+            }
+        }
+    }
+    const float *__restrict__ Xl = a.X + gl * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int base = beg; base < end; base += G) {
+        const int n = min(G, end - base);  // uniform inside a group
+        int c = 0;
+        float v = 0.0f;
+        if (gl < n) {
+            c = a.colidx[base + gl];
+            v = a.vals[base + gl];
+        }
+        for (int j = 0; j < n; j += UNROLL) {
+            float4 x[UNROLL];
+            float vv[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int jj = min(j + u, n - 1);
+                const int cj = __shfl(c, jj, G);
+                vv[u] = __shfl(v, jj, G);
+                x[u] = *reinterpret_cast<const float4 *>(Xl + (size_t)cj * D);
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                if (j + u < n) {
+                    acc.x = fmaf(vv[u], x[u].x, acc.x);
+                    acc.y = fmaf(vv[u], x[u].y, acc.y);
+                    acc.z = fmaf(vv[u], x[u].z, acc.z);
+                    acc.w = fmaf(vv[u], x[u].w, acc.w);
+                }
+            }
+        }
+    }
+    if (!valid)
+        return;
+    const float y[4] = {acc.x, acc.y, acc.z, acc.w};
+    if (item < a.n_chunks)
+        store_vec<4>(a.ws + (size_t)item * D + gl * 4, y);
+    else if (row >= 0)
+        epilogue<4>(a, (size_t)row * D + gl * 4, y);
+}
+
+// one thread per (split row, column): y = ((p0 + p1) + p2) + ... in chunk order, then the usual epilogue
+__global__ __launch_bounds__(256) void k_spmm_narrow_reduce(const SpmmArgs a, const int *__restrict__ long_rows,
+                                                            const int *__restrict__ long_chunk_ptr, int n_long)
+{
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int l = (int)(t / a.d), col = (int)(t % a.d);
+    if (l >= n_long)
+        return;
+    const int c0 = long_chunk_ptr[l], c1 = long_chunk_ptr[l + 1];
+    float yv = a.ws[(size_t)c0 * a.d + col];
+    for (int c = c0 + 1; c < c1; ++c)
+        yv = yv + a.ws[(size_t)c * a.d + col];
+    const float y[1] = {yv};
+    epilogue<1>(a, (size_t)long_rows[l] * a.d + col, y);
+}
+
 // XCD-affine segmented launch (tgcn_spmm_segmented_f32).  Waves [0, n_tiles) walk one tile each of the plan's
 // own (column, value) streams: 64 pairs are loaded at a time (the next 64 while the current ones are consumed),
 // rows of X are gathered 16 or 32 at a time, and every entry whose bit is set in the stream's flag words
@@ -497,7 +584,8 @@ extern "C" int tgcn_spmm_csr_f32(const int32_t *rowptr, const int32_t *colidx, c
     a.n_rows = (int)n_rows, a.d = d;
     a.threshold = INT_MAX, a.n_chunks = 0, a.chunk_beg = nullptr, a.chunk_end = nullptr, a.ws = nullptr;
     a.row_order = row_order;
-    const bool split = plan && plan->n_chunks > 0 && vec_ok;
+    const bool narrow_ok = (d == 8 || d == 16 || d == 32);
+    const bool split = plan && plan->n_chunks > 0 && (vec_ok || narrow_ok);
     if (split) {
         TGCN_REQUIRE(plan->threshold > 0, "plan->threshold must be positive");
         TGCN_REQUIRE(plan->chunk_beg && plan->chunk_end && plan->long_rows && plan->long_chunk_ptr && plan->workspace,
@@ -508,6 +596,25 @@ extern "C" int tgcn_spmm_csr_f32(const int32_t *rowptr, const int32_t *colidx, c
     }
 
     int rc;
+    if (narrow_ok) {
+        const long long items = (long long)a.n_chunks + a.n_rows;
+        const long long grid = (items * (d / 4) + 255) / 256;
+        TGCN_REQUIRE(grid < INT_MAX, "too many rows for one narrow launch");
+        if (d == 32)
+            hipLaunchKernelGGL((k_spmm_narrow<8, 8>), dim3((unsigned)grid), dim3(256), 0, s, a);
+        else if (d == 16)
+            hipLaunchKernelGGL((k_spmm_narrow<4, 4>), dim3((unsigned)grid), dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL((k_spmm_narrow<2, 2>), dim3((unsigned)grid), dim3(256), 0, s, a);
+        if ((rc = check_launch("k_spmm_narrow")) != TGCN_OK)
+            return rc;
+        if (split) {
+            const long long rgrid = ((long long)plan->n_long * d + 255) / 256;
+            hipLaunchKernelGGL(k_spmm_narrow_reduce, dim3((unsigned)rgrid), dim3(256), 0, s, a, plan->long_rows, plan->long_chunk_ptr, plan->n_long);
+            rc = check_launch("k_spmm_narrow_reduce");
+        }
+        return rc;
+    }
     if (!vec_ok) {
         a.row_waves = a.n_rows;
         const int grid = (a.n_rows + 3) / 4;

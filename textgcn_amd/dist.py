@@ -360,3 +360,55 @@ class ShardedPropagator:
         if self._capi_comm is not None:
             self._capi_comm.close()
             self._capi_comm = None
+
+
+class ColumnShardedPropagator:
+    """The alternative partition: by FEATURE columns.  Every rank holds the whole graph and d / P columns of every table.
+
+    The product is independent per column, so a layer needs no exchange at all and each column's fmaf chain is exactly the
+    single-GPU one (bit-identical, whatever P); one all-gather of the combined table after layer K assembles the d columns.
+    Against the row partition this trades the (P-1)/P x N x d x 4 bytes received per layer for P-fold replicated CSR reads
+    and narrower row gathers (4 d / P bytes: one 128-byte line at d = 64, P = 2; below that the fabric over-fetches).  On
+    xGMI (point-to-point links) it is the better split for small P, where a row partition's all-gather crosses one or three
+    links; it is an option (`bench.py --shard features`), the row partition stays the default."""
+
+    def __init__(self, graph: NormGraph, d, rank, world, device, group=None, split_threshold=DEFAULT_SPLIT_THRESHOLD,
+                 force_collective=False):
+        from .propagate import Propagator
+        self.rank, self.world = int(rank), int(world)
+        self.device = resolve_device(device)
+        self.group = group
+        if d % self.world or (d // self.world) % 4 or (d // self.world) not in (8, 16, 32, 64, 128, 256):
+            raise ValueError(f'd = {d} cannot be split in {world} column blocks of a supported width (8, 16, 32, 64, 128, 256)')
+        self.d, self.dl = int(d), d // self.world
+        self.cols = slice(self.rank * self.dl, (self.rank + 1) * self.dl)
+        self.n = graph.n
+        self.n_users = graph.n_users
+        # narrow tables are far beyond what an XCD-affine block could hold: the one-wave-per-row / group kernels
+        self.prop = Propagator(graph, self.device, split_threshold=split_threshold, segment=None)
+        self.uses_collective = self.world > 1 or force_collective
+        self.backend = dist.get_backend(group) if self.uses_collective else 'none'
+
+    def local_e0(self, e0_full):
+        """this rank's columns of a full [N, d] table (host or device tensor), contiguous on the device"""
+        return e0_full[:, self.cols].to(self.device).contiguous()
+
+    def forward(self, e0_cols, n_layers, single=False, exact=False):
+        """e0_cols [N, d / P] -> the combined table's same columns [N, d / P]; no communication."""
+        return self.prop.forward(e0_cols, n_layers, single=single, exact=exact)
+
+    def assemble(self, out_cols):
+        """[N, d / P] of every rank -> [N, d] on every rank: ONE all-gather + a column interleave."""
+        if not self.uses_collective:
+            return out_cols if self.world == 1 else None
+        blocks = torch.empty((self.world, self.n, self.dl), dtype=torch.float32, device=out_cols.device)
+        if self.backend == 'nccl' or out_cols.device.type == 'cpu':
+            dist.all_gather_into_tensor(blocks.view(self.world * self.n, self.dl), out_cols.contiguous(), group=self.group)
+        else:   # one-GPU rehearsal (gloo, device tensors): staged through host memory
+            host = torch.empty((self.world * self.n, self.dl), dtype=torch.float32)
+            dist.all_gather_into_tensor(host, out_cols.detach().cpu().contiguous(), group=self.group)
+            blocks.copy_(host.view(self.world, self.n, self.dl))
+        return blocks.permute(1, 0, 2).reshape(self.n, self.d)
+
+    def close(self):
+        pass
