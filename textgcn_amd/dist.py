@@ -386,8 +386,7 @@ class ColumnShardedPropagator:
         self.n_users = graph.n_users
         # narrow tables are far beyond what an XCD-affine block could hold: the one-wave-per-row / group kernels
         self.prop = Propagator(graph, self.device, split_threshold=split_threshold, segment=None)
-        self.uses_collective = self.world > 1 or force_collective
-        self.backend = dist.get_backend(group) if self.uses_collective else 'none'
+        self.uses_collective = self.world > 1 or force_collective     # the process group is only needed by assemble()
 
     def local_e0(self, e0_full):
         """this rank's columns of a full [N, d] table (host or device tensor), contiguous on the device"""
@@ -402,7 +401,7 @@ class ColumnShardedPropagator:
         if not self.uses_collective:
             return out_cols if self.world == 1 else None
         blocks = torch.empty((self.world, self.n, self.dl), dtype=torch.float32, device=out_cols.device)
-        if self.backend == 'nccl' or out_cols.device.type == 'cpu':
+        if dist.get_backend(self.group) == 'nccl' or out_cols.device.type == 'cpu':
             dist.all_gather_into_tensor(blocks.view(self.world * self.n, self.dl), out_cols.contiguous(), group=self.group)
         else:   # one-GPU rehearsal (gloo, device tensors): staged through host memory
             host = torch.empty((self.world * self.n, self.dl), dtype=torch.float32)
