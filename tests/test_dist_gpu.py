@@ -100,6 +100,7 @@ def test_column_partition_is_bit_identical(cuda, oracle, d, world):
     """The feature partition without any process group: every 'rank' computes its d / P columns of the K-layer forward on the
     whole graph (d / P in {8, 16, 32}: the narrow kernels); the concatenation must carry the bits of the full-width forward and
     of the oracle -- the product is independent per column."""
+    import torch
     from textgcn_amd import synth
     from textgcn_amd.dist import ColumnShardedPropagator
     from textgcn_amd.graph import NormGraph
