@@ -176,6 +176,14 @@ def _fused_vs_dense(cuda, u, it, k, mask=None, user_ids=None, round4=True):
     torch.cuda.synchronize()
     assert torch.equal(i, ri), (i != ri).sum().item()
     assert np.array_equal(bits(v.cpu().numpy()), bits(rv.cpu().numpy()))
+    # the bf16-prefiltered entry point (tgcn_score_topk_prefilter_f32): the same bits, with the item norm computed inside the
+    # call and handed in
+    for norm in (None, scoring.item_norm_max(itd)):
+        pv, pi = scoring.score_topk(ud, itd, k, user_ids=ids, mask_rowptr=rp, mask_items=it_, round4=round4, prefilter=True,
+                                    item_norm=norm)
+        torch.cuda.synchronize()
+        assert torch.equal(pi, ri), ('prefilter', (pi != ri).sum().item())
+        assert np.array_equal(bits(pv.cpu().numpy()), bits(rv.cpu().numpy()))
     return v, i
 
 
@@ -342,3 +350,36 @@ def test_fused_topk_very_large_catalogue(cuda):
     np.cumsum(cnt, out=rp[1:])
     items = np.concatenate([np.sort(rng.choice(i, size=c, replace=False)) for c in cnt])
     _fused_vs_dense(cuda, u, it, k, mask=(rp, items))
+
+
+@pytest.mark.parametrize('d', [64, 128, 32])
+def test_prefilter_bound_under_worst_case_rounding(cuda, d):
+    """Data built against the bf16 bound: every element sits just below a bf16 rounding boundary with the signs aligned, so the
+    approximate score of the planted winners is lower than their fp32 score by nearly the whole bound (2^-7 |u| |i|) while
+    thousands of other items sit just under the threshold.  The prefiltered call must still return the dense path's bits."""
+    rng = np.random.default_rng(d)
+    b, i, k = 160, 20000, 40
+    # elements (1 + 2^-8 - 2^-20) * 2^e: bf16 rounds them DOWN by a relative 2^-8 (the worst case of round-to-nearest)
+    mant = np.float32(1.0 + 2.0 ** -8 - 2.0 ** -20)
+    u = (mant * np.exp2(rng.integers(-4, 0, size=(b, d)))).astype(np.float32)
+    it = (mant * np.exp2(rng.integers(-4, 0, size=(i, d)))).astype(np.float32)
+    # crowd: most items are an exact-bf16 copy scaled so their scores land a hair under the planted ones
+    it[k:] = (np.exp2(rng.integers(-4, 0, size=(i - k, d)))).astype(np.float32) * np.float32(1.0 + 2.0 ** -7)
+    _fused_vs_dense(cuda, u, it, k, mask=_rand_mask(rng, b, i, 0, 20), round4=False)
+    # mixed signs and magnitudes from denormal to large, a NaN row and an inf row among the items
+    u2 = (rng.standard_normal((b, d)) * np.exp2(rng.integers(-30, 10, size=(b, 1)))).astype(np.float32)
+    it2 = (rng.standard_normal((i, d)) * np.exp2(rng.integers(-30, 10, size=(i, 1)))).astype(np.float32)
+    it2[5] = 1e-42
+    it2[7, 0] = np.inf
+    it2[9, 1] = np.nan
+    _fused_vs_dense(cuda, u2, it2, k, mask=_rand_mask(rng, b, i, 0, 20), round4=False)
+
+
+def test_item_norm_max(cuda):
+    from textgcn_amd import scoring
+    rng = np.random.default_rng(3)
+    for n, d in ((50000, 64), (777, 128), (1000, 100), (5, 32)):
+        it = (rng.standard_normal((n, d)) * 0.3).astype(np.float32)
+        want = (np.maximum(np.abs(it.astype(np.float64)), 2.0 ** -50) ** 2).sum(axis=1).max()
+        got = float(scoring.item_norm_max(torch.from_numpy(it).to(cuda)).item())
+        assert abs(got - want) <= 1e-5 * want

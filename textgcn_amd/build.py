@@ -14,7 +14,7 @@ ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, 'csrc')
 LIB_DIR = os.path.join(_HERE, '_lib')
 LIB = os.path.join(LIB_DIR, 'libtgcn.so')
-SOURCES = ['tgcn_core.hip', 'tgcn_spmm.hip', 'tgcn_score.hip', 'tgcn_score_fused.hip', 'tgcn_ltr.hip', 'tgcn_comm.hip', 'tgcn_train.hip']
+SOURCES = ['tgcn_core.hip', 'tgcn_spmm.hip', 'tgcn_score.hip', 'tgcn_score_fused.hip', 'tgcn_score_prefilter.hip', 'tgcn_ltr.hip', 'tgcn_comm.hip', 'tgcn_train.hip']
 HEADERS = [os.path.join(ROOT, 'include', 'tgcn.h'), os.path.join(CSRC, 'tgcn_internal.h'), os.path.join(CSRC, 'tgcn_topk.h')]
 ARCH = 'gfx950'
 

@@ -47,11 +47,59 @@ __device__ __forceinline__ float readlane_f(float v, int lane)
 }
 
 
+// max over the 64 lanes, returned to every lane.  DPP steps inside the rows of 16 (quad_perm, row_half_mirror, row_mirror),
+// then row_bcast15 / row_bcast31 (GFX9 family incl. gfx950) carry the row maxima into row 3: seven VALU instructions and a
+// readlane, where six __shfl_xor are six ds_bpermute round trips (~100 cycles each on a serial chain).  NaNs are ignored
+// (fmaxf).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_max_step(float v)
+{
+    const int x = __float_as_int(v);
+    return fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(x, x, CTRL, ROW_MASK, 0xf, false)));
+}
+
+__device__ __forceinline__ float wave_max_all(float v)
+{
+    v = dpp_max_step<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+    v = dpp_max_step<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+    v = dpp_max_step<0x141, 0xf>(v);   // row_half_mirror
+    v = dpp_max_step<0x140, 0xf>(v);   // row_mirror: every lane holds its row's maximum
+    v = dpp_max_step<0x142, 0xa>(v);   // row_bcast15 into rows 1 and 3
+    v = dpp_max_step<0x143, 0xc>(v);   // row_bcast31 into rows 2 and 3
+    return readlane_f(v, 63);
+}
+
+// ---- the error bound of the bf16 candidate pass (tgcn_score_prefilter.hip holds the derivation) ----------------------------
+constexpr float kNormFloor = 0x1p-50f;
+__device__ __forceinline__ float floored_sq(float x)
+{
+    const float f = fmaxf(fabsf(x), kNormFloor);
+    return f * f;
+}
+__device__ __forceinline__ float nan_max(float a, float b) { return (b > a || !(b == b)) ? b : a; }   // a NaN sticks
+// tau' = tau - c |u~| M from the squared norms; a non-finite bound gives -inf (everything is logged -> the exact fallback)
+__device__ __forceinline__ float lowered_tau(float tau, float user_sq, float item_sq_max)
+{
+    const float c = 0x1p-7f * (1.0f + 0x1p-4f);
+    const float delta = c * sqrtf(user_sq) * sqrtf(item_sq_max);
+    const float t = tau - delta;
+    return (delta < INFINITY && t == t) ? t : -INFINITY;
+}
+
 // launchers shared between translation units (arguments already validated by the caller)
 int launch_score_dense(const float *U, const int64_t *user_ids, int B, const float *It, int I, int d, int item_mul, float *S,
                        int64_t lds, hipStream_t stream);
 int launch_score_dense_filter(const float *U, const int64_t *user_ids, int B, const float *It, int I, int d, const float *tau,
                               int tau_stride, void *logs, int *counts, int S, int items_per_split, int cap2, hipStream_t stream);
+// tgcn_score_prefilter.hip: candidates from a bf16 pass, rescored in fp32
+bool prefilter_supports(int d);
+int launch_item_norm_part(const float *It, int I, int d, float *part, int n_part, float *total, hipStream_t stream);
+int launch_tau_lo(const float *U, const int64_t *user_ids, int B, int d, const float *tau, int tau_stride, const float *part,
+                  int n_part, float *tau_lo, hipStream_t stream);
+int launch_prefilter(const float *U, const int64_t *user_ids, int B, const float *It, int I, int d, const float *tau_lo, void *logs,
+                     int *counts, int S, int items_per_split, int cap2, hipStream_t stream);
+int launch_rescore(const float *U, const int64_t *user_ids, int B, const float *It, int d, const float *tau, int tau_stride,
+                   void *logs, const int *counts, int S, int cap2, hipStream_t stream);
 int launch_topk(const float *S, int64_t lds, int B, int I, int k, int do_round, float *out_val, int64_t *out_idx,
                 hipStream_t stream);
 int launch_mask(float *S, int64_t lds, int B, int I, const int *mask_rowptr, const int *mask_items, int item_div,

@@ -196,6 +196,9 @@ __global__ __launch_bounds__(256) void k_score_dense_filter(const DenseFilterArg
         const int user = u0 + w * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
         tau_r[r] = user < a.B ? a.tau[(size_t)user * a.tau_stride] : INFINITY;
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        asm volatile("" ::"v"(tau_r[r]));   // arrived before the loops (see filter_pipelined in tgcn_score_fused.hip)
     const int cap = 2 * a.cap2;
     bool first = true;
     for (int i0 = i_beg; i0 < i_end; i0 += kTile) {

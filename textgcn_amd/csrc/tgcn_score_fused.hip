@@ -38,6 +38,7 @@ constexpr int kTauRank = 10;       // tau = kTauRank-th largest masked sample sc
 constexpr int kUsersPerWG = 128;   // 4 waves x 32 users
 constexpr int kStage = 64;         // items per LDS stage (2 MFMA sub-tiles of 32)
 constexpr int kSmallI = 8192;      // below this the dense path (score -> mask -> top-k) is used
+constexpr int kNormParts = 1024;   // workgroups of the item-norm pass (prefilter mode)
 
 #ifdef TGCN_FILTER_PROBE
 // diagnostic build only (tools/filter_probe.py compiles its own copy with -DTGCN_FILTER_PROBE; never in libtgcn.so): per
@@ -158,6 +159,9 @@ __global__ __launch_bounds__(256) void k_score_filter(const FilterArgs a)
     float2 *__restrict__ log = a.logs + ((size_t)(user_ok ? user : 0) * a.S + split) * 2 * a.cap2 + (size_t)h * a.cap2;
     int cnt = 0;
     __syncthreads();
+    // tau has arrived before the loop: with its first use inside, hipcc's wait-count pass merges the pending tau load with the
+    // stage prefetch across the back edge and puts an s_waitcnt vmcnt in front of every threshold test
+    asm volatile("" ::"v"(tau));
 
     // ---- item stages: global -> registers (issued before the MFMA block) -> LDS (after it), double buffered
     float4 nxt[(kStage * DQ) / 256];
@@ -295,6 +299,9 @@ __device__ __forceinline__ void filter_pipelined(const FilterArgs &a)
     }
     const float tau = user_ok ? a.tau[(size_t)user * a.tau_stride] : INFINITY;
     __syncthreads();
+    // tau has arrived before the loop: with its first use inside, hipcc's wait-count pass merges the pending tau load with the
+    // stage prefetch across the back edge and puts an s_waitcnt vmcnt in front of every threshold test
+    asm volatile("" ::"v"(tau));
     {
         const float *pu = smem + (w * 32 + r32) * ROW + 2 * h;
 #pragma unroll
@@ -475,18 +482,13 @@ constexpr int kMaskCache = 512;  // train items per user cached in LDS for the m
 // staged in LDS (coalesced load, mask applied by the lanes that own the train items), read back VPL values per lane, and
 // the maximum is extracted kTauRank times (per-lane max, wave max, the owning lane retires one copy).  Replaces the
 // k_mask + k_topk pair on the sample (28 us for 2048 x 1563 -> ~4 us) and zeroes the fallback counter for this call.
-__device__ __forceinline__ float wave_max_f(float v)
-{
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-        v = fmaxf(v, __shfl_xor(v, o));
-    return v;
-}
-
+// Prefilter mode (tau_lo != NULL): the lowered threshold of tgcn_score_prefilter.hip is written too -- the user's floored
+// squared norm and the maximum of the item-norm partials are fetched before the rounds and cost no extra launch.
 template <int VPL>
 __global__ __launch_bounds__(256) void k_tau(const float *__restrict__ Ss, int m_ld, int B, int m, const int *__restrict__ mask_rowptr,
                                              const int *__restrict__ mask_items, float *__restrict__ tau, int *__restrict__ flagged,
-                                             int *__restrict__ done)
+                                             int *__restrict__ done, const float *__restrict__ U, const int64_t *__restrict__ user_ids,
+                                             int d, const float *__restrict__ norm_part, int n_part, float *__restrict__ tau_lo)
 {
     extern __shared__ float srow[];   // [4][64 * VPL]
     const int lane = lane_id();
@@ -505,6 +507,14 @@ __global__ __launch_bounds__(256) void k_tau(const float *__restrict__ Ss, int m
         const int j = lane + kWave * i;
         row[j] = (ok && j < m) ? Ss[(size_t)b * m_ld + j] : -INFINITY;
     }
+    float usq = 0.0f, isq = 0.0f;
+    if (tau_lo && ok) {
+        const float *__restrict__ p = U + (size_t)(user_ids ? user_ids[b] : b) * d;
+        for (int k = lane; k < d; k += kWave)
+            usq += floored_sq(p[k]);
+        for (int i = lane; i < n_part; i += kWave)
+            isq = nan_max(isq, norm_part[i]);
+    }
     __syncthreads();
     if (ok && mask_rowptr) {
         const int mb = mask_rowptr[b], me = mask_rowptr[b + 1];
@@ -515,30 +525,37 @@ __global__ __launch_bounds__(256) void k_tau(const float *__restrict__ Ss, int m
         }
     }
     __syncthreads();
-    float x[VPL];
+    // the lane's two largest values, then kTauRank rounds of (wave maximum, its first owner retires one copy).  A lane that
+    // holds three or more of the row's kTauRank largest gives a slightly lower tau than the exact rank: tau is only a bar that
+    // at least k items must clear (k_select checks that), not a result.
+    float a0 = -INFINITY, a1 = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < VPL; ++i)
-        x[i] = row[lane + kWave * i];
+    for (int i = 0; i < VPL; ++i) {
+        const float x = row[lane + kWave * i];
+        a1 = fmaxf(a1, fminf(a0, x));
+        a0 = fmaxf(a0, x);
+    }
     float t = -INFINITY;
     for (int r = 0; r < kTauRank; ++r) {
-        float lm = x[0];
-#pragma unroll
-        for (int i = 1; i < VPL; ++i)
-            lm = fmaxf(lm, x[i]);
-        t = wave_max_f(lm);
-        const int owner = __ffsll((long long)__ballot(lm == t)) - 1;
+        t = wave_max_all(a0);
+        const int owner = __ffsll((long long)__ballot(a0 == t)) - 1;
         if (lane == owner) {
-            bool done = false;
-#pragma unroll
-            for (int i = 0; i < VPL; ++i)
-                if (!done && x[i] == t) {
-                    x[i] = -INFINITY;
-                    done = true;
-                }
+            a0 = a1;
+            a1 = -INFINITY;
         }
     }
-    if (ok && lane == 0)
+    if (tau_lo) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            usq += __shfl_xor(usq, o);
+            isq = nan_max(isq, __shfl_xor(isq, o));
+        }
+    }
+    if (ok && lane == 0) {
         tau[b] = t;
+        if (tau_lo)
+            tau_lo[b] = lowered_tau(t, usq, isq);
+    }
 }
 
 // ---- exact selection from the logs ----------------------------------------------------------------------------------------
@@ -717,7 +734,9 @@ __global__ __launch_bounds__(256) void k_select(const SelectArgs a)
             bool on = j < n;
             if (on) {
                 const int si = __float_as_int(cand[j].y);
-                if (cached ? sorted_contains(smask[w], 0, me - mb, si) : sorted_contains(a.mask_items, mb, me, si)) {
+                if (si == INT_MAX)          // retired by k_rescore (fp32 score not above tau)
+                    on = false;
+                else if (cached ? sorted_contains(smask[w], 0, me - mb, si) : sorted_contains(a.mask_items, mb, me, si)) {
                     cand[j].y = __int_as_float(INT_MAX);
                     on = false;
                 }
@@ -868,7 +887,7 @@ __global__ __launch_bounds__(kBruteWaves * 64) void k_brute_part(const BruteArgs
 
 struct Plan {
     int S, items_per_split, cap2, m, m_ld;  // m = sampled items
-    size_t off_sample, off_tauv, off_taui, off_tau, off_logs, off_counts, off_parts, off_flags, off_done, total;
+    size_t off_sample, off_tauv, off_taui, off_tau, off_taulo, off_npart, off_logs, off_counts, off_parts, off_flags, off_done, total;
     int flag_cap;
     bool small;
 };
@@ -901,6 +920,8 @@ Plan make_plan(int B, int I, int d, int k)
     p.off_tauv = o, o += align256((size_t)B * kTauRank * sizeof(float));
     p.off_taui = o, o += align256((size_t)B * kTauRank * sizeof(int64_t));
     p.off_tau = o, o += align256((size_t)B * sizeof(float));
+    p.off_taulo = o, o += align256((size_t)B * sizeof(float));             // prefilter mode: the lowered thresholds
+    p.off_npart = o, o += align256((size_t)kNormParts * sizeof(float));    // and the per-workgroup item-norm maxima
     p.off_logs = o, o += align256((size_t)B * p.S * 2 * p.cap2 * sizeof(float2));
     p.off_counts = o, o += align256((size_t)B * p.S * 2 * sizeof(int));
     p.flag_cap = B;   // every user may need the fallback (e.g. fully tied scores): 16 KB of partial lists each
@@ -965,10 +986,14 @@ extern "C" int64_t tgcn_score_topk_workspace_bytes(int32_t B, int32_t I, int32_t
     return (int64_t)make_plan(B, I, d, k).total;
 }
 
-extern "C" int tgcn_score_topk_f32(const float *U, const int64_t *user_ids, int32_t B, const float *It, int32_t I,
-                                   int32_t d, const int32_t *mask_rowptr, const int32_t *mask_items, int32_t k,
-                                   int32_t round4, float *out_val, int64_t *out_idx, void *workspace,
-                                   int64_t workspace_bytes, tgcn_stream_t stream)
+namespace {
+// prefilter: candidates from the bf16 pass of tgcn_score_prefilter.hip, rescored in fp32 (same results; d <= 128, d % 4 == 0,
+// otherwise the fp32 filter runs).  item_norm: device pointer to max_i sum_j max(|y_ij|, 2^-50)^2 (tgcn_item_norm_max_f32), or
+// NULL: computed by this call.
+int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const float *It, int32_t I, int32_t d,
+                    const int32_t *mask_rowptr, const int32_t *mask_items, int32_t k, int32_t round4, float *out_val,
+                    int64_t *out_idx, void *workspace, int64_t workspace_bytes, tgcn_stream_t stream, bool prefilter,
+                    const float *item_norm)
 {
     TGCN_REQUIRE(B >= 0 && I >= 0, "negative size");
     TGCN_REQUIRE(d > 0 && d <= 4096, "d out of range");
@@ -995,6 +1020,18 @@ extern "C" int tgcn_score_topk_f32(const float *U, const int64_t *user_ids, int3
         return launch_topk(S, I, B, I, k, round4, out_val, out_idx, s);
     }
 
+    // prefilter mode: the item-side factor of the bound, unless the caller holds it
+    prefilter = prefilter && prefilter_supports(d);
+    float *tau_lo = prefilter ? reinterpret_cast<float *>(ws + p.off_taulo) : nullptr;
+    const float *npart = item_norm;
+    int n_part = 1;
+    if (prefilter && !npart) {
+        float *np = reinterpret_cast<float *>(ws + p.off_npart);
+        n_part = min(kNormParts, (I + 63) / 64);
+        if ((rc = launch_item_norm_part(It, I, d, np, n_part, nullptr, s)) != TGCN_OK)
+            return rc;
+        npart = np;
+    }
     // 1. tau from a strided item sample
     float *Ss = reinterpret_cast<float *>(ws + p.off_sample);
     float *tauv = reinterpret_cast<float *>(ws + p.off_tauv);
@@ -1011,10 +1048,10 @@ extern "C" int tgcn_score_topk_f32(const float *U, const int64_t *user_ids, int3
         const int vpl = p.m <= 8 * kWave ? 8 : p.m <= 16 * kWave ? 16 : p.m <= 32 * kWave ? 32 : 64;
         const size_t lds = (size_t)4 * kWave * vpl * sizeof(float);
         switch (vpl) {
-            case 8: hipLaunchKernelGGL((k_tau<8>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, tau1, flagged, done); break;
-            case 16: hipLaunchKernelGGL((k_tau<16>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, tau1, flagged, done); break;
-            case 32: hipLaunchKernelGGL((k_tau<32>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, tau1, flagged, done); break;
-            default: hipLaunchKernelGGL((k_tau<64>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, tau1, flagged, done); break;
+            case 8: hipLaunchKernelGGL((k_tau<8>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, tau1, flagged, done, U, user_ids, d, npart, n_part, tau_lo); break;
+            case 16: hipLaunchKernelGGL((k_tau<16>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, tau1, flagged, done, U, user_ids, d, npart, n_part, tau_lo); break;
+            case 32: hipLaunchKernelGGL((k_tau<32>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, tau1, flagged, done, U, user_ids, d, npart, n_part, tau_lo); break;
+            default: hipLaunchKernelGGL((k_tau<64>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, tau1, flagged, done, U, user_ids, d, npart, n_part, tau_lo); break;
         }
         if ((rc = check_launch("k_tau")) != TGCN_OK)
             return rc;
@@ -1035,7 +1072,13 @@ extern "C" int tgcn_score_topk_f32(const float *U, const int64_t *user_ids, int3
     fa.logs = reinterpret_cast<float2 *>(ws + p.off_logs);
     fa.counts = reinterpret_cast<int *>(ws + p.off_counts);
     fa.B = B, fa.I = I, fa.d = d, fa.S = p.S, fa.items_per_split = p.items_per_split, fa.cap2 = p.cap2;
-    if (d <= 128) {
+    if (prefilter) {
+        if (tau_stride != 1 && (rc = launch_tau_lo(U, user_ids, B, d, tau_ptr, tau_stride, npart, n_part, tau_lo, s)) != TGCN_OK)
+            return rc;       // (the k_tau launch wrote tau_lo itself)
+        if ((rc = launch_prefilter(U, user_ids, B, It, I, d, tau_lo, fa.logs, fa.counts, p.S, p.items_per_split, p.cap2, s)) != TGCN_OK)
+            return rc;
+        rc = launch_rescore(U, user_ids, B, It, d, tau_ptr, tau_stride, fa.logs, fa.counts, p.S, p.cap2, s);
+    } else if (d <= 128) {
         const dim3 grid((B + kUsersPerWG - 1) / kUsersPerWG, p.S);
         if (d == 64)
             hipLaunchKernelGGL((k_score_filter16<true>), grid, dim3(256), 0, s, fa);
@@ -1067,4 +1110,53 @@ extern "C" int tgcn_score_topk_f32(const float *U, const int64_t *user_ids, int3
         return rc;
     hipLaunchKernelGGL(k_brute_part, dim3(kBruteSplits, 8), dim3(kBruteWaves * 64), brute_lds, s, ba);
     return check_launch("k_brute_part");
+}
+}  // namespace
+
+extern "C" int tgcn_score_topk_f32(const float *U, const int64_t *user_ids, int32_t B, const float *It, int32_t I,
+                                   int32_t d, const int32_t *mask_rowptr, const int32_t *mask_items, int32_t k,
+                                   int32_t round4, float *out_val, int64_t *out_idx, void *workspace,
+                                   int64_t workspace_bytes, tgcn_stream_t stream)
+{
+    return score_topk_impl(U, user_ids, B, It, I, d, mask_rowptr, mask_items, k, round4, out_val, out_idx, workspace,
+                           workspace_bytes, stream, false, nullptr);
+}
+
+extern "C" int tgcn_score_topk_prefilter_f32(const float *U, const int64_t *user_ids, int32_t B, const float *It, int32_t I,
+                                             int32_t d, const int32_t *mask_rowptr, const int32_t *mask_items, int32_t k,
+                                             int32_t round4, const float *item_norm, float *out_val, int64_t *out_idx,
+                                             void *workspace, int64_t workspace_bytes, tgcn_stream_t stream)
+{
+    return score_topk_impl(U, user_ids, B, It, I, d, mask_rowptr, mask_items, k, round4, out_val, out_idx, workspace,
+                           workspace_bytes, stream, true, item_norm);
+}
+
+extern "C" int tgcn_score_topk_fallback_count(const void *workspace, int32_t B, int32_t I, int32_t d, int32_t k, int32_t *out_host,
+                                              tgcn_stream_t stream)
+{
+    TGCN_REQUIRE(workspace && out_host, "NULL pointer");
+    TGCN_REQUIRE(B > 0 && I > 0 && d > 0, "empty call");
+    const Plan p = make_plan(B, I, d, k);
+    *out_host = 0;
+    if (p.small)
+        return TGCN_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemcpyAsync(out_host, static_cast<const char *>(workspace) + p.off_flags, sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess)
+        return check_launch("tgcn_score_topk_fallback_count");
+    return TGCN_OK;
+}
+
+extern "C" int tgcn_item_norm_max_f32(const float *It, int32_t I, int32_t d, float *out, tgcn_stream_t stream)
+{
+    TGCN_REQUIRE(I >= 0, "negative size");
+    TGCN_REQUIRE(d > 0 && d <= 4096, "d out of range");
+    TGCN_REQUIRE(out, "NULL pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(out, 0, sizeof(float), s) != hipSuccess)
+        return check_launch("hipMemsetAsync(item norm)");
+    if (I == 0)
+        return TGCN_OK;
+    TGCN_REQUIRE(It, "NULL pointer");
+    return launch_item_norm_part(It, I, d, nullptr, min(kNormParts, (I + 63) / 64), out, s);
 }

@@ -99,10 +99,39 @@ def _workspace(dev, nbytes, slot=0):
     return buf
 
 
-def score_topk(users_emb, items_emb, k, user_ids=None, mask_rowptr=None, mask_items=None, round4=False, slot=0):
+def fallback_count(dev, b, n_items, d, k, slot=0):
+    """Users of the last score_topk call on (dev, slot) that took the exact fallback (diagnostic; synchronises)."""
+    import ctypes
+    dev = _capi.resolve_device(dev)
+    ws = _WORKSPACE.get((dev, slot)) if (dev, slot) in _WORKSPACE else None
+    if ws is None:
+        raise RuntimeError('no score_topk call has used this slot')
+    out = ctypes.c_int32(0)
+    rc = _capi.lib().tgcn_score_topk_fallback_count(_capi.ptr(ws), b, n_items, d, int(min(k, MAX_K_PER_PASS)), ctypes.byref(out),
+                                                    _capi.current_stream(dev))
+    _capi.check(rc, 'tgcn_score_topk_fallback_count')
+    return out.value
+
+
+def item_norm_max(items_emb):
+    """One device float: max_i sum_j max(|items_emb[i, j]|, 2^-50)^2 (tgcn_item_norm_max_f32) -- the item-side factor of the
+    prefilter's error bound.  Compute it once per item table and hand it to score_topk(prefilter=True, item_norm=...)."""
+    dev = _dev(items_emb)
+    _f32c(items_emb, 'items_emb')
+    out = torch.empty(1, dtype=torch.float32, device=dev)
+    rc = _capi.lib().tgcn_item_norm_max_f32(_capi.ptr(items_emb), items_emb.shape[0], items_emb.shape[1], _capi.ptr(out),
+                                            _capi.current_stream(dev))
+    _capi.check(rc, 'tgcn_item_norm_max_f32')
+    return out
+
+
+def score_topk(users_emb, items_emb, k, user_ids=None, mask_rowptr=None, mask_items=None, round4=False, slot=0, prefilter=False,
+               item_norm=None):
     """Fused predict step: top-k over all items of the masked scores (tgcn_score_topk_f32).  Same result as
     score_dense -> mask_train -> topk, without the [B, I] matrix.  mask_* is a CSR over the batch rows.
-    `slot` selects the scratch buffer: use distinct slots for calls issued on different streams."""
+    `slot` selects the scratch buffer: use distinct slots for calls issued on different streams.
+    `prefilter`: find the candidates with the bf16 pass and rescore them in fp32 (tgcn_score_topk_prefilter_f32) -- the same
+    result bit for bit; `item_norm` = item_norm_max(items_emb) when the table is shared by many calls."""
     dev = _dev(users_emb)
     _f32c(users_emb, 'users_emb'), _f32c(items_emb, 'items_emb')
     if users_emb.shape[1] != items_emb.shape[1]:
@@ -132,7 +161,7 @@ def score_topk(users_emb, items_emb, k, user_ids=None, mask_rowptr=None, mask_it
             kk = min(MAX_K_PER_PASS, k - k0)
             v, i = score_topk(users_emb, items_emb, kk, user_ids, rowptr.to(torch.int32),
                               (keys % n_items).to(torch.int32) if keys.numel() else torch.zeros(1, dtype=torch.int32, device=dev),
-                              round4, slot)
+                              round4, slot, prefilter, item_norm)
             vals.append(v), idxs.append(i)
             keys = torch.sort(torch.cat([keys, (rows[:, None] * n_items + i).reshape(-1)]))[0]
             rowptr = rowptr + kk * torch.arange(b + 1, device=dev, dtype=torch.int64)
@@ -142,6 +171,15 @@ def score_topk(users_emb, items_emb, k, user_ids=None, mask_rowptr=None, mask_it
     lib = _capi.lib()
     need = lib.tgcn_score_topk_workspace_bytes(b, n_items, d, int(k))
     ws = _workspace(dev, max(need, 256), slot)
+    if prefilter:
+        if item_norm is not None and (item_norm.dtype != torch.float32 or item_norm.numel() != 1 or item_norm.device != dev):
+            raise TypeError('item_norm must be one float32 on the same device (item_norm_max)')
+        rc = lib.tgcn_score_topk_prefilter_f32(_capi.ptr(users_emb), _capi.ptr(user_ids), b, _capi.ptr(items_emb), n_items, d,
+                                               _capi.ptr(mask_rowptr), _capi.ptr(mask_items), int(k), 1 if round4 else 0,
+                                               _capi.ptr(item_norm), _capi.ptr(val), _capi.ptr(idx), _capi.ptr(ws), ws.numel(),
+                                               _capi.current_stream(dev))
+        _capi.check(rc, 'tgcn_score_topk_prefilter_f32')
+        return val, idx
     rc = lib.tgcn_score_topk_f32(_capi.ptr(users_emb), _capi.ptr(user_ids), b, _capi.ptr(items_emb), n_items, d,
                                  _capi.ptr(mask_rowptr), _capi.ptr(mask_items), int(k), 1 if round4 else 0, _capi.ptr(val),
                                  _capi.ptr(idx), _capi.ptr(ws), ws.numel(), _capi.current_stream(dev))
