@@ -96,10 +96,10 @@ bool prefilter_supports(int d);
 int launch_item_norm_part(const float *It, int I, int d, float *part, int n_part, float *total, hipStream_t stream);
 int launch_tau_lo(const float *U, const int64_t *user_ids, int B, int d, const float *tau, int tau_stride, const float *part,
                   int n_part, float *tau_lo, hipStream_t stream);
-int launch_prefilter(const float *U, const int64_t *user_ids, int B, const float *It, int I, int d, const float *tau_lo, void *logs,
-                     int *counts, int S, int items_per_split, int cap2, hipStream_t stream);
+int launch_prefilter(const float *U, const int64_t *user_ids, int B, const float *It, int I, int d, const float *tau_lo,
+                     unsigned *mask, int Wh, int S, int items_per_split, hipStream_t stream);
 int launch_rescore(const float *U, const int64_t *user_ids, int B, const float *It, int d, const float *tau, int tau_stride,
-                   void *logs, const int *counts, int S, int cap2, hipStream_t stream);
+                   const unsigned *mask, int Wh, void *lists, int *totals, int list_cap, hipStream_t stream);
 int launch_topk(const float *S, int64_t lds, int B, int I, int k, int do_round, float *out_val, int64_t *out_idx,
                 hipStream_t stream);
 int launch_mask(float *S, int64_t lds, int B, int I, const int *mask_rowptr, const int *mask_items, int item_div,

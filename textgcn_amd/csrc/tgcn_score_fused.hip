@@ -473,6 +473,7 @@ struct SelectArgs {
     int64_t *__restrict__ out_idx;
     int *__restrict__ flagged;  // [1 + B]: count, then the flagged user rows (count zeroed by the caller each call)
     int B, S, cap2, k, do_round;
+    const int *__restrict__ totals;   // flat mode (k_rescore's output): user b's entries are logs[b * S * 2 * cap2 + 0 .. totals[b])
 };
 
 constexpr int kMaskCache = 512;  // train items per user cached in LDS for the membership test
@@ -488,7 +489,8 @@ template <int VPL>
 __global__ __launch_bounds__(256) void k_tau(const float *__restrict__ Ss, int m_ld, int B, int m, const int *__restrict__ mask_rowptr,
                                              const int *__restrict__ mask_items, float *__restrict__ tau, int *__restrict__ flagged,
                                              int *__restrict__ done, const float *__restrict__ U, const int64_t *__restrict__ user_ids,
-                                             int d, const float *__restrict__ norm_part, int n_part, float *__restrict__ tau_lo)
+                                             int d, const float *__restrict__ norm_part, int n_part, float *__restrict__ tau_lo,
+                                             int *__restrict__ totals)
 {
     extern __shared__ float srow[];   // [4][64 * VPL]
     const int lane = lane_id();
@@ -498,8 +500,11 @@ __global__ __launch_bounds__(256) void k_tau(const float *__restrict__ Ss, int m
     // the caller's and arrives uninitialised); saves the memset node in front of every call
     if (blockIdx.x == 0 && threadIdx.x == 0)
         flagged[0] = 0;
-    if (b < B && lane == 0)
+    if (b < B && lane == 0) {
         done[b] = 0;
+        if (totals)
+            totals[b] = 0;      // k_rescore's per-user list lengths
+    }
     float *row = srow + w * (kWave * VPL);
     const bool ok = b < B;
 #pragma unroll
@@ -690,40 +695,53 @@ __global__ __launch_bounds__(256) void k_select(const SelectArgs a)
         for (int j = lane; j < me - mb; j += kWave)
             smask[w][j] = a.mask_items[mb + j];
     const int n_seg = a.S * 2;   // <= 64: one segment per lane
-    int cnt = lane < n_seg ? a.counts[(size_t)b * n_seg + lane] : 0;
-    bool overflow = __any(cnt > a.cap2);
-    cnt = min(cnt, a.cap2);
-    // exclusive prefix of the counts over lanes
-    int off = cnt;
+    bool overflow = false;
+    int n = 0, cnt = 0, off = 0;
+    if (a.totals) {
+        n = a.totals[b];
+        overflow = n > min(kSelCap, n_seg * a.cap2);
+    } else {
+        cnt = lane < n_seg ? a.counts[(size_t)b * n_seg + lane] : 0;
+        overflow = __any(cnt > a.cap2);
+        cnt = min(cnt, a.cap2);
+        // exclusive prefix of the counts over lanes
+        off = cnt;
 #pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-        const int t = __shfl_up(off, o);
-        if (lane >= o)
-            off += t;
+        for (int o = 1; o < kWave; o <<= 1) {
+            const int t = __shfl_up(off, o);
+            if (lane >= o)
+                off += t;
+        }
+        n = __builtin_amdgcn_readlane(off, kWave - 1);
+        off -= cnt;
+        if (n > kSelCap)
+            overflow = true;
     }
-    const int n = __builtin_amdgcn_readlane(off, kWave - 1);
-    off -= cnt;
-    if (n > kSelCap)
-        overflow = true;
     bool ok = !overflow;
     float out_v = -INFINITY;
     int out_i = INT_MAX;
     if (ok) {
         float2 *cand = scand[w];
-        const float2 *__restrict__ lg = a.logs + ((size_t)b * n_seg + min(lane, n_seg - 1)) * a.cap2;
-        int longest = cnt;
+        if (a.totals) {
+            const float2 *__restrict__ lg = a.logs + (size_t)b * n_seg * a.cap2;
+            for (int j = lane; j < n; j += kWave)
+                cand[j] = lg[j];
+        } else {
+            const float2 *__restrict__ lg = a.logs + ((size_t)b * n_seg + min(lane, n_seg - 1)) * a.cap2;
+            int longest = cnt;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1)
-            longest = max(longest, __shfl_xor(longest, o));
-        for (int j0 = 0; j0 < longest; j0 += 8) {
-            float2 t[8];
+            for (int o = 32; o > 0; o >>= 1)
+                longest = max(longest, __shfl_xor(longest, o));
+            for (int j0 = 0; j0 < longest; j0 += 8) {
+                float2 t[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                t[u] = lg[min(j0 + u, a.cap2 - 1)];   // in bounds; entries past cnt are ignored
+                for (int u = 0; u < 8; ++u)
+                    t[u] = lg[min(j0 + u, a.cap2 - 1)];   // in bounds; entries past cnt are ignored
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (j0 + u < cnt)
-                    cand[off + j0 + u] = t[u];
+                for (int u = 0; u < 8; ++u)
+                    if (j0 + u < cnt)
+                        cand[off + j0 + u] = t[u];
+            }
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
@@ -734,9 +752,7 @@ __global__ __launch_bounds__(256) void k_select(const SelectArgs a)
             bool on = j < n;
             if (on) {
                 const int si = __float_as_int(cand[j].y);
-                if (si == INT_MAX)          // retired by k_rescore (fp32 score not above tau)
-                    on = false;
-                else if (cached ? sorted_contains(smask[w], 0, me - mb, si) : sorted_contains(a.mask_items, mb, me, si)) {
+                if (cached ? sorted_contains(smask[w], 0, me - mb, si) : sorted_contains(a.mask_items, mb, me, si)) {
                     cand[j].y = __int_as_float(INT_MAX);
                     on = false;
                 }
@@ -887,7 +903,9 @@ __global__ __launch_bounds__(kBruteWaves * 64) void k_brute_part(const BruteArgs
 
 struct Plan {
     int S, items_per_split, cap2, m, m_ld;  // m = sampled items
-    size_t off_sample, off_tauv, off_taui, off_tau, off_taulo, off_npart, off_logs, off_counts, off_parts, off_flags, off_done, total;
+    int Wh;                                 // 64-item units of the catalogue (d <= 128: the filters emit pass bits)
+    size_t off_mask;
+    size_t off_sample, off_tauv, off_taui, off_tau, off_taulo, off_npart, off_logs, off_counts, off_parts, off_flags, off_done, off_totals, total;
     int flag_cap;
     bool small;
 };
@@ -922,12 +940,17 @@ Plan make_plan(int B, int I, int d, int k)
     p.off_tau = o, o += align256((size_t)B * sizeof(float));
     p.off_taulo = o, o += align256((size_t)B * sizeof(float));             // prefilter mode: the lowered thresholds
     p.off_npart = o, o += align256((size_t)kNormParts * sizeof(float));    // and the per-workgroup item-norm maxima
+    p.Wh = (I + kStage - 1) / kStage;
+    p.off_mask = o;
+    if (d <= 128)
+        o += align256((size_t)((B + kUsersPerWG - 1) / kUsersPerWG) * kUsersPerWG * 2 * p.Wh * sizeof(unsigned));
     p.off_logs = o, o += align256((size_t)B * p.S * 2 * p.cap2 * sizeof(float2));
     p.off_counts = o, o += align256((size_t)B * p.S * 2 * sizeof(int));
     p.flag_cap = B;   // every user may need the fallback (e.g. fully tied scores): 16 KB of partial lists each
     p.off_parts = o, o += align256((size_t)p.flag_cap * kBruteSplits * kWave * sizeof(float2));
     p.off_flags = o, o += align256((size_t)(B + 1) * sizeof(int));
     p.off_done = o, o += align256((size_t)p.flag_cap * sizeof(int));   // contiguous with the flags: one memset covers both
+    p.off_totals = o, o += align256((size_t)B * sizeof(int));          // ... and k_rescore's list lengths
     p.total = o;
     return p;
 }
@@ -1039,6 +1062,7 @@ int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const fl
     float *tau1 = reinterpret_cast<float *>(ws + p.off_tau);
     int *flagged = reinterpret_cast<int *>(ws + p.off_flags);
     int *done = reinterpret_cast<int *>(ws + p.off_done);
+    int *totals = prefilter ? reinterpret_cast<int *>(ws + p.off_totals) : nullptr;
     if ((rc = launch_score_dense(U, user_ids, B, It, p.m, d, kSampleStride, Ss, p.m_ld, s)) != TGCN_OK)
         return rc;
     const float *tau_ptr;
@@ -1048,17 +1072,17 @@ int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const fl
         const int vpl = p.m <= 8 * kWave ? 8 : p.m <= 16 * kWave ? 16 : p.m <= 32 * kWave ? 32 : 64;
         const size_t lds = (size_t)4 * kWave * vpl * sizeof(float);
         switch (vpl) {
-            case 8: hipLaunchKernelGGL((k_tau<8>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, tau1, flagged, done, U, user_ids, d, npart, n_part, tau_lo); break;
-            case 16: hipLaunchKernelGGL((k_tau<16>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, tau1, flagged, done, U, user_ids, d, npart, n_part, tau_lo); break;
-            case 32: hipLaunchKernelGGL((k_tau<32>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, tau1, flagged, done, U, user_ids, d, npart, n_part, tau_lo); break;
-            default: hipLaunchKernelGGL((k_tau<64>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, tau1, flagged, done, U, user_ids, d, npart, n_part, tau_lo); break;
+            case 8: hipLaunchKernelGGL((k_tau<8>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, tau1, flagged, done, U, user_ids, d, npart, n_part, tau_lo, totals); break;
+            case 16: hipLaunchKernelGGL((k_tau<16>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, tau1, flagged, done, U, user_ids, d, npart, n_part, tau_lo, totals); break;
+            case 32: hipLaunchKernelGGL((k_tau<32>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, tau1, flagged, done, U, user_ids, d, npart, n_part, tau_lo, totals); break;
+            default: hipLaunchKernelGGL((k_tau<64>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, tau1, flagged, done, U, user_ids, d, npart, n_part, tau_lo, totals); break;
         }
         if ((rc = check_launch("k_tau")) != TGCN_OK)
             return rc;
         tau_ptr = tau1, tau_stride = 1;
     } else {                   // very large catalogues (> 131 072 items): mask + workgroup-per-row top-k on the sample
         // the fallback's flag count and arrival counters start from zero (the workspace arrives uninitialised)
-        if (hipMemsetAsync(flagged, 0, (size_t)(ws + p.off_done - reinterpret_cast<char *>(flagged)) + (size_t)p.flag_cap * sizeof(int), s) != hipSuccess)
+        if (hipMemsetAsync(flagged, 0, (size_t)(ws + p.off_totals - reinterpret_cast<char *>(flagged)) + (size_t)B * sizeof(int), s) != hipSuccess)
             return check_launch("hipMemsetAsync(flagged, done)");
         if (mask_rowptr && (rc = launch_mask(Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, kSampleStride, s)) != TGCN_OK)
             return rc;
@@ -1072,12 +1096,13 @@ int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const fl
     fa.logs = reinterpret_cast<float2 *>(ws + p.off_logs);
     fa.counts = reinterpret_cast<int *>(ws + p.off_counts);
     fa.B = B, fa.I = I, fa.d = d, fa.S = p.S, fa.items_per_split = p.items_per_split, fa.cap2 = p.cap2;
-    if (prefilter) {
+    if (prefilter) {   // pass bits from the bf16 GEMM, then candidates -> fp32 chains -> flat (score, item) lists
+        unsigned *mask = reinterpret_cast<unsigned *>(ws + p.off_mask);
         if (tau_stride != 1 && (rc = launch_tau_lo(U, user_ids, B, d, tau_ptr, tau_stride, npart, n_part, tau_lo, s)) != TGCN_OK)
             return rc;       // (the k_tau launch wrote tau_lo itself)
-        if ((rc = launch_prefilter(U, user_ids, B, It, I, d, tau_lo, fa.logs, fa.counts, p.S, p.items_per_split, p.cap2, s)) != TGCN_OK)
+        if ((rc = launch_prefilter(U, user_ids, B, It, I, d, tau_lo, mask, p.Wh, p.S, p.items_per_split, s)) != TGCN_OK)
             return rc;
-        rc = launch_rescore(U, user_ids, B, It, d, tau_ptr, tau_stride, fa.logs, fa.counts, p.S, p.cap2, s);
+        rc = launch_rescore(U, user_ids, B, It, d, tau_ptr, tau_stride, mask, p.Wh, fa.logs, totals, p.S * 2 * p.cap2, s);
     } else if (d <= 128) {
         const dim3 grid((B + kUsersPerWG - 1) / kUsersPerWG, p.S);
         if (d == 64)
@@ -1090,14 +1115,14 @@ int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const fl
             hipLaunchKernelGGL((k_score_filter32<false>), grid, dim3(256), 0, s, fa);
         rc = check_launch("k_score_filter16/32");
     } else {
-        rc = d <= 64 ? launch_filter<16>(fa, s) : d <= 128 ? launch_filter<32>(fa, s) : d <= 256 ? launch_filter<64>(fa, s)
+        rc = d <= 256 ? launch_filter<64>(fa, s)
             : launch_score_dense_filter(U, user_ids, B, It, I, d, tau_ptr, tau_stride, fa.logs, fa.counts, p.S, p.items_per_split, p.cap2, s);
     }
     if (rc != TGCN_OK)
         return rc;
 
     // 3. exact selection from the logs; 4. exact rescoring of flagged users
-    SelectArgs sa{fa.logs, fa.counts, mask_rowptr, mask_items, out_val, out_idx, flagged, B, p.S, p.cap2, k, round4};
+    SelectArgs sa{fa.logs, fa.counts, mask_rowptr, mask_items, out_val, out_idx, flagged, B, p.S, p.cap2, k, round4, totals};
     hipLaunchKernelGGL(k_select, dim3((B + 3) / 4), dim3(256), 0, s, sa);
     if ((rc = check_launch("k_select")) != TGCN_OK)
         return rc;

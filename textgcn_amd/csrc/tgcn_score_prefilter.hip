@@ -141,17 +141,18 @@ struct PreArgs {
     const int64_t *__restrict__ user_ids;
     const float *__restrict__ It;
     const float *__restrict__ tau_lo;
-    float2 *__restrict__ logs;      // [B][S][2][cap2]  (approximate score, item-as-float-bits)
-    int *__restrict__ counts;       // [B][S][2]
-    int B, I, d, S, items_per_split, cap2;
+    unsigned *__restrict__ mask;    // [B padded to 128][2][Wh] pass bits (layout: filter_pipelined in tgcn_score_fused.hip)
+    int Wh;
+    int B, I, d, items_per_split;
 };
 
 // KS = 16-wide k-steps per dot product (d <= 16 KS).  Items on MFMA rows (A operand, LDS stages of ST rows of bf16), the wave's
 // 32 users on columns (B operand, KS x 4 registers for the whole pass): C/D col (user) = lane & 31, row (item) =
 // (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5), so a lane's 16 results belong to one user and its threshold is one register.
-// The kernel is bound by the tests (one compare per result register, an append for the ~1/3 that have a passing lane) and by
-// the latency of the item rows, not by the matrix pipe: 2 KS MFMAs of 32 cycles per 64 items.  A stage's rows are requested
-// one whole stage ahead (ST = 128: the 64-item stages of the fp32 kernel are over before their successor's rows arrive).
+// Output: one pass bit per (user, item), a 32-bit word per lane and 64-item unit (no branch, no append in the loop: with
+// lane-private logs the loop spent ~2000 issue cycles per unit on compare-and-branch and appends against 256 cycles of MFMA).
+// A stage's rows are requested one whole stage ahead; d <= 64 walks 256-item stages (four units, ~1400 issue cycles each for
+// the SIMD's two waves: shorter stages end before their successor's rows arrive).
 template <int KS, bool FULLK, int ST>
 __global__ __launch_bounds__(256) void k_score_prefilter(const PreArgs a)
 {
@@ -224,28 +225,16 @@ __global__ __launch_bounds__(256) void k_score_prefilter(const PreArgs a)
 #pragma unroll
     for (int s = 0; s < KS; ++s)
         bfr[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(smem + (w * 32 + r32) * RB + 32 * s + 16 * h));
-    float2 *__restrict__ log = a.logs + ((size_t)(user_ok ? user : 0) * a.S + split) * 2 * a.cap2 + (size_t)h * a.cap2;
-    const int cap = user_ok ? a.cap2 : 0;     // padded users never write (their tau is +inf, but a NaN approximation passes the test)
-    int cnt = 0;
+    unsigned *__restrict__ mrow = a.mask + ((size_t)user * 2 + h) * a.Wh;   // rows of padded users exist and are never read
     __syncthreads();
-    if (i_beg >= i_end) {
-        if (user_ok)
-            a.counts[((size_t)user * a.S + split) * 2 + h] = 0;
+    if (i_beg >= i_end)
         return;
-    }
     store(smem, nxt);
     __syncthreads();
     // tau has arrived before the loop: a first use inside it makes hipcc's wait-count pass put s_waitcnt vmcnt(0) in front of
     // EVERY test (the loop-carried state merges the pending tau load with the stage prefetch), which serialises the prefetch
     asm volatile("" ::"v"(tau));
     int buf = 0;
-    auto test = [&](float val, int item) {
-        if (!(val <= tau)) {
-            if (cnt < cap)
-                log[cnt] = make_float2(val, __int_as_float(item));
-            ++cnt;
-        }
-    };
     for (int s0 = i_beg; s0 < i_end; s0 += ST) {
         const bool more = s0 + ST < i_end;
         if (more)
@@ -267,106 +256,167 @@ __global__ __launch_bounds__(256) void k_score_prefilter(const PreArgs a)
                 c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bfr[s], c0, 0, 0, 0);
                 c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bfr[s], c1, 0, 0, 0);
             }
+            // one pass bit per result register (!(approx <= tau'): a NaN approximation passes), register t on bit 31 - t
             const int lim = i_end - t0;
-            if (lim >= kStage) {
+            unsigned bits = 0;
+            if (lim >= kStage) {   // bits = 2 bits + pass: a compare into vcc and an add-with-carry per register
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    test(c0[r], t0 + (r & 3) + 8 * (r >> 2) + 4 * h);
+                    asm volatile("v_cmp_nle_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(c0[r]), "v"(tau) : "vcc");
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    test(c1[r], t0 + 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
+                    asm volatile("v_cmp_nle_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(c1[r]), "v"(tau) : "vcc");
             } else {   // the partial last unit of the catalogue: rows past i_end are clamped copies
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (row < lim)
-                        test(c0[r], t0 + row);
-                }
+                for (int r = 0; r < 16; ++r)
+                    bits = (bits << 1) | (((r & 3) + 8 * (r >> 2) + 4 * h < lim && !(c0[r] <= tau)) ? 1u : 0u);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (row < lim)
-                        test(c1[r], t0 + row);
-                }
+                for (int r = 0; r < 16; ++r)
+                    bits = (bits << 1) | ((32 + (r & 3) + 8 * (r >> 2) + 4 * h < lim && !(c1[r] <= tau)) ? 1u : 0u);
             }
+            mrow[t0 >> 6] = user_ok ? bits : 0u;
         }
         if (more)
             store(smem + (buf ^ 1) * ST * RB, nxt);
         __syncthreads();
         buf ^= 1;
     }
-    if (user_ok)
-        a.counts[((size_t)user * a.S + split) * 2 + h] = cnt;
 }
 
-// ---- fp32 rescoring of the logged pairs -------------------------------------------------------------------------------------
-// One workgroup of eight waves per user, each wave takes an eighth of the user's log segments (~40 entries: one tile).  The
-// wave lists its entries and their item ids in LDS, then walks them 64 at a time: the 64 item rows are read in k-blocks of 32
-// floats with coalesced 16-byte loads (8 lanes per row; the next k-block's loads are in flight while this one is chained),
+// ---- candidates from the pass bits, fp32 scores, compact lists -----------------------------------------------------------
+// One WAVE per user, no workgroup-level synchronisation.  (1) the user's 2 Wh mask words are read 32 per lane at a time (all
+// loads of a chunk in flight together), counted, scanned once per chunk, and the set bits become item ids in LDS (more than
+// kUserCap: the user is handed to the exact fallback); (2) 64 entries at a time: the item rows are read in k-blocks of 32
+// floats with coalesced 16-byte loads (8 lanes per row; the next step's loads are in flight while this one is chained),
 // transposed through a padded LDS tile, and lane l continues candidate l's chain  s = fmaf(u_k, y_k, s), k ascending -- the
-// chain of the MFMA 32x32x2 f32 path and of k_brute_part; u_k comes from scalar loads (the user is the workgroup's).  The
-// entry's score is overwritten; an entry with !(s > tau) is retired (item = INT_MAX, which k_select skips).
+// chain of the MFMA 32x32x2 f32 path, of the dense path and of k_brute_part; (3) entries with s > tau are appended to the
+// user's flat (score, item) list; its length goes to totals[b] (the order of the list is irrelevant to k_select).  This is
+// where the superset shrinks to {score > tau}.  Measured alternatives (config 2, 2048 users): a workgroup per user with the
+// list shared by eight waves 55 us, a wave per (user, eighth of the item table) placed on its own XCD 60 us -- both bound by
+// their chain of dependent round trips (mask, mask again, rows, atomic), not by bytes: without the row loads 50 us.
 struct RescoreArgs {
     const float *__restrict__ U;
     const int64_t *__restrict__ user_ids;
     const float *__restrict__ It;
     const float *__restrict__ tau;
     int tau_stride;
-    float2 *__restrict__ logs;
-    const int *__restrict__ counts;
-    int B, d, S, cap2;
+    const unsigned *__restrict__ mask;
+    int Wh;
+    float2 *__restrict__ lists;     // [B][list_cap]
+    int *__restrict__ totals;       // [B]
+    int B, d, list_cap;
 };
 
-constexpr int kRescoreWaves = 8;
+constexpr int kUserCap = 1536;      // candidates of a user held in LDS
+constexpr int kOverflow = 1 << 20;  // a total beyond any list: k_select hands the user to the fallback
 constexpr int kKB = 32;             // floats of a row per LDS tile
 constexpr int kTileRow = kKB + 1;   // padded: lane = row reads are conflict-free
+constexpr int kChunkWords = 32;     // mask words per lane per chunk
 
-__global__ __launch_bounds__(kRescoreWaves * 64) void k_rescore(const RescoreArgs a)
+template <bool ALIGNED4>     // rows are multiples of 16 bytes (d % 4 == 0): one float4 per (row, piece), else four scalars
+__global__ __launch_bounds__(256) void k_rescore(const RescoreArgs a)
 {
-    extern __shared__ float sh[];   // per wave: positions [8 cap2] | item ids [8 cap2] | tile [64][33]
+    __shared__ int ids_all[4][kUserCap];
+    __shared__ float tiles[4][kWave * kTileRow];
+    __shared__ __attribute__((aligned(16))) float su_all[4][128];   // the user's row (d <= 128 on this path)
     const int lane = lane_id();
     const int w = threadIdx.x >> 6;
-    const int b = blockIdx.x;
-    const int per_wave = 16 * a.cap2 + kWave * kTileRow;
-    int *pos = reinterpret_cast<int *>(sh + (size_t)w * per_wave);
-    int *ids = pos + 8 * a.cap2;
-    float *tile = reinterpret_cast<float *>(ids + 8 * a.cap2);
-    const float *__restrict__ urow = a.U + (size_t)(a.user_ids ? a.user_ids[b] : (int64_t)b) * a.d;   // wave-uniform
-    const int n_seg = a.S * 2;                               // <= 64
-    const int spw = (n_seg + kRescoreWaves - 1) / kRescoreWaves;   // segments per wave, <= 8
-    const int seg = w * spw + lane;
-    const int cnt = (lane < spw && seg < n_seg) ? min(a.counts[(size_t)b * n_seg + seg], a.cap2) : 0;
-    int off = cnt;
-#pragma unroll
-    for (int o = 1; o < 8; o <<= 1) {
-        const int t = __shfl_up(off, o);
-        if (lane >= o)
-            off += t;
-    }
-    const int n = __builtin_amdgcn_readlane(off, 7);
-    if (n == 0)
+    const int b = blockIdx.x * 4 + w;
+    if (b >= a.B)
         return;
-    off -= cnt;
-    for (int j = 0; j < cnt; ++j)
-        pos[off + j] = seg * a.cap2 + j;
+    int *ids = ids_all[w];
+    float *tile = tiles[w];
+    float *su = su_all[w];   // read back as LDS broadcasts: left to the compiler, u_k of the chains is a vector load from global
+                             // memory per fmaf (the address is not proven uniform), 5 us per 64-entry step
+    {
+        const float *__restrict__ urow = a.U + (size_t)(a.user_ids ? a.user_ids[b] : (int64_t)b) * a.d;
+        for (int k = lane; k < a.d; k += kWave)
+            su[k] = urow[k];
+    }
+    const unsigned *__restrict__ mrow = a.mask + (size_t)b * 2 * a.Wh;
+    const int n_words = 2 * a.Wh;
+    // (1) extract: lane l of a chunk owns words l * 32 .. l * 32 + 31 (contiguous: 128-byte reads per lane)
+    int n = 0;
+    for (int c0 = 0; c0 < n_words; c0 += kWave * kChunkWords) {
+        unsigned word[kChunkWords];
+        const int j0 = c0 + lane * kChunkWords;
+        if (j0 + kChunkWords <= n_words && ((size_t)mrow & 15) == 0 && (n_words & 3) == 0) {
+#pragma unroll
+            for (int i = 0; i < kChunkWords; i += 4) {
+                const uint4 t = *reinterpret_cast<const uint4 *>(mrow + j0 + i);
+                word[i] = t.x, word[i + 1] = t.y, word[i + 2] = t.z, word[i + 3] = t.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < kChunkWords; ++i)
+                word[i] = j0 + i < n_words ? mrow[j0 + i] : 0u;
+        }
+        int mine = 0;
+#pragma unroll
+        for (int i = 0; i < kChunkWords; ++i)
+            mine += __popc(word[i]);
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if (lane >= o)
+                incl += t;
+        }
+        const int chunk_n = __builtin_amdgcn_readlane(incl, kWave - 1);
+        if (n + chunk_n > kUserCap) {    // too many candidates (tau' = -inf, a degenerate threshold ...)
+            if (lane == 0)
+                a.totals[b] = kOverflow;
+            return;
+        }
+        int off = n + incl - mine;
+        if (mine) {
+#pragma unroll
+            for (int i = 0; i < kChunkWords; ++i) {
+                unsigned wd = word[i];
+                const int j = j0 + i;
+                const int hh = j >= a.Wh ? 1 : 0;
+                const int base = (j - hh * a.Wh) * 64 + 4 * hh;
+                while (wd) {
+                    const int t = __clz(wd);          // register index: bit 31 - t
+                    wd &= ~(0x80000000u >> t);
+                    ids[off++] = base + (t < 16 ? 0 : 32) + (t & 3) + 8 * ((t & 15) >> 2);
+                }
+            }
+        }
+        n += chunk_n;
+    }
+    if (n == 0) {
+        if (lane == 0)
+            a.totals[b] = 0;
+        return;
+    }
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
-    float2 *__restrict__ lg = a.logs + (size_t)b * n_seg * a.cap2;
-    for (int j = lane; j < n; j += kWave)
-        ids[j] = __float_as_int(lg[pos[j]].y);
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_wave_barrier();
+    // (2) fp32 chains, (3) append
     const float tau = a.tau[(size_t)b * a.tau_stride];
+    float2 *__restrict__ lg = a.lists + (size_t)b * a.list_cap;
     const int sub = lane >> 3, q = lane & 7;   // loader role: row sub + 8 pass, 16-byte piece q of the k-block
     const int nkb = (a.d + kKB - 1) / kKB;
     const int total = ((n + kWave - 1) / kWave) * nkb;
+    int kept = 0;
 
-    auto issue = [&](int step, float4 (&v)[8]) {
+    // every step's loads are issued unconditionally (a step past the end repeats the last one): with a branch around them, or
+    // around the float4 / scalar forms, hipcc's wait-count pass cannot count the loads in flight and puts s_waitcnt vmcnt(0)
+    // in front of every LDS transpose -- each 64-entry step then pays a whole memory round trip (measured: 6 us per step)
+    auto issue = [&](int step_, float4 (&v)[8]) {
+        const int step = min(step_, total - 1);
         const int t0 = (step / nkb) * kWave, k = (step % nkb) * kKB + 4 * q;
 #pragma unroll
         for (int pass = 0; pass < 8; ++pass) {
-            const size_t ro = (size_t)ids[min(t0 + pass * 8 + sub, n - 1)] * a.d;
-            v[pass] = k < a.d ? *reinterpret_cast<const float4 *>(a.It + ro + k) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            const float *__restrict__ p = a.It + (size_t)ids[min(t0 + pass * 8 + sub, n - 1)] * a.d;
+            if constexpr (ALIGNED4) {
+                v[pass] = *reinterpret_cast<const float4 *>(p + min(k, a.d - 4));    // k past the row: a copy nobody chains
+            } else {
+                v[pass].x = p[min(k + 0, a.d - 1)];
+                v[pass].y = p[min(k + 1, a.d - 1)];
+                v[pass].z = p[min(k + 2, a.d - 1)];
+                v[pass].w = p[min(k + 3, a.d - 1)];
+            }
         }
     };
     float s = 0.0f;
@@ -386,29 +436,43 @@ __global__ __launch_bounds__(kRescoreWaves * 64) void k_rescore(const RescoreArg
         if (kb + kKB <= a.d) {
 #pragma unroll
             for (int kk = 0; kk < kKB; ++kk)
-                s = fmaf(urow[kb + kk], row[kk], s);
+                s = fmaf(su[kb + kk], row[kk], s);
         } else {
             for (int kk = 0; kk < a.d - kb; ++kk)
-                s = fmaf(urow[kb + kk], row[kk], s);
+                s = fmaf(su[kb + kk], row[kk], s);
         }
-        if (kb + kKB >= a.d && t0 + lane < n) {
-            const int p = pos[t0 + lane];
-            const int item = ids[t0 + lane];
-            lg[p] = make_float2(s, __int_as_float(s > tau ? item : INT_MAX));
+        if (kb + kKB >= a.d) {
+            const bool keep = t0 + lane < n && s > tau;
+            const unsigned long long m = __ballot(keep);
+            const int pos = kept + __popcll(m & ((1ull << lane) - 1ull));
+            if (keep && pos < a.list_cap)
+                lg[pos] = make_float2(s, __int_as_float(ids[t0 + lane]));
+            kept += __popcll(m);
         }
     };
-    float4 va[8], vb[8];
-    issue(0, va);
-    for (int step = 0; step < total; step += 2) {
-        if (step + 1 < total)
-            issue(step + 1, vb);
-        process(step, va);
-        if (step + 1 < total) {
-            if (step + 2 < total)
-                issue(step + 2, va);
-            process(step + 1, vb);
-        }
+    // three steps ahead: a wave is alone with its user, so the depth of its own prefetch is what hides the row latency
+    float4 v0[8], v1[8], v2[8], v3[8];
+    issue(0, v0);
+    issue(1, v1);
+    issue(2, v2);
+    for (int step = 0; step < total; step += 4) {
+        issue(step + 3, v3);
+        process(step, v0);
+        if (step + 1 >= total)
+            break;
+        issue(step + 4, v0);
+        process(step + 1, v1);
+        if (step + 2 >= total)
+            break;
+        issue(step + 5, v1);
+        process(step + 2, v2);
+        if (step + 3 >= total)
+            break;
+        issue(step + 6, v2);
+        process(step + 3, v3);
     }
+    if (lane == 0)
+        a.totals[b] = kept;
 }
 
 }  // namespace
@@ -426,17 +490,17 @@ int launch_tau_lo(const float *U, const int64_t *user_ids, int B, int d, const f
     return check_launch("k_tau_lo");
 }
 
-bool prefilter_supports(int d) { return d <= 128 && (d & 3) == 0; }
+bool prefilter_supports(int d) { return d <= 128; }
 
-int launch_prefilter(const float *U, const int64_t *user_ids, int B, const float *It, int I, int d, const float *tau_lo, void *logs,
-                     int *counts, int S, int items_per_split, int cap2, hipStream_t s)
+int launch_prefilter(const float *U, const int64_t *user_ids, int B, const float *It, int I, int d, const float *tau_lo,
+                     unsigned *mask, int Wh, int S, int items_per_split, hipStream_t s)
 {
-    PreArgs a{U, user_ids, It, tau_lo, static_cast<float2 *>(logs), counts, B, I, d, S, items_per_split, cap2};
+    PreArgs a{U, user_ids, It, tau_lo, mask, Wh, B, I, d, items_per_split};
     const dim3 grid((B + kUsersPerWG - 1) / kUsersPerWG, S);
     if (d == 64)
-        hipLaunchKernelGGL((k_score_prefilter<4, true, 128>), grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((k_score_prefilter<4, true, 256>), grid, dim3(256), 0, s, a);
     else if (d < 64)
-        hipLaunchKernelGGL((k_score_prefilter<4, false, 128>), grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((k_score_prefilter<4, false, 256>), grid, dim3(256), 0, s, a);
     else if (d == 128)
         hipLaunchKernelGGL((k_score_prefilter<8, true, 128>), grid, dim3(256), 0, s, a);
     else
@@ -444,12 +508,14 @@ int launch_prefilter(const float *U, const int64_t *user_ids, int B, const float
     return check_launch("k_score_prefilter");
 }
 
-int launch_rescore(const float *U, const int64_t *user_ids, int B, const float *It, int d, const float *tau, int tau_stride, void *logs,
-                   const int *counts, int S, int cap2, hipStream_t s)
+int launch_rescore(const float *U, const int64_t *user_ids, int B, const float *It, int d, const float *tau, int tau_stride,
+                   const unsigned *mask, int Wh, void *lists, int *totals, int list_cap, hipStream_t s)
 {
-    RescoreArgs a{U, user_ids, It, tau, tau_stride, static_cast<float2 *>(logs), counts, B, d, S, cap2};
-    const size_t lds = (size_t)kRescoreWaves * (16 * cap2 + kWave * kTileRow) * sizeof(float);
-    hipLaunchKernelGGL(k_rescore, dim3(B), dim3(kRescoreWaves * 64), lds, s, a);
+    RescoreArgs a{U, user_ids, It, tau, tau_stride, mask, Wh, static_cast<float2 *>(lists), totals, B, d, list_cap};
+    if ((d & 3) == 0)
+        hipLaunchKernelGGL(k_rescore<true>, dim3((B + 3) / 4), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(k_rescore<false>, dim3((B + 3) / 4), dim3(256), 0, s, a);
     return check_launch("k_rescore");
 }
 
