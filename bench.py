@@ -221,21 +221,24 @@ def batch_masks(users, mrp, mit, dev, ids_origin=0):
             torch.from_numpy(np.ascontiguousarray(items)).to(dev))
 
 
-def scoring_region(ue, ie, batches, k_top, dev, barrier):
+def scoring_region(ue, ie, batches, k_top, dev, barrier, prefilter=False):
     """Consecutive calls are independent: issued round-robin on three HIP streams with their own scratch buffers, as
-    LightGCN.predict does, so one call's small selection kernels run under the next call's GEMM.  Returns seconds."""
+    LightGCN.predict does, so one call's small selection kernels run under the next call's GEMM.  Returns seconds.
+    prefilter: tgcn_score_topk_prefilter_f32 (candidates from a bf16 pass, fp32 chains for every score: the same lists); the
+    item-norm factor of its bound is computed inside the timed region, once per region as predict does per call."""
     from textgcn_amd import scoring
     main = torch.cuda.current_stream(dev)
     side = [torch.cuda.Stream(dev) for _ in range(3)]
 
     def score_all(bts):   # the predict step of base_model.py:254-263, fused (tgcn_score_topk_f32)
+        norm = scoring.item_norm_max(ie) if prefilter else None
         for st in side:
             st.wait_stream(main)
         keep = []
         for j, (ids, rp, it) in enumerate(bts):
             with torch.cuda.stream(side[j % 3]):
                 keep.append(scoring.score_topk(ue, ie, k_top, user_ids=ids, mask_rowptr=rp, mask_items=it, round4=True,
-                                               slot=j % 3))
+                                               slot=j % 3, prefilter=prefilter, item_norm=norm))
         for st in side:
             main.wait_stream(st)
         return keep
@@ -369,6 +372,7 @@ def records_c3_c5(dev, want_c5=True, cpu=True):
             return m.representation
     reps = 10
     t_fwd = _timed(fwd, reps)
+    m.score_prefilter = False     # the record's own numbers: fp32 MFMA filter; the bf16-candidate path is reported beside them
     t_all = _timed(lambda: m.predict_tensors(users), 2)    # representation + fused scoring of every user
     t_score = t_all - t_fwd
     pairs = n_u * n_i
@@ -397,6 +401,21 @@ def records_c3_c5(dev, want_c5=True, cpu=True):
     m.evaluate()
     torch.cuda.synchronize()
     c3['scoring']['evaluate_wall_s_all_users'] = round(time.time() - t1, 4)
+    ref_v, ref_i = m.predict_tensors(users)
+    m.score_prefilter = True      # the model class's default
+    pv, pi = m.predict_tensors(users)
+    t_all_p = _timed(lambda: m.predict_tensors(users), 2)
+    m.evaluate()
+    torch.cuda.synchronize()
+    t1 = time.time()
+    m.evaluate()
+    torch.cuda.synchronize()
+    c3['scoring']['bf16_candidates'] = {
+        'what': 'LightGCN.score_prefilter = True (the class default): tgcn_score_topk_prefilter_f32',
+        'value': pairs / (t_all_p - t_fwd), 'unit': 'pairs/s', 'ms_total': (t_all_p - t_fwd) * 1e3,
+        'identical_to_fp32_path': bool(torch.equal(pv, ref_v) and torch.equal(pi, ref_i)),
+        'evaluate_wall_s_all_users': round(time.time() - t1, 4)}
+    del ref_v, ref_i, pv, pi
     ue, ie = fwd()
     if cpu:
         c3['cpu_baseline'], c3['verify'] = cpu_baseline_propagation(g, e0, K, gpu_out=torch.cat([ue, ie]), budget_s=4.0)
@@ -662,6 +681,19 @@ def main():
             'roofline': {'bound': 'mfma', 'achieved': round(flops / ts / 1e12 / max(world, 1), 2), 'peak': MFMA_F32_PEAK_TF,
                          'unit': 'TFLOP/s', 'frac': round(flops / ts / 1e12 / max(world, 1) / MFMA_F32_PEAK_TF, 4), 'traffic': None},
         }
+        # the same calls with the candidates found by the bf16 matrix pass (every score and the order still come from the
+        # fp32 chains): checked bit for bit against the fp32-filter outputs above, reported beside them -- `value` of this
+        # record stays the fp32 path
+        if d <= 128:
+            tp, keep_p = scoring_region(ue, ie, batches, k_top, dev, barrier, prefilter=True)
+            same = all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(keep, keep_p))
+            if sharded:
+                tp = reduce_max_sum([tp, 0.0])[0][0]
+            result['scoring']['bf16_candidates'] = {
+                'what': 'tgcn_score_topk_prefilter_f32: bf16 MFMA pass with a proven error bound keeps a superset of the candidates, '
+                        'k-ordered fp32 chains rescore them; top-k lists and scores identical to the fp32 path',
+                'value': pairs / tp, 'unit': 'pairs/s', 'ms_per_batch': tp / n_batches * 1e3,
+                'identical_to_fp32_path': bool(same), 'speedup': round(ts / tp, 3)}
         # the model class scores 16384 users per call (LightGCN.predict_chunk); same kernels, fewer launches
         big = min(16384, len(users_all))
         if not sharded and big > bsz:
@@ -672,6 +704,9 @@ def main():
             result['scoring']['large_batch'] = {'users_per_call': big, 'value': pb / tb, 'unit': 'pairs/s',
                                                 'ms_per_call': tb / n_big * 1e3,
                                                 'mfma_frac': round(2.0 * d * pb / tb / 1e12 / MFMA_F32_PEAK_TF, 4)}
+            if d <= 128:
+                tbp, _ = scoring_region(ue, ie, bb, k_top, dev, barrier, prefilter=True)
+                result['scoring']['large_batch']['bf16_candidates'] = {'value': pb / tbp, 'unit': 'pairs/s', 'ms_per_call': tbp / n_big * 1e3}
 
     # ---------------- CPU baseline beside it + verification of the timed outputs (rank 0, N = 1 only; outside the timed regions)
     if not sharded and not args.no_cpu_baseline:

@@ -232,6 +232,10 @@ def test_predict_streams_do_not_change_results(cuda, tmp_path):
     m.predict_streams, m._streams = 1, None
     v1, i1 = m.predict_tensors(users)
     assert torch.equal(i3, i1) and torch.equal(v3, v1)
+    assert m.score_prefilter          # the class default: candidates from the bf16 pass ...
+    m.score_prefilter = False         # ... and the fp32 MFMA filter: the same lists and scores
+    vf, jf = m.predict_tensors(users)
+    assert torch.equal(jf, i1) and torch.equal(vf, v1)
     with torch.no_grad():
         ue, ie = m.representation
     s = scoring.score_dense(ue.contiguous(), ie.contiguous(), user_ids=torch.from_numpy(users).to(cuda))

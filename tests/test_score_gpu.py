@@ -196,7 +196,8 @@ def _rand_mask(rng, b, n_items, lo, hi):
 
 
 @pytest.mark.parametrize('b,i,d,k', [(300, 20000, 64, 40), (257, 9000, 128, 20), (130, 12345, 256, 64), (64, 10000, 100, 1),
-                                     (2048, 50000, 64, 40), (5, 8193, 48, 7)])
+                                     (2048, 50000, 64, 40), (5, 8193, 48, 7), (130, 9000, 50, 10), (70, 20011, 101, 33),
+                                     (513, 16400, 127, 40)])
 def test_fused_topk_equals_dense_path(cuda, b, i, d, k):
     rng = np.random.default_rng(b + i + d + k)
     u = (rng.standard_normal((b, d)) * 0.1).astype(np.float32)
@@ -383,3 +384,19 @@ def test_item_norm_max(cuda):
         want = (np.maximum(np.abs(it.astype(np.float64)), 2.0 ** -50) ** 2).sum(axis=1).max()
         got = float(scoring.item_norm_max(torch.from_numpy(it).to(cuda)).item())
         assert abs(got - want) <= 1e-5 * want
+
+
+@pytest.mark.parametrize('b,i,d', [(2048, 50000, 64), (2048, 60000, 128)])
+def test_prefilter_keeps_the_fallback_rare(cuda, b, i, d):
+    """The exact fallback hides a filter that loses or floods candidates (the results stay right, the call gets slow): on
+    Gaussian embeddings the bf16-candidate path must hand no more users to it than a handful per call."""
+    from textgcn_amd import scoring
+    g = torch.Generator().manual_seed(d)
+    for _ in range(3):
+        ue = (torch.randn(b, d, generator=g) * 0.1).to(cuda)
+        ie = (torch.randn(i, d, generator=g) * 0.1).to(cuda)
+        counts = {}
+        for mode in (False, True):
+            scoring.score_topk(ue, ie, 40, prefilter=mode, slot=7)
+            counts[mode] = scoring.fallback_count(cuda, b, i, d, 40, slot=7)
+        assert counts[False] <= 2 and counts[True] <= 4, counts

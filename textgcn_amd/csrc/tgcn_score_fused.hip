@@ -943,7 +943,7 @@ Plan make_plan(int B, int I, int d, int k)
     p.Wh = (I + kStage - 1) / kStage;
     p.off_mask = o;
     if (d <= 128)
-        o += align256((size_t)((B + kUsersPerWG - 1) / kUsersPerWG) * kUsersPerWG * 2 * p.Wh * sizeof(unsigned));
+        o += align256((size_t)((B + 255) / 256) * 256 * 2 * p.Wh * sizeof(unsigned));   // rows of the bf16 filter's padded users
     p.off_logs = o, o += align256((size_t)B * p.S * 2 * p.cap2 * sizeof(float2));
     p.off_counts = o, o += align256((size_t)B * p.S * 2 * sizeof(int));
     p.flag_cap = B;   // every user may need the fallback (e.g. fully tied scores): 16 KB of partial lists each

@@ -29,7 +29,9 @@ using f32x2 = __attribute__((ext_vector_type(2))) float;
 using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
-constexpr int kUsersPerWG = 128;   // 4 waves x 32 users (the log layout of tgcn_score_fused.hip)
+constexpr int kPreWaves = 8;        // waves (x 32 users) per workgroup of the bf16 filter: every item row a workgroup stages is
+                                   // fetched from L2 once per 256 users (with 128 the 16 user tiles of a 2048-user call pulled
+                                   // 205 MB through L2 for a 12.8 MB table: the launch was bound by that)
 constexpr int kStage = 64;         // items per LDS stage
 
 __device__ __forceinline__ unsigned pack_bf16(float lo, float hi)
@@ -141,7 +143,7 @@ struct PreArgs {
     const int64_t *__restrict__ user_ids;
     const float *__restrict__ It;
     const float *__restrict__ tau_lo;
-    unsigned *__restrict__ mask;    // [B padded to 128][2][Wh] pass bits (layout: filter_pipelined in tgcn_score_fused.hip)
+    unsigned *__restrict__ mask;    // [B padded to 256][2][Wh] pass bits: word (user, h, unit), register t of the unit on bit 31 - t
     int Wh;
     int B, I, d, items_per_split;
 };
@@ -153,39 +155,39 @@ struct PreArgs {
 // lane-private logs the loop spent ~2000 issue cycles per unit on compare-and-branch and appends against 256 cycles of MFMA).
 // A stage's rows are requested one whole stage ahead; d <= 64 walks 256-item stages (four units, ~1400 issue cycles each for
 // the SIMD's two waves: shorter stages end before their successor's rows arrive).
-template <int KS, bool FULLK, int ST>
-__global__ __launch_bounds__(256) void k_score_prefilter(const PreArgs a)
+template <int KS, bool FULLK, int ST, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
 {
+    constexpr int T = WAVES * 64;              // threads; WAVES x 32 users per workgroup share every item stage
+    constexpr int UT = WAVES * 32;
     constexpr int DQ = 4 * KS;                 // float4 pieces per source row
     constexpr int RB = 32 * KS + 16;           // LDS row stride in bytes: bf16 row + 16 (conflict-free ds_read_b128 of a column slice)
-    constexpr int N = (ST * DQ) / 256;         // float4 pieces per thread per item stage
-    constexpr int NU = (kStage * DQ) / 256;    // ... per 64-user half tile
-    static_assert(ST % kStage == 0 && ST >= kUsersPerWG / 2, "the user tile passes through the stage buffers");
-    constexpr int kBuf = ST >= kUsersPerWG ? ST : kUsersPerWG;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[(ST >= kUsersPerWG ? 2 * ST : kUsersPerWG) * RB];
-    (void)kBuf;
+    constexpr int N = (ST * DQ) / T;           // float4 pieces per thread per item stage
+    constexpr int NU = (kStage * DQ) / T;      // ... per 64-user piece of the user tile
+    static_assert(ST % kStage == 0 && 2 * ST >= UT && (kStage * DQ) % T == 0, "the user tile passes through the stage buffers");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * ST * RB];
     const int lane = lane_id();
     const int w = threadIdx.x >> 6;
     const int r32 = lane & 31;
     const int h = lane >> 5;
-    const int u0 = blockIdx.x * kUsersPerWG;
+    const int u0 = blockIdx.x * UT;
     const int split = blockIdx.y;
     const int i_beg = split * a.items_per_split;
     const int i_end = min(a.I, i_beg + a.items_per_split);
 
-    // M x 256 16-byte pieces of consecutive source rows -> registers (rows past the table clamped to the last one: every load
+    // M x T 16-byte pieces of consecutive source rows -> registers (rows past the table clamped to the last one: every load
     // unconditional when FULLK), and from there, as bf16, into LDS rows
     auto load = [&](auto &v, const float *__restrict__ src, const int64_t *__restrict__ ids, int row0, int n_rows) {
         constexpr int M = sizeof(v) / sizeof(float4);
         size_t srow[M];
 #pragma unroll
         for (int i = 0; i < M; ++i) {
-            const int r = min(row0 + (i * 256 + (int)threadIdx.x) / DQ, n_rows - 1);
+            const int r = min(row0 + (i * T + (int)threadIdx.x) / DQ, n_rows - 1);
             srow[i] = ids ? (size_t)ids[r] : (size_t)r;
         }
 #pragma unroll
         for (int i = 0; i < M; ++i) {
-            const int k = ((i * 256 + (int)threadIdx.x) % DQ) * 4;
+            const int k = ((i * T + (int)threadIdx.x) % DQ) * 4;
             const float *p = src + srow[i] * a.d;
             if constexpr (FULLK) {
                 v[i] = *reinterpret_cast<const float4 *>(p + k);
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(256) void k_score_prefilter(const PreArgs a)
         constexpr int M = sizeof(v) / sizeof(float4);
 #pragma unroll
         for (int i = 0; i < M; ++i) {
-            const int f = i * 256 + threadIdx.x;
+            const int f = i * T + threadIdx.x;
             const int r = f / DQ, q = f % DQ;
             *reinterpret_cast<uint2 *>(dst + r * RB + q * 8) = make_uint2(pack_bf16(v[i].x, v[i].y), pack_bf16(v[i].z, v[i].w));
         }
@@ -210,14 +212,15 @@ __global__ __launch_bounds__(256) void k_score_prefilter(const PreArgs a)
     const int user = u0 + w * 32 + r32;
     const bool user_ok = user < a.B;
     float4 nxt[N];
-    {
+    {   // the user tile in 64-row pieces; the first item stage is requested before the last piece is stored
         float4 v[NU];
-        load(v, a.U, a.user_ids, u0, a.B);
-        store(smem, v);
-        load(v, a.U, a.user_ids, u0 + kStage, a.B);
-        if (i_beg < i_end)
-            load(nxt, a.It, nullptr, i_beg, i_end);
-        store(smem + kStage * RB, v);
+#pragma unroll
+        for (int piece = 0; piece < UT / kStage; ++piece) {
+            load(v, a.U, a.user_ids, u0 + piece * kStage, a.B);
+            if (piece == UT / kStage - 1 && i_beg < i_end)
+                load(nxt, a.It, nullptr, i_beg, i_end);
+            store(smem + piece * kStage * RB, v);
+        }
     }
     const float tau = user_ok ? a.tau_lo[user] : INFINITY;
     __syncthreads();
@@ -496,15 +499,16 @@ int launch_prefilter(const float *U, const int64_t *user_ids, int B, const float
                      unsigned *mask, int Wh, int S, int items_per_split, hipStream_t s)
 {
     PreArgs a{U, user_ids, It, tau_lo, mask, Wh, B, I, d, items_per_split};
-    const dim3 grid((B + kUsersPerWG - 1) / kUsersPerWG, S);
+    constexpr int UT = kPreWaves * 32;
+    const dim3 grid((B + UT - 1) / UT, S), block(kPreWaves * 64);
     if (d == 64)
-        hipLaunchKernelGGL((k_score_prefilter<4, true, 256>), grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((k_score_prefilter<4, true, 256, kPreWaves>), grid, block, 0, s, a);
     else if (d < 64)
-        hipLaunchKernelGGL((k_score_prefilter<4, false, 256>), grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((k_score_prefilter<4, false, 256, kPreWaves>), grid, block, 0, s, a);
     else if (d == 128)
-        hipLaunchKernelGGL((k_score_prefilter<8, true, 128>), grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((k_score_prefilter<8, true, 128, kPreWaves>), grid, block, 0, s, a);
     else
-        hipLaunchKernelGGL((k_score_prefilter<8, false, 128>), grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((k_score_prefilter<8, false, 128, kPreWaves>), grid, block, 0, s, a);
     return check_launch("k_score_prefilter");
 }
 
