@@ -77,7 +77,9 @@ typedef struct tgcn_split_plan {
  * `plan` may be NULL (every row summed by one wave: bit-identical to the reference's CPU result).
  * `row_order` (optional, [n_rows], a permutation of the row ids): the order in which rows are handed to
  * wavefronts.  Results do not depend on it; descending row length (longest work first) shortens the launch's
- * tail -- 6 % on BASELINE config 2.  Honoured by the wave-per-row kernel. */
+ * tail -- 6 % on BASELINE config 2.  Honoured by the wave-per-row kernel.
+ * d in {8, 16, 32} (a rank's share of the columns under the feature partition, dist.ColumnShardedPropagator) runs the
+ * narrow form: d/4 lanes per source row, 64 / (d/4) entries per wave instruction, the same chains and long-row chunks. */
 int tgcn_spmm_csr_f32(const int32_t *rowptr, const int32_t *colidx, const float *vals, int64_t n_rows,
                       const float *X, int64_t n_src_rows, int32_t d, float *Y, const float *acc_in,
                       float *acc_out, float acc_div, const tgcn_split_plan_t *plan, const int32_t *row_order,
