@@ -231,7 +231,7 @@ def scoring_region(ue, ie, batches, k_top, dev, barrier, prefilter=False):
     side = [torch.cuda.Stream(dev) for _ in range(3)]
 
     def score_all(bts):   # the predict step of base_model.py:254-263, fused (tgcn_score_topk_f32)
-        norm = scoring.item_norm_max(ie) if prefilter else None
+        norm = scoring.item_norms(ie) if prefilter else None
         for st in side:
             st.wait_stream(main)
         keep = []

@@ -78,7 +78,7 @@ def test_c_abi_rejects_bad_arguments_with_message(built_lib):
     rc = lib.tgcn_score_topk_prefilter_f32(None, None, 4, None, 100, 64, None, None, 10, 0, None, None, None, None, 0, None)
     assert rc == -1
     assert lib.tgcn_score_topk_prefilter_f32(None, None, 0, None, 100, 64, None, None, 10, 0, None, None, None, None, 0, None) == 0
-    rc = lib.tgcn_item_norm_max_f32(None, 10, 64, None, None)
+    rc = lib.tgcn_item_norms_f32(None, 10, 64, None, None)
     assert rc == -1 and b'NULL' in lib.tgcn_last_error()
     rc = lib.tgcn_score_topk_fallback_count(None, 4, 100, 64, 10, None, None)
     assert rc == -1

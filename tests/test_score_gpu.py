@@ -178,7 +178,7 @@ def _fused_vs_dense(cuda, u, it, k, mask=None, user_ids=None, round4=True):
     assert np.array_equal(bits(v.cpu().numpy()), bits(rv.cpu().numpy()))
     # the bf16-prefiltered entry point (tgcn_score_topk_prefilter_f32): the same bits, with the item norm computed inside the
     # call and handed in
-    for norm in (None, scoring.item_norm_max(itd)):
+    for norm in (None, scoring.item_norms(itd)):
         pv, pi = scoring.score_topk(ud, itd, k, user_ids=ids, mask_rowptr=rp, mask_items=it_, round4=round4, prefilter=True,
                                     item_norm=norm)
         torch.cuda.synchronize()
@@ -376,14 +376,37 @@ def test_prefilter_bound_under_worst_case_rounding(cuda, d):
     _fused_vs_dense(cuda, u2, it2, k, mask=_rand_mask(rng, b, i, 0, 20), round4=False)
 
 
-def test_item_norm_max(cuda):
+def test_item_norms(cuda):
+    """the item factors of the bound: never below the floored Euclidean norm, within 2^-11 above it; an infinite row gives +inf
+    (a NaN element needs nothing from the bound: the pair's bf16 score is NaN, which passes the test by itself)"""
     from textgcn_amd import scoring
     rng = np.random.default_rng(3)
-    for n, d in ((50000, 64), (777, 128), (1000, 100), (5, 32)):
+    for n, d in ((50000, 64), (777, 128), (1000, 100), (5, 32), (3, 16)):
         it = (rng.standard_normal((n, d)) * 0.3).astype(np.float32)
-        want = (np.maximum(np.abs(it.astype(np.float64)), 2.0 ** -50) ** 2).sum(axis=1).max()
-        got = float(scoring.item_norm_max(torch.from_numpy(it).to(cuda)).item())
-        assert abs(got - want) <= 1e-5 * want
+        if n > 100:
+            it[7, 3] = np.inf
+            it[9, 0] = np.nan
+            it[11] = 0.0
+        want = np.sqrt((np.maximum(np.abs(it.astype(np.float64)), 2.0 ** -50) ** 2).sum(axis=1))
+        got = scoring.item_norms(torch.from_numpy(it).to(cuda)).cpu().numpy().astype(np.float64)
+        fin = np.isfinite(want)
+        assert np.all(got[fin] >= want[fin]) and np.all(got[fin] <= want[fin] * (1 + 2.0 ** -11))
+        assert np.all(np.isposinf(got[np.isposinf(want)]))
+
+
+def test_prefilter_outlier_item_does_not_flood_the_lists(cuda):
+    """The bound is per (user, item) pair: one item row of enormous norm (here 1000x the rest, pointing away from every user)
+    becomes everybody's candidate but must not hand the users to the exact fallback, and the lists stay the dense path's."""
+    from textgcn_amd import scoring
+    rng = np.random.default_rng(8)
+    b, i, d, k = 512, 30000, 64, 40
+    u = np.abs(rng.standard_normal((b, d)) * 0.1).astype(np.float32)
+    it = (rng.standard_normal((i, d)) * 0.1).astype(np.float32)
+    it[12345] = -100.0
+    _fused_vs_dense(cuda, u, it, k, mask=_rand_mask(rng, b, i, 0, 20), round4=False)
+    ud, itd = torch.from_numpy(u).to(cuda), torch.from_numpy(it).to(cuda)
+    scoring.score_topk(ud, itd, k, prefilter=True, slot=7)
+    assert scoring.fallback_count(cuda, b, i, d, k, slot=7) <= 2
 
 
 @pytest.mark.parametrize('b,i,d', [(2048, 50000, 64), (2048, 60000, 128)])

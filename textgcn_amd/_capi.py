@@ -45,7 +45,7 @@ _SIGNATURES = {
     'tgcn_score_topk_prefilter_f32': (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int32,
                                                      c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     'tgcn_score_topk_fallback_count': (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, POINTER(c_int32), c_void_p]),
-    'tgcn_item_norm_max_f32': (ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+    'tgcn_item_norms_f32': (ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     'tgcn_ltr_folded_width': (c_int32, [c_int32, c_int32]),
     'tgcn_ltr_fold_users_f32': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
                                                POINTER(c_float), c_float, c_void_p, c_void_p]),

@@ -77,13 +77,22 @@ __device__ __forceinline__ float floored_sq(float x)
     return f * f;
 }
 __device__ __forceinline__ float nan_max(float a, float b) { return (b > a || !(b == b)) ? b : a; }   // a NaN sticks
-// tau' = tau - c |u~| M from the squared norms; a non-finite bound gives -inf (everything is logged -> the exact fallback)
-__device__ __forceinline__ float lowered_tau(float tau, float user_sq, float item_sq_max)
+// the two factors of the bound c |u~| |y~| from floored squared norms, each rounded up; a non-finite norm gives +inf (every
+// pair of that user / item is then kept as a candidate and decided by its fp32 score)
+__device__ __forceinline__ float bound_user_factor(float user_sq)
 {
-    const float c = 0x1p-7f * (1.0f + 0x1p-4f);
-    const float delta = c * sqrtf(user_sq) * sqrtf(item_sq_max);
-    const float t = tau - delta;
-    return (delta < INFINITY && t == t) ? t : -INFINITY;
+    const float f = 0x1p-7f * (1.0f + 0x1p-4f) * sqrtf(user_sq) * (1.0f + 0x1p-12f);
+    return f < INFINITY ? f : INFINITY;      // (a NaN compares false)
+}
+__device__ __forceinline__ float bound_item_factor(float item_sq)
+{
+    const float f = sqrtf(item_sq) * (1.0f + 0x1p-12f);
+    return f < INFINITY ? f : INFINITY;
+}
+// smallest bf16 >= x for x >= 0 (or +inf), as the high half of a float: the bound's factors enter the bf16 product rounded UP
+__device__ __forceinline__ unsigned bf16_up_bits(float x)
+{
+    return x < INFINITY ? (__float_as_uint(x) + 0xFFFFu) >> 16 : 0x7F80u;
 }
 
 // launchers shared between translation units (arguments already validated by the caller)
@@ -93,11 +102,10 @@ int launch_score_dense_filter(const float *U, const int64_t *user_ids, int B, co
                               int tau_stride, void *logs, int *counts, int S, int items_per_split, int cap2, hipStream_t stream);
 // tgcn_score_prefilter.hip: candidates from a bf16 pass, rescored in fp32
 bool prefilter_supports(int d);
-int launch_item_norm_part(const float *It, int I, int d, float *part, int n_part, float *total, hipStream_t stream);
-int launch_tau_lo(const float *U, const int64_t *user_ids, int B, int d, const float *tau, int tau_stride, const float *part,
-                  int n_part, float *tau_lo, hipStream_t stream);
-int launch_prefilter(const float *U, const int64_t *user_ids, int B, const float *It, int I, int d, const float *tau_lo,
-                     unsigned *mask, int Wh, int S, int items_per_split, hipStream_t stream);
+int launch_item_norms(const float *It, int I, int d, float *norms, hipStream_t stream);
+int launch_user_bound(const float *U, const int64_t *user_ids, int B, int d, float *ubound, hipStream_t stream);
+int launch_prefilter(const float *U, const int64_t *user_ids, int B, const float *It, int I, int d, const float *tau, int tau_stride,
+                     const float *ubound, const float *inorm, unsigned *mask, int Wh, int S, int items_per_split, hipStream_t stream);
 int launch_rescore(const float *U, const int64_t *user_ids, int B, const float *It, int d, const float *tau, int tau_stride,
                    const unsigned *mask, int Wh, void *lists, int *totals, int list_cap, hipStream_t stream);
 int launch_topk(const float *S, int64_t lds, int B, int I, int k, int do_round, float *out_val, int64_t *out_idx,

@@ -38,7 +38,6 @@ constexpr int kTauRank = 10;       // tau = kTauRank-th largest masked sample sc
 constexpr int kUsersPerWG = 128;   // 4 waves x 32 users
 constexpr int kStage = 64;         // items per LDS stage (2 MFMA sub-tiles of 32)
 constexpr int kSmallI = 8192;      // below this the dense path (score -> mask -> top-k) is used
-constexpr int kNormParts = 1024;   // workgroups of the item-norm pass (prefilter mode)
 
 #ifdef TGCN_FILTER_PROBE
 // diagnostic build only (tools/filter_probe.py compiles its own copy with -DTGCN_FILTER_PROBE; never in libtgcn.so): per
@@ -483,14 +482,13 @@ constexpr int kMaskCache = 512;  // train items per user cached in LDS for the m
 // staged in LDS (coalesced load, mask applied by the lanes that own the train items), read back VPL values per lane, and
 // the maximum is extracted kTauRank times (per-lane max, wave max, the owning lane retires one copy).  Replaces the
 // k_mask + k_topk pair on the sample (28 us for 2048 x 1563 -> ~4 us) and zeroes the fallback counter for this call.
-// Prefilter mode (tau_lo != NULL): the lowered threshold of tgcn_score_prefilter.hip is written too -- the user's floored
-// squared norm and the maximum of the item-norm partials are fetched before the rounds and cost no extra launch.
+// Prefilter mode (ubound != NULL): the user's factor c |x~_u| of tgcn_score_prefilter.hip's bound is written too -- the row is
+// fetched before the rounds and costs no extra launch.
 template <int VPL>
 __global__ __launch_bounds__(256) void k_tau(const float *__restrict__ Ss, int m_ld, int B, int m, const int *__restrict__ mask_rowptr,
                                              const int *__restrict__ mask_items, float *__restrict__ tau, int *__restrict__ flagged,
                                              int *__restrict__ done, const float *__restrict__ U, const int64_t *__restrict__ user_ids,
-                                             int d, const float *__restrict__ norm_part, int n_part, float *__restrict__ tau_lo,
-                                             int *__restrict__ totals)
+                                             int d, float *__restrict__ ubound, int *__restrict__ totals)
 {
     extern __shared__ float srow[];   // [4][64 * VPL]
     const int lane = lane_id();
@@ -512,13 +510,11 @@ __global__ __launch_bounds__(256) void k_tau(const float *__restrict__ Ss, int m
         const int j = lane + kWave * i;
         row[j] = (ok && j < m) ? Ss[(size_t)b * m_ld + j] : -INFINITY;
     }
-    float usq = 0.0f, isq = 0.0f;
-    if (tau_lo && ok) {
+    float usq = 0.0f;
+    if (ubound && ok) {
         const float *__restrict__ p = U + (size_t)(user_ids ? user_ids[b] : b) * d;
         for (int k = lane; k < d; k += kWave)
             usq += floored_sq(p[k]);
-        for (int i = lane; i < n_part; i += kWave)
-            isq = nan_max(isq, norm_part[i]);
     }
     __syncthreads();
     if (ok && mask_rowptr) {
@@ -549,17 +545,15 @@ __global__ __launch_bounds__(256) void k_tau(const float *__restrict__ Ss, int m
             a1 = -INFINITY;
         }
     }
-    if (tau_lo) {
+    if (ubound) {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
+        for (int o = 32; o > 0; o >>= 1)
             usq += __shfl_xor(usq, o);
-            isq = nan_max(isq, __shfl_xor(isq, o));
-        }
     }
     if (ok && lane == 0) {
         tau[b] = t;
-        if (tau_lo)
-            tau_lo[b] = lowered_tau(t, usq, isq);
+        if (ubound)
+            ubound[b] = bound_user_factor(usq);
     }
 }
 
@@ -938,8 +932,10 @@ Plan make_plan(int B, int I, int d, int k)
     p.off_tauv = o, o += align256((size_t)B * kTauRank * sizeof(float));
     p.off_taui = o, o += align256((size_t)B * kTauRank * sizeof(int64_t));
     p.off_tau = o, o += align256((size_t)B * sizeof(float));
-    p.off_taulo = o, o += align256((size_t)B * sizeof(float));             // prefilter mode: the lowered thresholds
-    p.off_npart = o, o += align256((size_t)kNormParts * sizeof(float));    // and the per-workgroup item-norm maxima
+    p.off_taulo = o, o += align256((size_t)B * sizeof(float));             // prefilter mode: the users' factors of the bound
+    p.off_npart = o;                                                       // ... and the items' (unless the caller holds them)
+    if (d <= 128)
+        o += align256((size_t)I * sizeof(float));
     p.Wh = (I + kStage - 1) / kStage;
     p.off_mask = o;
     if (d <= 128)
@@ -1011,7 +1007,7 @@ extern "C" int64_t tgcn_score_topk_workspace_bytes(int32_t B, int32_t I, int32_t
 
 namespace {
 // prefilter: candidates from the bf16 pass of tgcn_score_prefilter.hip, rescored in fp32 (same results; d <= 128, d % 4 == 0,
-// otherwise the fp32 filter runs).  item_norm: device pointer to max_i sum_j max(|y_ij|, 2^-50)^2 (tgcn_item_norm_max_f32), or
+// otherwise the fp32 filter runs).  item_norms: device pointer to the I item factors of the bound (tgcn_item_norms_f32), or
 // NULL: computed by this call.
 int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const float *It, int32_t I, int32_t d,
                     const int32_t *mask_rowptr, const int32_t *mask_items, int32_t k, int32_t round4, float *out_val,
@@ -1045,15 +1041,13 @@ int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const fl
 
     // prefilter mode: the item-side factor of the bound, unless the caller holds it
     prefilter = prefilter && prefilter_supports(d);
-    float *tau_lo = prefilter ? reinterpret_cast<float *>(ws + p.off_taulo) : nullptr;
-    const float *npart = item_norm;
-    int n_part = 1;
-    if (prefilter && !npart) {
+    float *ubound = prefilter ? reinterpret_cast<float *>(ws + p.off_taulo) : nullptr;
+    const float *inorm = item_norm;
+    if (prefilter && !inorm) {
         float *np = reinterpret_cast<float *>(ws + p.off_npart);
-        n_part = min(kNormParts, (I + 63) / 64);
-        if ((rc = launch_item_norm_part(It, I, d, np, n_part, nullptr, s)) != TGCN_OK)
+        if ((rc = launch_item_norms(It, I, d, np, s)) != TGCN_OK)
             return rc;
-        npart = np;
+        inorm = np;
     }
     // 1. tau from a strided item sample
     float *Ss = reinterpret_cast<float *>(ws + p.off_sample);
@@ -1072,10 +1066,10 @@ int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const fl
         const int vpl = p.m <= 8 * kWave ? 8 : p.m <= 16 * kWave ? 16 : p.m <= 32 * kWave ? 32 : 64;
         const size_t lds = (size_t)4 * kWave * vpl * sizeof(float);
         switch (vpl) {
-            case 8: hipLaunchKernelGGL((k_tau<8>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, tau1, flagged, done, U, user_ids, d, npart, n_part, tau_lo, totals); break;
-            case 16: hipLaunchKernelGGL((k_tau<16>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, tau1, flagged, done, U, user_ids, d, npart, n_part, tau_lo, totals); break;
-            case 32: hipLaunchKernelGGL((k_tau<32>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, tau1, flagged, done, U, user_ids, d, npart, n_part, tau_lo, totals); break;
-            default: hipLaunchKernelGGL((k_tau<64>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, tau1, flagged, done, U, user_ids, d, npart, n_part, tau_lo, totals); break;
+            case 8: hipLaunchKernelGGL((k_tau<8>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, tau1, flagged, done, U, user_ids, d, ubound, totals); break;
+            case 16: hipLaunchKernelGGL((k_tau<16>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, tau1, flagged, done, U, user_ids, d, ubound, totals); break;
+            case 32: hipLaunchKernelGGL((k_tau<32>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, tau1, flagged, done, U, user_ids, d, ubound, totals); break;
+            default: hipLaunchKernelGGL((k_tau<64>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, tau1, flagged, done, U, user_ids, d, ubound, totals); break;
         }
         if ((rc = check_launch("k_tau")) != TGCN_OK)
             return rc;
@@ -1098,9 +1092,14 @@ int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const fl
     fa.B = B, fa.I = I, fa.d = d, fa.S = p.S, fa.items_per_split = p.items_per_split, fa.cap2 = p.cap2;
     if (prefilter) {   // pass bits from the bf16 GEMM, then candidates -> fp32 chains -> flat (score, item) lists
         unsigned *mask = reinterpret_cast<unsigned *>(ws + p.off_mask);
-        if (tau_stride != 1 && (rc = launch_tau_lo(U, user_ids, B, d, tau_ptr, tau_stride, npart, n_part, tau_lo, s)) != TGCN_OK)
-            return rc;       // (the k_tau launch wrote tau_lo itself)
-        if ((rc = launch_prefilter(U, user_ids, B, It, I, d, tau_lo, mask, p.Wh, p.S, p.items_per_split, s)) != TGCN_OK)
+        if (tau_stride != 1 && (rc = launch_user_bound(U, user_ids, B, d, ubound, s)) != TGCN_OK)
+            return rc;       // (the k_tau launch wrote the users' factors itself)
+        // its own item splits: pass bits are indexed by unit, not by split, so the grid may be finer than k_select's 32 segments.
+        // Measured (2048 users, rocprofv3): d = 128, 60 k items 68.6 -> 62.2 us with 1024-item splits; d = 64, 50 k items
+        // 37.5 -> 41.4 us (the 256-user tile is re-staged per workgroup): finer only for the wide rows
+        const int ips_pre = (d > 64 && I <= (1 << 18)) ? 1024 : p.items_per_split;
+        if ((rc = launch_prefilter(U, user_ids, B, It, I, d, tau_ptr, tau_stride, ubound, inorm, mask, p.Wh, (I + ips_pre - 1) / ips_pre,
+                                   ips_pre, s)) != TGCN_OK)
             return rc;
         rc = launch_rescore(U, user_ids, B, It, d, tau_ptr, tau_stride, mask, p.Wh, fa.logs, totals, p.S * 2 * p.cap2, s);
     } else if (d <= 128) {
@@ -1172,16 +1171,12 @@ extern "C" int tgcn_score_topk_fallback_count(const void *workspace, int32_t B, 
     return TGCN_OK;
 }
 
-extern "C" int tgcn_item_norm_max_f32(const float *It, int32_t I, int32_t d, float *out, tgcn_stream_t stream)
+extern "C" int tgcn_item_norms_f32(const float *It, int32_t I, int32_t d, float *out, tgcn_stream_t stream)
 {
     TGCN_REQUIRE(I >= 0, "negative size");
     TGCN_REQUIRE(d > 0 && d <= 4096, "d out of range");
-    TGCN_REQUIRE(out, "NULL pointer");
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(out, 0, sizeof(float), s) != hipSuccess)
-        return check_launch("hipMemsetAsync(item norm)");
     if (I == 0)
         return TGCN_OK;
-    TGCN_REQUIRE(It, "NULL pointer");
-    return launch_item_norm_part(It, I, d, nullptr, min(kNormParts, (I + 63) / 64), out, s);
+    TGCN_REQUIRE(It && out, "NULL pointer");
+    return launch_item_norms(It, I, d, out, static_cast<hipStream_t>(stream));
 }

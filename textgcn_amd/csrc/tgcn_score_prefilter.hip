@@ -13,11 +13,14 @@
 //   |sum_j a_j b_j - sum_j x_j y_j| <= (2^-7 + 2^-16) sum_j x~_j y~_j <= (2^-7 + 2^-16) |x~|_2 |y~|_2       (Cauchy-Schwarz)
 // the matrix pipe's fp32 accumulation of the d <= 256 exact bf16 products and the fp32 chain's own rounding add at most
 // 2^-11 sum_j |x_j y_j| between them (budgeted ~30x above d 2^-23 + d 2^-24; products below 2^-126 that flush are below the
-// floor's 2^-108).  So with c = 2^-7 (1 + 2^-4) and M = max_i |y~_i|_2:
-//   score(u, i) > tau_u   ==>   approx(u, i) > tau_u - c |x~_u|_2 M =: tau'_u.
-// Norms are fp32 sums of squares of the floored values (never underestimated by more than 2^-20 relatively: inside c's
-// slack).  Non-finite data: a non-finite tau' becomes -inf (everything is logged -> log overflow -> the exact fallback), and the
-// test is !(approx <= tau') so that a NaN approximation (inf - inf in bf16 only) is kept and decided by its fp32 score.
+// floor's 2^-108).  So with c = 2^-7 (1 + 2^-4):
+//   score(u, i) > tau_u   ==>   approx(u, i) + c |x~_u|_2 |y~_i|_2 > tau_u.
+// The second term is computed BY the matrix pipe: one more 16-wide k-step whose only non-zero operands are the two factors
+// c |x~_u| and |y~_i| (fp32 sums of squares of the floored values, square root, a 2^-12 margin, rounded UP to bf16), so the
+// test stays one compare of the accumulator against tau_u.  The bound is per PAIR: one item row of enormous norm becomes a
+// candidate for everybody but does not loosen anybody else's test (with max_i |y~_i| in its place one such row floods every
+// user's list and hands the whole call to the exact fallback).  Non-finite data: a non-finite norm becomes +inf, the
+// accumulator +inf or NaN, and the test is !(acc <= tau) -- the pair is kept and decided by its fp32 score.
 #include "tgcn_internal.h"
 #include "tgcn_topk.h"
 
@@ -48,14 +51,14 @@ __device__ __forceinline__ float wave_sum_f(float v)
     return v;
 }
 
-// ---- item norms: part[g] = max over workgroup g's rows of sum_j max(|y_j|, floor)^2 ----------------------------------------
+// ---- item factors: norms[i] = |y~_i| (rounded up) ------------------------------------------------------------------------
 // G = d / 4 lanes per row (a power of two <= 32): one 16-byte piece per lane, 64 / G rows per wave instruction, four in flight
 template <int G>
-__device__ __forceinline__ float norm_rows_pow2(const float *__restrict__ It, int I, int d, int wave, int n_waves, int lane)
+__device__ __forceinline__ void norm_rows_pow2(const float *__restrict__ It, int I, int d, int wave, int n_waves, int lane,
+                                               float *__restrict__ norms)
 {
     constexpr int R = kWave / G;
     const int sub = lane / G, q = lane % G;
-    float best = 0.0f;
     for (int r0 = wave * 4 * R; r0 < I; r0 += n_waves * 4 * R) {
         float4 v[4];
 #pragma unroll
@@ -67,74 +70,53 @@ __device__ __forceinline__ float norm_rows_pow2(const float *__restrict__ It, in
 #pragma unroll
             for (int o = G / 2; o > 0; o >>= 1)
                 t += __shfl_xor(t, o);
-            best = nan_max(best, t);
+            const int r = r0 + u * R + sub;
+            if (q == 0 && r < I)
+                norms[r] = bound_item_factor(t);
         }
     }
-    return best;
 }
 
-__global__ __launch_bounds__(256) void k_item_norm_part(const float *__restrict__ It, int I, int d, float *__restrict__ part,
-                                                        unsigned *__restrict__ total)
+__global__ __launch_bounds__(256) void k_item_norms(const float *__restrict__ It, int I, int d, float *__restrict__ norms)
 {
-    __shared__ float sm[4];
     const int lane = lane_id();
-    const int w = threadIdx.x >> 6;
-    const int wave = blockIdx.x * 4 + w, n_waves = gridDim.x * 4;
-    float best = 0.0f;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
     if (d == 64)
-        best = norm_rows_pow2<16>(It, I, d, wave, n_waves, lane);
+        norm_rows_pow2<16>(It, I, d, wave, n_waves, lane, norms);
     else if (d == 128)
-        best = norm_rows_pow2<32>(It, I, d, wave, n_waves, lane);
+        norm_rows_pow2<32>(It, I, d, wave, n_waves, lane, norms);
     else if (d == 32)
-        best = norm_rows_pow2<8>(It, I, d, wave, n_waves, lane);
+        norm_rows_pow2<8>(It, I, d, wave, n_waves, lane, norms);
     else if (d == 16)
-        best = norm_rows_pow2<4>(It, I, d, wave, n_waves, lane);
+        norm_rows_pow2<4>(It, I, d, wave, n_waves, lane, norms);
     else {
         for (int r = wave; r < I; r += n_waves) {
             const float *__restrict__ p = It + (size_t)r * d;
             float s = 0.0f;
             for (int k = lane; k < d; k += kWave)
                 s += floored_sq(p[k]);
-            best = nan_max(best, wave_sum_f(s));
+            s = wave_sum_f(s);
+            if (lane == 0)
+                norms[r] = bound_item_factor(s);
         }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-        best = nan_max(best, __shfl_xor(best, o));
-    if (lane == 0)
-        sm[w] = best;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const float b = nan_max(nan_max(sm[0], sm[1]), nan_max(sm[2], sm[3]));
-        if (part)
-            part[blockIdx.x] = b;
-        if (total)   // non-negative floats (and NaNs above them) order as their bit patterns
-            atomicMax(total, __float_as_uint(b));
     }
 }
 
-// ---- tau' = tau - c |u~| M: one wave per user ----------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_tau_lo(const float *__restrict__ U, const int64_t *__restrict__ user_ids, int B, int d,
-                                                const float *__restrict__ tau, int tau_stride, const float *__restrict__ part,
-                                                int n_part, float *__restrict__ tau_lo)
+// ---- user factors c |x~_u| (rounded up): one wave per user (catalogues too large for k_tau, which writes them itself) -------
+__global__ __launch_bounds__(256) void k_user_bound(const float *__restrict__ U, const int64_t *__restrict__ user_ids, int B, int d,
+                                                    float *__restrict__ ubound)
 {
     const int lane = lane_id();
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B)
         return;
-    float m2 = 0.0f;
-    for (int i = lane; i < n_part; i += kWave)
-        m2 = nan_max(m2, part[i]);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-        m2 = nan_max(m2, __shfl_xor(m2, o));
     const float *__restrict__ p = U + (size_t)(user_ids ? user_ids[b] : b) * d;
     float s = 0.0f;
     for (int k = lane; k < d; k += kWave)
         s += floored_sq(p[k]);
     s = wave_sum_f(s);
     if (lane == 0)
-        tau_lo[b] = lowered_tau(tau[(size_t)b * tau_stride], s, m2);
+        ubound[b] = bound_user_factor(s);
 }
 
 // ---- the bf16 filter ------------------------------------------------------------------------------------------------------
@@ -142,7 +124,10 @@ struct PreArgs {
     const float *__restrict__ U;
     const int64_t *__restrict__ user_ids;
     const float *__restrict__ It;
-    const float *__restrict__ tau_lo;
+    const float *__restrict__ tau;      // tau of user b at tau[b * tau_stride]
+    int tau_stride;
+    const float *__restrict__ ubound;   // c |x~_u|  (k_tau / k_user_bound)
+    const float *__restrict__ inorm;    // |y~_i|    (k_item_norms)
     unsigned *__restrict__ mask;    // [B padded to 256][2][Wh] pass bits: word (user, h, unit), register t of the unit on bit 31 - t
     int Wh;
     int B, I, d, items_per_split;
@@ -209,20 +194,42 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
         }
     };
 
+    // the item rows' factors |y~_i| of the bound travel with the stage: element 0 of the row's 16-byte pad chunk, zeros behind
+    auto load_norms = [&](float (&nn)[N], int row0, int n_rows) {
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            nn[i] = a.inorm[min(row0 + (i * T + (int)threadIdx.x) / DQ, n_rows - 1)];
+    };
+    auto store_norms = [&](unsigned char *dst, const float (&nn)[N]) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int f = i * T + threadIdx.x;
+            if (f % DQ == 0)
+                *reinterpret_cast<uint4 *>(dst + (f / DQ) * RB + 32 * KS) = make_uint4(bf16_up_bits(nn[i]), 0u, 0u, 0u);
+        }
+    };
+
     const int user = u0 + w * 32 + r32;
     const bool user_ok = user < a.B;
     float4 nxt[N];
+    float nxt_n[N];
     {   // the user tile in 64-row pieces; the first item stage is requested before the last piece is stored
         float4 v[NU];
 #pragma unroll
         for (int piece = 0; piece < UT / kStage; ++piece) {
             load(v, a.U, a.user_ids, u0 + piece * kStage, a.B);
-            if (piece == UT / kStage - 1 && i_beg < i_end)
+            if (piece == UT / kStage - 1 && i_beg < i_end) {
                 load(nxt, a.It, nullptr, i_beg, i_end);
+                load_norms(nxt_n, i_beg, i_end);
+            }
             store(smem + piece * kStage * RB, v);
         }
     }
-    const float tau = user_ok ? a.tau_lo[user] : INFINITY;
+    const float tau = user_ok ? a.tau[(size_t)user * a.tau_stride] : INFINITY;
+    // the extra k-step's B operand: c |x~_u| in element 0 of the h = 0 half, zeros elsewhere (both halves of the A operand
+    // read the row's pad chunk, so the step adds exactly c |x~_u| |y~_i| to the accumulator)
+    const float ub = user_ok ? a.ubound[user] : 0.0f;
+    const bf16x8 bfx = __builtin_bit_cast(bf16x8, make_uint4(h == 0 ? bf16_up_bits(ub) : 0u, 0u, 0u, 0u));
     __syncthreads();
     bf16x8 bfr[KS];
 #pragma unroll
@@ -233,15 +240,18 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
     if (i_beg >= i_end)
         return;
     store(smem, nxt);
+    store_norms(smem, nxt_n);
     __syncthreads();
     // tau has arrived before the loop: a first use inside it makes hipcc's wait-count pass put s_waitcnt vmcnt(0) in front of
     // EVERY test (the loop-carried state merges the pending tau load with the stage prefetch), which serialises the prefetch
-    asm volatile("" ::"v"(tau));
+    asm volatile("" ::"v"(tau), "v"(bfx));
     int buf = 0;
     for (int s0 = i_beg; s0 < i_end; s0 += ST) {
         const bool more = s0 + ST < i_end;
-        if (more)
+        if (more) {
             load(nxt, a.It, nullptr, s0 + ST, i_end);
+            load_norms(nxt_n, s0 + ST, i_end);
+        }
 #pragma unroll
         for (int un = 0; un < ST / kStage; ++un) {
             const int t0 = s0 + un * kStage;     // first item of this 64-item unit
@@ -259,7 +269,14 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
                 c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bfr[s], c0, 0, 0, 0);
                 c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bfr[s], c1, 0, 0, 0);
             }
-            // one pass bit per result register (!(approx <= tau'): a NaN approximation passes), register t on bit 31 - t
+            {   // + c |x~_u| |y~_i|
+                const unsigned char *pn = smem + ((buf * ST + un * kStage) + r32) * RB + 32 * KS;
+                const bf16x8 a0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pn));
+                const bf16x8 a1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pn + 32 * RB));
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bfx, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bfx, c1, 0, 0, 0);
+            }
+            // one pass bit per result register (!(acc <= tau): a NaN accumulator passes), register t on bit 31 - t
             const int lim = i_end - t0;
             unsigned bits = 0;
             if (lim >= kStage) {   // bits = 2 bits + pass: a compare into vcc and an add-with-carry per register
@@ -279,8 +296,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
             }
             mrow[t0 >> 6] = user_ok ? bits : 0u;
         }
-        if (more)
+        if (more) {
             store(smem + (buf ^ 1) * ST * RB, nxt);
+            store_norms(smem + (buf ^ 1) * ST * RB, nxt_n);
+        }
         __syncthreads();
         buf ^= 1;
     }
@@ -480,25 +499,24 @@ __global__ __launch_bounds__(256) void k_rescore(const RescoreArgs a)
 
 }  // namespace
 
-int launch_item_norm_part(const float *It, int I, int d, float *part, int n_part, float *total, hipStream_t s)
+int launch_item_norms(const float *It, int I, int d, float *norms, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_item_norm_part, dim3(n_part), dim3(256), 0, s, It, I, d, part, reinterpret_cast<unsigned *>(total));
-    return check_launch("k_item_norm_part");
+    hipLaunchKernelGGL(k_item_norms, dim3(min(1024, (I + 63) / 64)), dim3(256), 0, s, It, I, d, norms);
+    return check_launch("k_item_norms");
 }
 
-int launch_tau_lo(const float *U, const int64_t *user_ids, int B, int d, const float *tau, int tau_stride, const float *part,
-                  int n_part, float *tau_lo, hipStream_t s)
+int launch_user_bound(const float *U, const int64_t *user_ids, int B, int d, float *ubound, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_tau_lo, dim3((B + 3) / 4), dim3(256), 0, s, U, user_ids, B, d, tau, tau_stride, part, n_part, tau_lo);
-    return check_launch("k_tau_lo");
+    hipLaunchKernelGGL(k_user_bound, dim3((B + 3) / 4), dim3(256), 0, s, U, user_ids, B, d, ubound);
+    return check_launch("k_user_bound");
 }
 
 bool prefilter_supports(int d) { return d <= 128; }
 
-int launch_prefilter(const float *U, const int64_t *user_ids, int B, const float *It, int I, int d, const float *tau_lo,
-                     unsigned *mask, int Wh, int S, int items_per_split, hipStream_t s)
+int launch_prefilter(const float *U, const int64_t *user_ids, int B, const float *It, int I, int d, const float *tau, int tau_stride,
+                     const float *ubound, const float *inorm, unsigned *mask, int Wh, int S, int items_per_split, hipStream_t s)
 {
-    PreArgs a{U, user_ids, It, tau_lo, mask, Wh, B, I, d, items_per_split};
+    PreArgs a{U, user_ids, It, tau, tau_stride, ubound, inorm, mask, Wh, B, I, d, items_per_split};
     constexpr int UT = kPreWaves * 32;
     const dim3 grid((B + UT - 1) / UT, S), block(kPreWaves * 64);
     if (d == 64)

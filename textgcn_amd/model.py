@@ -487,7 +487,7 @@ class LightGCN(nn.Module):
         # candidates from the bf16 pass, scores and order from the fp32 chains: the same lists bit for bit (scoring.score_topk);
         # the item-side factor of its error bound is computed once for the whole predict call
         prefilter = bool(getattr(self, 'score_prefilter', True)) and not custom
-        item_norm = scoring.item_norm_max(items_emb) if prefilter and len(users) else None
+        item_norm = scoring.item_norms(items_emb) if prefilter and len(users) else None
         for n, j in enumerate(range(0, len(users), step)):
             batch = users[j:j + step]
             ids = torch.from_numpy(batch).to(self.device)

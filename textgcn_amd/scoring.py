@@ -113,15 +113,15 @@ def fallback_count(dev, b, n_items, d, k, slot=0):
     return out.value
 
 
-def item_norm_max(items_emb):
-    """One device float: max_i sum_j max(|items_emb[i, j]|, 2^-50)^2 (tgcn_item_norm_max_f32) -- the item-side factor of the
-    prefilter's error bound.  Compute it once per item table and hand it to score_topk(prefilter=True, item_norm=...)."""
+def item_norms(items_emb):
+    """[I] floats: the item factors |y~_i| of the prefilter's error bound (tgcn_item_norms_f32).  Compute them once per item
+    table and hand them to score_topk(prefilter=True, item_norm=...)."""
     dev = _dev(items_emb)
     _f32c(items_emb, 'items_emb')
-    out = torch.empty(1, dtype=torch.float32, device=dev)
-    rc = _capi.lib().tgcn_item_norm_max_f32(_capi.ptr(items_emb), items_emb.shape[0], items_emb.shape[1], _capi.ptr(out),
-                                            _capi.current_stream(dev))
-    _capi.check(rc, 'tgcn_item_norm_max_f32')
+    out = torch.empty(items_emb.shape[0], dtype=torch.float32, device=dev)
+    rc = _capi.lib().tgcn_item_norms_f32(_capi.ptr(items_emb), items_emb.shape[0], items_emb.shape[1], _capi.ptr(out),
+                                         _capi.current_stream(dev))
+    _capi.check(rc, 'tgcn_item_norms_f32')
     return out
 
 
@@ -131,7 +131,7 @@ def score_topk(users_emb, items_emb, k, user_ids=None, mask_rowptr=None, mask_it
     score_dense -> mask_train -> topk, without the [B, I] matrix.  mask_* is a CSR over the batch rows.
     `slot` selects the scratch buffer: use distinct slots for calls issued on different streams.
     `prefilter`: find the candidates with the bf16 pass and rescore them in fp32 (tgcn_score_topk_prefilter_f32) -- the same
-    result bit for bit; `item_norm` = item_norm_max(items_emb) when the table is shared by many calls."""
+    result bit for bit; `item_norm` = item_norms(items_emb) when the table is shared by many calls."""
     dev = _dev(users_emb)
     _f32c(users_emb, 'users_emb'), _f32c(items_emb, 'items_emb')
     if users_emb.shape[1] != items_emb.shape[1]:
@@ -172,8 +172,9 @@ def score_topk(users_emb, items_emb, k, user_ids=None, mask_rowptr=None, mask_it
     need = lib.tgcn_score_topk_workspace_bytes(b, n_items, d, int(k))
     ws = _workspace(dev, max(need, 256), slot)
     if prefilter:
-        if item_norm is not None and (item_norm.dtype != torch.float32 or item_norm.numel() != 1 or item_norm.device != dev):
-            raise TypeError('item_norm must be one float32 on the same device (item_norm_max)')
+        if item_norm is not None and (item_norm.dtype != torch.float32 or item_norm.numel() != n_items or item_norm.device != dev
+                                      or not item_norm.is_contiguous()):
+            raise TypeError('item_norm must be the [I] float32 tensor of item_norms(items_emb) on the same device')
         rc = lib.tgcn_score_topk_prefilter_f32(_capi.ptr(users_emb), _capi.ptr(user_ids), b, _capi.ptr(items_emb), n_items, d,
                                                _capi.ptr(mask_rowptr), _capi.ptr(mask_items), int(k), 1 if round4 else 0,
                                                _capi.ptr(item_norm), _capi.ptr(val), _capi.ptr(idx), _capi.ptr(ws), ws.numel(),

@@ -46,7 +46,7 @@ def main():
             rp = np.zeros(b + 1, dtype=np.int32)
             np.cumsum([len(r) for r in rows], out=rp[1:])
             batches.append((ids, torch.from_numpy(rp).to(dev), torch.from_numpy(np.concatenate(rows)).to(dev)))
-        norm = scoring.item_norm_max(ie)
+        norm = scoring.item_norms(ie)
         modes = {'fp32': dict(prefilter=False), 'prefilter': dict(prefilter=True, item_norm=None),
                  'prefilter+norm': dict(prefilter=True, item_norm=norm)}
         ref = None
