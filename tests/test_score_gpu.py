@@ -217,7 +217,7 @@ def test_fused_topk_small_catalogue_and_gather(cuda):
     _fused_vs_dense(cuda, table, it2, 40, mask=_rand_mask(rng, 333, 30000, 1, 50), user_ids=ids)
 
 
-@pytest.mark.parametrize('d', [64, 128, 40])
+@pytest.mark.parametrize('d', [64, 128, 40, 200, 320, 960])
 def test_fused_topk_hard_cases(cuda, d):
     """Cases built to defeat the threshold estimate: all-equal scores (no candidate passes a strict bar), scores
     increasing with the item id, a user whose train list covers most of the catalogue (log overflow / fewer

@@ -76,7 +76,6 @@ __device__ __forceinline__ float floored_sq(float x)
     const float f = fmaxf(fabsf(x), kNormFloor);
     return f * f;
 }
-__device__ __forceinline__ float nan_max(float a, float b) { return (b > a || !(b == b)) ? b : a; }   // a NaN sticks
 // the two factors of the bound c |u~| |y~| from floored squared norms, each rounded up; a non-finite norm gives +inf (every
 // pair of that user / item is then kept as a candidate and decided by its fp32 score)
 __device__ __forceinline__ float bound_user_factor(float user_sq)

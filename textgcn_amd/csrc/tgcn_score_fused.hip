@@ -796,7 +796,9 @@ struct BruteArgs {
 // A flagged user costs ~25 us of latency instead of ~1 ms in a single workgroup.
 constexpr int kBruteSplits = 32;
 constexpr int kBruteWaves = 4;
-constexpr int kBruteTileMaxD = 128;   // LDS tile: 4 waves x 64 rows x (d+1) floats <= 132 KB
+constexpr int kBruteTileMaxD = 128;   // LDS tile: 4 waves x 64 rows x (min(d, 128) + 1) floats <= 132 KB; wider rows pass through it in
+                                      // k-blocks of 128 (config 5's K = 960: the row-per-lane loop it replaces made a flagged user
+                                      // cost ~2 ms of a 16 384-user call)
 
 __global__ __launch_bounds__(kBruteWaves * 64) void k_brute_part(const BruteArgs a)
 {
@@ -806,8 +808,8 @@ __global__ __launch_bounds__(kBruteWaves * 64) void k_brute_part(const BruteArgs
     const int d_pad = (a.d + 63) & ~63;
     float *lv = su + d_pad;
     int *li = reinterpret_cast<int *>(lv + kBruteWaves * kWave);
-    const bool tiled = a.d <= kBruteTileMaxD && (a.d & 3) == 0;
-    const int trow = a.d + 1;
+    const bool tiled = (a.d & 3) == 0;
+    const int trow = min(a.d, kBruteTileMaxD) + 1;
     float *tile = reinterpret_cast<float *>(li + kBruteWaves * kWave) + (size_t)w * kWave * trow;
     const int split = blockIdx.x;
     const int n_flagged = min(a.flagged[0], a.flag_cap);
@@ -835,20 +837,25 @@ __global__ __launch_bounds__(kBruteWaves * 64) void k_brute_part(const BruteArgs
             const bool on = item < end;
             float s = 0.0f;
             if (tiled) {
-                // coalesced: consecutive lanes read consecutive 16-byte pieces of the 64 x d tile
+                // coalesced: consecutive lanes read consecutive 16-byte pieces of the 64 x kw block of the tile's rows
                 const int n_rows = min(kWave, end - i0);
                 const float *__restrict__ src = a.It + (size_t)i0 * a.d;
-                for (int p = lane; p < n_rows * q_per_row; p += kWave) {
-                    const float4 t = *reinterpret_cast<const float4 *>(src + (size_t)p * 4);
-                    const int r = p / q_per_row, k = (p % q_per_row) * 4;
-                    float *o = tile + r * trow + k;
-                    o[0] = t.x, o[1] = t.y, o[2] = t.z, o[3] = t.w;
+                for (int kb = 0; kb < a.d; kb += kBruteTileMaxD) {
+                    const int kw = min(kBruteTileMaxD, a.d - kb), qb = kw >> 2;
+                    __builtin_amdgcn_wave_barrier();   // the previous block's reads of the tile are done (same wave, in order)
+                    for (int p = lane; p < n_rows * qb; p += kWave) {
+                        const int r = p / qb, k = (p % qb) * 4;
+                        const float4 t = *reinterpret_cast<const float4 *>(src + (size_t)r * a.d + kb + k);
+                        float *o = tile + r * trow + k;
+                        o[0] = t.x, o[1] = t.y, o[2] = t.z, o[3] = t.w;
+                    }
+                    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes before its reads
+                    __builtin_amdgcn_wave_barrier();
+                    const float *__restrict__ row = tile + lane * trow;
+                    if (on)
+                        for (int k = 0; k < kw; ++k)
+                            s = fmaf(su[kb + k], row[k], s);
                 }
-                __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): this wave's LDS writes before its reads
-                const float *__restrict__ row = tile + lane * trow;
-                if (on)
-                    for (int k = 0; k < a.d; ++k)
-                        s = fmaf(su[k], row[k], s);
             } else if (on) {
                 const float *__restrict__ p = a.It + (size_t)item * a.d;
                 for (int k = 0; k < a.d; ++k)
@@ -1128,8 +1135,8 @@ int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const fl
     BruteArgs ba{U, user_ids, It, mask_rowptr, mask_items, flagged, reinterpret_cast<float2 *>(ws + p.off_parts), done, p.flag_cap,
                  out_val, out_idx, B, I, d, k, round4};
     size_t brute_lds = ((size_t)((d + 63) & ~63) + 2 * kBruteWaves * kWave) * sizeof(float);
-    if (d <= kBruteTileMaxD && (d & 3) == 0)
-        brute_lds += (size_t)kBruteWaves * kWave * (d + 1) * sizeof(float);
+    if ((d & 3) == 0)
+        brute_lds += (size_t)kBruteWaves * kWave * (min(d, kBruteTileMaxD) + 1) * sizeof(float);
     if ((rc = brute_lds_opt_in()) != TGCN_OK)
         return rc;
     hipLaunchKernelGGL(k_brute_part, dim3(kBruteSplits, 8), dim3(kBruteWaves * 64), brute_lds, s, ba);
