@@ -55,6 +55,8 @@ class LTRData(InteractionData):
 class LTRLinear(LightGCN):
     """reference: TextGCN/ltr_models.py:38-210 (LTRBase + LTRLinear)."""
 
+    ltr_predict_chunk = 8192    # users per folded scoring call (their [B, K] operand is built per call)
+
     def __init__(self, params, dataset):
         super().__init__(params, dataset)
         # the reference rebinds on the INSTANCE after construction so that the base model loaded inside
@@ -174,8 +176,9 @@ class LTRLinear(LightGCN):
         y_val, y_idx = [], []
         main = torch.cuda.current_stream(self.device)
         streams = self._predict_streams()       # chunks round-robin on a few streams, as in LightGCN.predict_tensors
-        for n, j in enumerate(range(0, len(users_np), self.batch_size)):
-            batch = users_np[j:j + self.batch_size]
+        step = max(self.batch_size, self.ltr_predict_chunk)   # no [B, I] matrix to bound: larger calls, fewer launches
+        for n, j in enumerate(range(0, len(users_np), step)):
+            batch = users_np[j:j + step]
             ids = torch.from_numpy(batch).to(self.device)
             rp, it = self._batch_mask(batch)
             slot = n % len(streams)
