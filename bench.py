@@ -221,14 +221,21 @@ def batch_masks(users, mrp, mit, dev, ids_origin=0):
             torch.from_numpy(np.ascontiguousarray(items)).to(dev))
 
 
+def n_score_streams(prefilter):
+    """calls in flight: 3 for the fp32 filter, 4 (LightGCN.predict_streams) for the bf16-candidate path -- sweeps of 2 / 3 / 4 / 6 on
+    the final kernels, profiles/r02_experiments.md"""
+    return 4 if prefilter else 3
+
+
 def scoring_region(ue, ie, batches, k_top, dev, barrier, prefilter=False):
-    """Consecutive calls are independent: issued round-robin on three HIP streams with their own scratch buffers, as
+    """Consecutive calls are independent: issued round-robin on a few HIP streams with their own scratch buffers, as
     LightGCN.predict does, so one call's small selection kernels run under the next call's GEMM.  Returns seconds.
     prefilter: tgcn_score_topk_prefilter_f32 (candidates from a bf16 pass, fp32 chains for every score: the same lists); the
     item-norm factor of its bound is computed inside the timed region, once per region as predict does per call."""
     from textgcn_amd import scoring
     main = torch.cuda.current_stream(dev)
-    side = [torch.cuda.Stream(dev) for _ in range(3)]
+    N_SCORE_STREAMS = n_score_streams(prefilter)
+    side = [torch.cuda.Stream(dev) for _ in range(N_SCORE_STREAMS)]
 
     def score_all(bts):   # the predict step of base_model.py:254-263, fused (tgcn_score_topk_f32)
         norm = scoring.item_norms(ie) if prefilter else None
@@ -236,13 +243,13 @@ def scoring_region(ue, ie, batches, k_top, dev, barrier, prefilter=False):
             st.wait_stream(main)
         keep = []
         for j, (ids, rp, it) in enumerate(bts):
-            with torch.cuda.stream(side[j % 3]):
+            with torch.cuda.stream(side[j % N_SCORE_STREAMS]):
                 keep.append(scoring.score_topk(ue, ie, k_top, user_ids=ids, mask_rowptr=rp, mask_items=it, round4=True,
-                                               slot=j % 3, prefilter=prefilter, item_norm=norm))
+                                               slot=j % N_SCORE_STREAMS, prefilter=prefilter, item_norm=norm))
         for st in side:
             main.wait_stream(st)
         return keep
-    score_all(batches[:3])
+    score_all(batches[:N_SCORE_STREAMS])
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()
@@ -676,7 +683,7 @@ def main():
             ts, pairs = mx[0], sm[1]
         flops = 2.0 * d * pairs
         result['scoring'] = {
-            'metric': f'scored user-item pairs/sec (scores + train mask + top-40 fused, B={bsz} per call, 3 streams)', 'value': pairs / ts,
+            'metric': f'scored user-item pairs/sec (scores + train mask + top-40 fused, B={bsz} per call, {n_score_streams(False)} streams)', 'value': pairs / ts,
             'unit': 'pairs/s', 'batches': n_batches, 'ms_per_batch': ts / n_batches * 1e3,
             'roofline': {'bound': 'mfma', 'achieved': round(flops / ts / 1e12 / max(world, 1), 2), 'peak': MFMA_F32_PEAK_TF,
                          'unit': 'TFLOP/s', 'frac': round(flops / ts / 1e12 / max(world, 1) / MFMA_F32_PEAK_TF, 4), 'traffic': None},
@@ -692,7 +699,7 @@ def main():
             result['scoring']['bf16_candidates'] = {
                 'what': 'tgcn_score_topk_prefilter_f32: bf16 MFMA pass with a proven error bound keeps a superset of the candidates, '
                         'k-ordered fp32 chains rescore them; top-k lists and scores identical to the fp32 path',
-                'value': pairs / tp, 'unit': 'pairs/s', 'ms_per_batch': tp / n_batches * 1e3,
+                'value': pairs / tp, 'unit': 'pairs/s', 'ms_per_batch': tp / n_batches * 1e3, 'streams': n_score_streams(True),
                 'identical_to_fp32_path': bool(same), 'speedup': round(ts / tp, 3)}
         # the model class scores 16384 users per call (LightGCN.predict_chunk); same kernels, fewer launches
         big = min(16384, len(users_all))

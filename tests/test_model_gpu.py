@@ -227,7 +227,7 @@ def test_predict_streams_do_not_change_results(cuda, tmp_path):
     m = LightGCN(_params(k=[20, 40], batch_size=64, save_path=str(tmp_path), exact=False), ds)
     m.predict_chunk = 128
     users = np.random.default_rng(0).permutation(n_u)
-    m.predict_streams, m._streams = 3, None
+    m.predict_streams, m._streams = 4, None
     v3, i3 = m.predict_tensors(users)
     m.predict_streams, m._streams = 1, None
     v1, i1 = m.predict_tensors(users)

@@ -127,7 +127,7 @@ class LightGCN(nn.Module):
     """reference: TextGCN/base_model.py:17-299 (class BaseModel)."""
 
     predict_chunk = 16384   # users per fused scoring call
-    predict_streams = 3     # chunks in flight (one HIP stream + scratch buffer each)
+    predict_streams = 4     # chunks in flight (one HIP stream + scratch buffer each)
     score_prefilter = True  # predict: candidates from the bf16 matrix pass, scores from the fp32 chains (identical lists and
                             # scores, ~2x the throughput for d <= 128); False: the fp32 MFMA filter finds the candidates
     exact = False   # True: no long-row split -> every row is one fmaf chain (bit-identical to the CPU reference)

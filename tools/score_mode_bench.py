@@ -28,6 +28,7 @@ def main():
     ap.add_argument('--shapes', default='c2,c2big,c3,c4')
     ap.add_argument('--reps', type=int, default=10)
     ap.add_argument('--k', type=int, default=40)
+    ap.add_argument('--streams', default='1,3')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     for name in args.shapes.split(','):
@@ -51,7 +52,7 @@ def main():
                  'prefilter+norm': dict(prefilter=True, item_norm=norm)}
         ref = None
         for mode, kw in modes.items():
-            for n_streams in (1, 3):
+            for n_streams in [int(x) for x in args.streams.split(',')]:
                 main_s = torch.cuda.current_stream(dev)
                 side = [torch.cuda.Stream(dev) for _ in range(n_streams)]
 
