@@ -906,7 +906,7 @@ struct Plan {
     int S, items_per_split, cap2, m, m_ld;  // m = sampled items
     int Wh;                                 // 64-item units of the catalogue (d <= 128: the filters emit pass bits)
     size_t off_mask;
-    size_t off_sample, off_tauv, off_taui, off_tau, off_taulo, off_npart, off_logs, off_counts, off_parts, off_flags, off_done, off_totals, total;
+    size_t off_sample, off_tauv, off_taui, off_tau, off_ubound, off_inorm, off_logs, off_counts, off_parts, off_flags, off_done, off_totals, total;
     int flag_cap;
     bool small;
 };
@@ -939,8 +939,8 @@ Plan make_plan(int B, int I, int d, int k)
     p.off_tauv = o, o += align256((size_t)B * kTauRank * sizeof(float));
     p.off_taui = o, o += align256((size_t)B * kTauRank * sizeof(int64_t));
     p.off_tau = o, o += align256((size_t)B * sizeof(float));
-    p.off_taulo = o, o += align256((size_t)B * sizeof(float));             // prefilter mode: the users' factors of the bound
-    p.off_npart = o;                                                       // ... and the items' (unless the caller holds them)
+    p.off_ubound = o, o += align256((size_t)B * sizeof(float));             // prefilter mode: the users' factors of the bound
+    p.off_inorm = o;                                                       // ... and the items' (unless the caller holds them)
     if (d <= 128)
         o += align256((size_t)I * sizeof(float));
     p.Wh = (I + kStage - 1) / kStage;
@@ -1048,10 +1048,10 @@ int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const fl
 
     // prefilter mode: the item-side factor of the bound, unless the caller holds it
     prefilter = prefilter && prefilter_supports(d);
-    float *ubound = prefilter ? reinterpret_cast<float *>(ws + p.off_taulo) : nullptr;
+    float *ubound = prefilter ? reinterpret_cast<float *>(ws + p.off_ubound) : nullptr;
     const float *inorm = item_norm;
     if (prefilter && !inorm) {
-        float *np = reinterpret_cast<float *>(ws + p.off_npart);
+        float *np = reinterpret_cast<float *>(ws + p.off_inorm);
         if ((rc = launch_item_norms(It, I, d, np, s)) != TGCN_OK)
             return rc;
         inorm = np;
