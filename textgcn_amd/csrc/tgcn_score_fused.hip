@@ -818,7 +818,6 @@ __global__ __launch_bounds__(kBruteWaves * 64) void k_brute_part(const BruteArgs
     const int s_beg = min(a.I, split * per_split), s_end = min(a.I, s_beg + per_split);
     const int per = ((((s_end - s_beg) + kBruteWaves - 1) / kBruteWaves + kWave - 1) / kWave) * kWave;
     const int beg = min(s_end, s_beg + w * per), end = min(s_end, beg + per);
-    const int q_per_row = a.d >> 2;
     for (int f = blockIdx.y; f < n_flagged; f += gridDim.y) {
         const int b = a.flagged[1 + f];
         __syncthreads();  // su / lists reused across iterations

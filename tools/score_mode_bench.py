@@ -16,6 +16,7 @@ from textgcn_amd import scoring  # noqa: E402
 
 SHAPES = {   # users per call, calls, items, d
     'c2': (2048, 12, 50_000, 64),
+    'c2x20': (2048, 20, 50_000, 64),
     'c2big': (16384, 6, 50_000, 64),
     'c3': (16384, 6, 60_000, 128),
     'c3small': (2048, 12, 60_000, 128),
