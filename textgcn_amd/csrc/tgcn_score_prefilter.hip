@@ -138,8 +138,7 @@ struct PreArgs {
 // (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5), so a lane's 16 results belong to one user and its threshold is one register.
 // Output: one pass bit per (user, item), a 32-bit word per lane and 64-item unit (no branch, no append in the loop: with
 // lane-private logs the loop spent ~2000 issue cycles per unit on compare-and-branch and appends against 256 cycles of MFMA).
-// A stage's rows are requested one whole stage ahead; d <= 64 walks 256-item stages (four units, ~1400 issue cycles each for
-// the SIMD's two waves: shorter stages end before their successor's rows arrive).
+// A stage's rows are requested one whole stage ahead; d <= 64 walks 256-item stages.
 template <int KS, bool FULLK, int ST, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
 {
@@ -194,36 +193,31 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
         }
     };
 
-    // the item rows' factors |y~_i| of the bound travel with the stage: element 0 of the row's 16-byte pad chunk, zeros behind
-    auto load_norms = [&](float (&nn)[N], int row0, int n_rows) {
-#pragma unroll
-        for (int i = 0; i < N; ++i)
-            nn[i] = a.inorm[min(row0 + (i * T + (int)threadIdx.x) / DQ, n_rows - 1)];
-    };
-    auto store_norms = [&](unsigned char *dst, const float (&nn)[N]) {
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            const int f = i * T + threadIdx.x;
-            if (f % DQ == 0)
-                *reinterpret_cast<uint4 *>(dst + (f / DQ) * RB + 32 * KS) = make_uint4(bf16_up_bits(nn[i]), 0u, 0u, 0u);
-        }
+    // the item rows' factors |y~_i| of the bound travel with the stage: element 0 of the row's 16-byte pad chunk, zeros behind.
+    // One load per thread (thread t < ST owns row t of the stage; the others repeat a row and store nothing)
+    static_assert(ST <= T, "one norm per thread");
+    auto load_norm = [&](int row0, int n_rows) { return a.inorm[min(row0 + min((int)threadIdx.x, ST - 1), n_rows - 1)]; };
+    auto store_norm = [&](unsigned char *dst, float nn) {
+        if (threadIdx.x < ST)
+            *reinterpret_cast<uint4 *>(dst + threadIdx.x * RB + 32 * KS) = make_uint4(bf16_up_bits(nn), 0u, 0u, 0u);
     };
 
     const int user = u0 + w * 32 + r32;
     const bool user_ok = user < a.B;
     float4 nxt[N];
-    float nxt_n[N];
-    {   // the user tile in 64-row pieces; the first item stage is requested before the last piece is stored
-        float4 v[NU];
+    float nxt_n = 0.0f;
+    {   // the whole user tile and the first item stage are requested together: one round trip for the ids, one for the rows
+        float4 v[UT / kStage][NU];
 #pragma unroll
-        for (int piece = 0; piece < UT / kStage; ++piece) {
-            load(v, a.U, a.user_ids, u0 + piece * kStage, a.B);
-            if (piece == UT / kStage - 1 && i_beg < i_end) {
-                load(nxt, a.It, nullptr, i_beg, i_end);
-                load_norms(nxt_n, i_beg, i_end);
-            }
-            store(smem + piece * kStage * RB, v);
+        for (int piece = 0; piece < UT / kStage; ++piece)
+            load(v[piece], a.U, a.user_ids, u0 + piece * kStage, a.B);
+        if (i_beg < i_end) {
+            load(nxt, a.It, nullptr, i_beg, i_end);
+            nxt_n = load_norm(i_beg, i_end);
         }
+#pragma unroll
+        for (int piece = 0; piece < UT / kStage; ++piece)
+            store(smem + piece * kStage * RB, v[piece]);
     }
     const float tau = user_ok ? a.tau[(size_t)user * a.tau_stride] : INFINITY;
     // the extra k-step's B operand: c |x~_u| in element 0 of the h = 0 half, zeros elsewhere (both halves of the A operand
@@ -240,18 +234,19 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
     if (i_beg >= i_end)
         return;
     store(smem, nxt);
-    store_norms(smem, nxt_n);
+    store_norm(smem, nxt_n);
     __syncthreads();
     // tau has arrived before the loop: a first use inside it makes hipcc's wait-count pass put s_waitcnt vmcnt(0) in front of
     // EVERY test (the loop-carried state merges the pending tau load with the stage prefetch), which serialises the prefetch
     asm volatile("" ::"v"(tau), "v"(bfx));
     int buf = 0;
+    // one stage: the rows of the next one are requested at its start and converted into the other LDS buffer at its end.  All
+    // loads and stores unconditional (rows past the split clamp to its last one; a buffer nobody reads takes the copies): a
+    // branch around them would leave the wait-count pass with vmcnt(0).  (Requesting TWO stages ahead, with a second register
+    // set, was measured: no change -- 33.2 vs 32.4 us at d = 64, 56.1 vs 55.4 at d = 128.)
     for (int s0 = i_beg; s0 < i_end; s0 += ST) {
-        const bool more = s0 + ST < i_end;
-        if (more) {
-            load(nxt, a.It, nullptr, s0 + ST, i_end);
-            load_norms(nxt_n, s0 + ST, i_end);
-        }
+        load(nxt, a.It, nullptr, s0 + ST, i_end);
+        nxt_n = load_norm(s0 + ST, i_end);
 #pragma unroll
         for (int un = 0; un < ST / kStage; ++un) {
             const int t0 = s0 + un * kStage;     // first item of this 64-item unit
@@ -296,10 +291,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
             }
             mrow[t0 >> 6] = user_ok ? bits : 0u;
         }
-        if (more) {
-            store(smem + (buf ^ 1) * ST * RB, nxt);
-            store_norms(smem + (buf ^ 1) * ST * RB, nxt_n);
-        }
+        store(smem + (buf ^ 1) * ST * RB, nxt);
+        store_norm(smem + (buf ^ 1) * ST * RB, nxt_n);
         __syncthreads();
         buf ^= 1;
     }
