@@ -503,12 +503,25 @@ __global__ __launch_bounds__(256) void k_tau(const float *__restrict__ Ss, int m
         if (totals)
             totals[b] = 0;      // k_rescore's per-user list lengths
     }
-    float *row = srow + w * (kWave * VPL);
+    float *row = srow + w * (kWave * VPL);     // private to the wave: wave-level barriers below
     const bool ok = b < B;
+    int mb = 0, me = 0;
+    if (ok && mask_rowptr) {                   // requested with the row, not after it
+        mb = mask_rowptr[b];
+        me = mask_rowptr[b + 1];
+    }
+    {   // the row, every load unconditional (clamped index): a `cond ? load : const` form makes hipcc branch around each load
+        // and wait for it inside the branch -- VPL dependent round trips instead of one
+        const float *__restrict__ src = Ss + (size_t)min(b, B - 1) * m_ld;
+        float x[VPL];
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-        const int j = lane + kWave * i;
-        row[j] = (ok && j < m) ? Ss[(size_t)b * m_ld + j] : -INFINITY;
+        for (int i = 0; i < VPL; ++i)
+            x[i] = src[min(lane + kWave * i, m - 1)];
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const int j = lane + kWave * i;
+            row[j] = (ok && j < m) ? x[i] : -INFINITY;
+        }
     }
     float usq = 0.0f;
     if (ubound && ok) {
@@ -516,16 +529,17 @@ __global__ __launch_bounds__(256) void k_tau(const float *__restrict__ Ss, int m
         for (int k = lane; k < d; k += kWave)
             usq += floored_sq(p[k]);
     }
-    __syncthreads();
-    if (ok && mask_rowptr) {
-        const int mb = mask_rowptr[b], me = mask_rowptr[b + 1];
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    {
         for (int e = mb + lane; e < me; e += kWave) {
             const int it = mask_items[e];
             if (it % kSampleStride == 0 && it / kSampleStride < m)
                 row[it / kSampleStride] = -INFINITY;
         }
     }
-    __syncthreads();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
     // the lane's two largest values, then kTauRank rounds of (wave maximum, its first owner retires one copy).  A lane that
     // holds three or more of the row's kTauRank largest gives a slightly lower tau than the exact rank: tau is only a bar that
     // at least k items must clear (k_select checks that), not a result.
@@ -685,9 +699,9 @@ __global__ __launch_bounds__(256) void k_select(const SelectArgs a)
         me = a.mask_rowptr[b + 1];
     }
     const bool cached = (me - mb) <= kMaskCache;
-    if (cached)
-        for (int j = lane; j < me - mb; j += kWave)
-            smask[w][j] = a.mask_items[mb + j];
+    // the first 64 train items are requested here and stored after the candidate loads have been issued too: one round trip
+    // for both instead of two
+    const int m_first = (cached && lane < me - mb) ? a.mask_items[mb + lane] : 0;
     const int n_seg = a.S * 2;   // <= 64: one segment per lane
     bool overflow = false;
     int n = 0, cnt = 0, off = 0;
@@ -718,8 +732,16 @@ __global__ __launch_bounds__(256) void k_select(const SelectArgs a)
         float2 *cand = scand[w];
         if (a.totals) {
             const float2 *__restrict__ lg = a.logs + (size_t)b * n_seg * a.cap2;
-            for (int j = lane; j < n; j += kWave)
-                cand[j] = lg[j];
+            for (int j0 = 0; j0 < n; j0 += 8 * kWave) {      // eight coalesced loads in flight (n > 0 inside the loop)
+                float2 t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    t[u] = lg[min(j0 + u * kWave + lane, n - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (j0 + u * kWave + lane < n)
+                        cand[j0 + u * kWave + lane] = t[u];
+            }
         } else {
             const float2 *__restrict__ lg = a.logs + ((size_t)b * n_seg + min(lane, n_seg - 1)) * a.cap2;
             int longest = cnt;
@@ -736,6 +758,12 @@ __global__ __launch_bounds__(256) void k_select(const SelectArgs a)
                     if (j0 + u < cnt)
                         cand[off + j0 + u] = t[u];
             }
+        }
+        if (cached) {
+            if (lane < me - mb)
+                smask[w][lane] = m_first;
+            for (int j = kWave + lane; j < me - mb; j += kWave)
+                smask[w][j] = a.mask_items[mb + j];
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
         __builtin_amdgcn_wave_barrier();
