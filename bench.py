@@ -224,7 +224,8 @@ def batch_masks(users, mrp, mit, dev, ids_origin=0):
 def n_score_streams(prefilter):
     """calls in flight: 3 for the fp32 filter, 4 (LightGCN.predict_streams) for the bf16-candidate path -- sweeps of 2 / 3 / 4 / 6 on
     the final kernels, profiles/r02_experiments.md"""
-    return 4 if prefilter else 3
+    env = os.environ.get('TGCN_BENCH_STREAMS_PREFILTER' if prefilter else 'TGCN_BENCH_STREAMS_FP32')     # sweeps only
+    return int(env) if env else (4 if prefilter else 3)
 
 
 def scoring_region(ue, ie, batches, k_top, dev, barrier, prefilter=False):

@@ -824,9 +824,10 @@ struct BruteArgs {
 // A flagged user costs ~25 us of latency instead of ~1 ms in a single workgroup.
 constexpr int kBruteSplits = 32;
 constexpr int kBruteWaves = 4;
-constexpr int kBruteTileMaxD = 128;   // LDS tile: 4 waves x 64 rows x (min(d, 128) + 1) floats <= 132 KB; wider rows pass through it in
-                                      // k-blocks of 128 (config 5's K = 960: the row-per-lane loop it replaces made a flagged user
-                                      // cost ~2 ms of a 16 384-user call)
+constexpr int kBruteTileMaxD = 32;    // floats of a row per pass through the LDS tile (4 waves x 64 rows x 33 floats = 34 KB).  With
+                                      // whole rows in the tile (132 KB at d = 128) every workgroup of this launch -- 256 of them,
+                                      // every call, almost always with nothing to do -- needed a CU's whole LDS to itself and
+                                      // waited for the other streams' workgroups to drain from one.
 
 __global__ __launch_bounds__(kBruteWaves * 64) void k_brute_part(const BruteArgs a)
 {
