@@ -678,6 +678,8 @@ def main():
         ie = ie.contiguous()
         ts, keep = scoring_region(ue, ie, batches, k_top, dev, barrier)
         first_topk = keep[0]
+        from textgcn_amd import scoring as _sc
+        fb_fp32 = _sc.fallback_count(dev, int(batches[0][0].numel()), n_i, d, k_top, slot=0)
         pairs = sum(int(bt[0].numel()) for bt in batches) * n_i
         if sharded:
             mx, sm = reduce_max_sum([ts, float(pairs)])
@@ -686,6 +688,7 @@ def main():
         result['scoring'] = {
             'metric': f'scored user-item pairs/sec (scores + train mask + top-40 fused, B={bsz} per call, {n_score_streams(False)} streams)', 'value': pairs / ts,
             'unit': 'pairs/s', 'batches': n_batches, 'ms_per_batch': ts / n_batches * 1e3,
+            'users_to_exact_fallback_last_call': fb_fp32,
             'roofline': {'bound': 'mfma', 'achieved': round(flops / ts / 1e12 / max(world, 1), 2), 'peak': MFMA_F32_PEAK_TF,
                          'unit': 'TFLOP/s', 'frac': round(flops / ts / 1e12 / max(world, 1) / MFMA_F32_PEAK_TF, 4), 'traffic': None},
         }
