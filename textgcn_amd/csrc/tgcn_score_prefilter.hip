@@ -21,6 +21,8 @@
 // candidate for everybody but does not loosen anybody else's test (with max_i |y~_i| in its place one such row floods every
 // user's list and hands the whole call to the exact fallback).  Non-finite data: a non-finite norm becomes +inf, the
 // accumulator +inf or NaN, and the test is !(acc <= tau) -- the pair is kept and decided by its fp32 score.
+#include <type_traits>
+
 #include "tgcn_internal.h"
 #include "tgcn_topk.h"
 
@@ -244,58 +246,92 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
     // loads and stores unconditional (rows past the split clamp to its last one; a buffer nobody reads takes the copies): a
     // branch around them would leave the wait-count pass with vmcnt(0).  (Requesting TWO stages ahead, with a second register
     // set, was measured: no change -- 33.2 vs 32.4 us at d = 64, 56.1 vs 55.4 at d = 128.)
+    // one 64-item unit: c0/c1 <- its accumulators; the pass bits of the PREVIOUS unit (q0/q1, a full unit: only the last unit
+    // of the catalogue can be partial, and the last unit of a split is drained after the loop) are formed between the MFMAs --
+    // a compare into vcc and an add-with-carry per register (bits = 2 bits + pass, register t on bit 31 - t), ~6 of them in the
+    // shadow of every MFMA pair.  With the tests AFTER the unit's MFMAs the two waves of a SIMD, synchronised by the stage
+    // barrier, run their matrix phases together and their vector phases together: PMC at 16 384 users -- matrix pipe 28 % busy,
+    // vector instructions 37 %, and they did not overlap (203 us).
+    auto unit = [&](auto prev_tag, int t0, int un, f32x16 &c0, f32x16 &c1, const f32x16 &q0, const f32x16 &q1, int t_prev) {
+        constexpr bool PREV = decltype(prev_tag)::value;
+        constexpr int STEPS = KS + 1;                  // k-steps incl. the bound's
+        const unsigned char *pi = smem + ((buf * ST + un * kStage) + r32) * RB;
+        unsigned bits = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            c0[r] = 0.0f, c1[r] = 0.0f;
+        // all operand fragments of the unit are requested first (their LDS latency is paid once per unit, under the first tests,
+        // not once per k-step), then per k-step: the previous unit's tests of that step, the MFMA pair
+        bf16x8 fa0[STEPS], fa1[STEPS];
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            const int off = s < KS ? 32 * s + 16 * h : 32 * KS;        // the bound's step: both halves read the pad chunk
+            fa0[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pi + off));
+            fa1[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pi + 32 * RB + off));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            if constexpr (PREV) {
+#pragma unroll
+                for (int t = (32 * s) / STEPS; t < (32 * (s + 1)) / STEPS; ++t) {
+                    const float val = t < 16 ? q0[t & 15] : q1[t & 15];
+                    asm volatile("v_cmp_nle_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(val), "v"(tau) : "vcc");
+                }
+            }
+            const bf16x8 bb = s < KS ? bfr[s < KS ? s : 0] : bfx;
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[s], bb, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[s], bb, c1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (PREV)
+            mrow[t_prev >> 6] = user_ok ? bits : 0u;
+    };
+    // the last unit of the split (possibly the partial last unit of the catalogue: rows past i_end are clamped copies)
+    auto drain = [&](const f32x16 &q0, const f32x16 &q1, int t_prev) {
+        const int lim = i_end - t_prev;
+        unsigned bits = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            bits = (bits << 1) | (((r & 3) + 8 * (r >> 2) + 4 * h < lim && !(q0[r] <= tau)) ? 1u : 0u);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            bits = (bits << 1) | ((32 + (r & 3) + 8 * (r >> 2) + 4 * h < lim && !(q1[r] <= tau)) ? 1u : 0u);
+        mrow[t_prev >> 6] = user_ok ? bits : 0u;
+    };
+    using Yes = std::true_type;
+    using No = std::false_type;
+    f32x16 A0, A1, B0, B1;       // units alternate between the two accumulator sets (a stage holds an even number of units)
+    static_assert((ST / kStage) % 2 == 0, "units per stage");
+    int t_last = i_beg;
+    bool last_is_a = true;
     for (int s0 = i_beg; s0 < i_end; s0 += ST) {
         load(nxt, a.It, nullptr, s0 + ST, i_end);
         nxt_n = load_norm(s0 + ST, i_end);
 #pragma unroll
-        for (int un = 0; un < ST / kStage; ++un) {
+        for (int un = 0; un < ST / kStage; un += 2) {
             const int t0 = s0 + un * kStage;     // first item of this 64-item unit
-            if (un > 0 && t0 >= i_end)
+            if (t0 >= i_end)
                 break;
-            const unsigned char *pi = smem + ((buf * ST + un * kStage) + r32) * RB + 16 * h;
-            f32x16 c0, c1;
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                c0[r] = 0.0f, c1[r] = 0.0f;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const bf16x8 a0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pi + 32 * s));
-                const bf16x8 a1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pi + 32 * RB + 32 * s));
-                c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bfr[s], c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bfr[s], c1, 0, 0, 0);
-            }
-            {   // + c |x~_u| |y~_i|
-                const unsigned char *pn = smem + ((buf * ST + un * kStage) + r32) * RB + 32 * KS;
-                const bf16x8 a0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pn));
-                const bf16x8 a1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pn + 32 * RB));
-                c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bfx, c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bfx, c1, 0, 0, 0);
-            }
-            // one pass bit per result register (!(acc <= tau): a NaN accumulator passes), register t on bit 31 - t
-            const int lim = i_end - t0;
-            unsigned bits = 0;
-            if (lim >= kStage) {   // bits = 2 bits + pass: a compare into vcc and an add-with-carry per register
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    asm volatile("v_cmp_nle_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(c0[r]), "v"(tau) : "vcc");
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    asm volatile("v_cmp_nle_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(c1[r]), "v"(tau) : "vcc");
-            } else {   // the partial last unit of the catalogue: rows past i_end are clamped copies
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    bits = (bits << 1) | (((r & 3) + 8 * (r >> 2) + 4 * h < lim && !(c0[r] <= tau)) ? 1u : 0u);
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    bits = (bits << 1) | ((32 + (r & 3) + 8 * (r >> 2) + 4 * h < lim && !(c1[r] <= tau)) ? 1u : 0u);
-            }
-            mrow[t0 >> 6] = user_ok ? bits : 0u;
+            if (t0 == i_beg)
+                unit(No{}, t0, un, A0, A1, B0, B1, 0);
+            else
+                unit(Yes{}, t0, un, A0, A1, B0, B1, t0 - kStage);
+            t_last = t0, last_is_a = true;
+            if (t0 + kStage >= i_end)
+                break;
+            unit(Yes{}, t0 + kStage, un + 1, B0, B1, A0, A1, t0);
+            t_last = t0 + kStage, last_is_a = false;
         }
         store(smem + (buf ^ 1) * ST * RB, nxt);
         store_norm(smem + (buf ^ 1) * ST * RB, nxt_n);
         __syncthreads();
         buf ^= 1;
     }
+    if (last_is_a)
+        drain(A0, A1, t_last);
+    else
+        drain(B0, B1, t_last);
 }
 
 // ---- candidates from the pass bits, fp32 scores, compact lists -----------------------------------------------------------

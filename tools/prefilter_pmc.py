@@ -1,0 +1,20 @@
+"""A few prefiltered scoring calls of 16 384 users x 50 000 items x d (default 64) for PMC passes over k_score_prefilter / k_rescore:
+    rocprofv3 --pmc <counters> --kernel-trace --output-format csv -d out -- python tools/prefilter_pmc.py [d]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from textgcn_amd import scoring  # noqa: E402
+
+dev = torch.device('cuda:0')
+d = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+b = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
+g = torch.Generator().manual_seed(0)
+ue = (torch.randn(b, d, generator=g) * 0.1).to(dev)
+ie = (torch.randn(50000, d, generator=g) * 0.1).to(dev)
+norm = scoring.item_norms(ie)
+for _ in range(3):
+    scoring.score_topk(ue, ie, 40, prefilter=True, item_norm=norm)
+torch.cuda.synchronize()
