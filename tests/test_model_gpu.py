@@ -194,6 +194,12 @@ def test_fit_runs_and_checkpoint_roundtrip(cuda, tmp_path):
     p2 = _params(k=[5, 10], batch_size=256, load=str(tmp_path), save_path=str(tmp_path), exact=False, data=str(folder))
     m2 = LightGCN(p2, ds)
     assert m2.predict(np.arange(ds.n_users)) == pred
+    # a NaN loss stops the run with the reference's assertion (base_model.py:123), whichever step it appears in
+    with torch.no_grad():
+        m2.embedding_item.weight[3, 0] = float('nan')
+    m2.epochs, m2.evaluate_every = 1, 1
+    with pytest.raises(AssertionError, match='loss is NA'):
+        m2.fit(loader)
 
 
 def test_predict_edge_cases(golden, cuda, tmp_path):

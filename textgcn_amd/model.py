@@ -387,14 +387,21 @@ class LightGCN(nn.Module):
         self.train()
         self.training = True
         self._loss_values = defaultdict(float)
+        pending = None                     # the previous step's NaN flag (a device scalar)
         for data in batches:
             self.optimizer.zero_grad()
             loss = self.get_loss(data)
-            is_nan = loss.isnan()          # read after the step is enqueued: the only host sync of the step
+            is_nan = loss.isnan()
             loss.backward()
             self.optimizer.step()
-            if bool(is_nan):
-                raise AssertionError(f'loss is NA at epoch {epoch}')   # base_model.py:123
+            # base_model.py:123 checks the loss before backward(); here the flag of step t - 1 is read once step t is enqueued,
+            # so the only host sync of a step never leaves the GPU without queued work (~0.1 ms of a 1.5 ms step on config 2).
+            # A NaN still stops the run with the same AssertionError, one step later.
+            if pending is not None and bool(pending):
+                raise AssertionError(f'loss is NA at epoch {epoch}')
+            pending = is_nan
+        if pending is not None and bool(pending):
+            raise AssertionError(f'loss is NA at epoch {epoch}')
 
     def fit(self, batches):
         """Adam over all parameters; every `evaluate_every` epochs: log losses, evaluate, checkpoint, early stop.
