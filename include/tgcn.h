@@ -159,17 +159,18 @@ int tgcn_score_topk_f32(const float *U, const int64_t *user_ids, int32_t B, cons
                         tgcn_stream_t stream);
 
 /* The same call with the candidates found by a bf16 matrix pass and rescored with the fp32 chains: the test
- * approx(u, i) + c |u| |i| > tau_u, with a proven bound on the bf16 error (tgcn_score_prefilter.hip), keeps a superset of
+ * approx(u, i) + bound(u, i) > tau_u, with a proven bound on the bf16 error (tgcn_score_prefilter.hip), keeps a superset of
  * {i : score > tau_u}; every kept pair gets its k-ordered fp32 fmaf score and is dropped again unless score > tau_u.  Results
  * are bit-identical to tgcn_score_topk_f32 (indices, scores, tie order, fallback); only the cost of finding the candidates
  * changes.  Applies to d <= 128 and I > 8192; any other shape runs tgcn_score_topk_f32's own path.  Same workspace.
- * `item_norms`: device pointer to the I item factors of the bound as written by tgcn_item_norms_f32 for this item table
+ * `item_norms`: device pointer to the 2 I item factors of the bound as written by tgcn_item_norms_f32 for this item table
  * (the table is fixed across the batches of a predict call), or NULL: computed inside the call. */
 int tgcn_score_topk_prefilter_f32(const float *U, const int64_t *user_ids, int32_t B, const float *It, int32_t I,
                                   int32_t d, const int32_t *mask_rowptr, const int32_t *mask_items, int32_t k,
                                   int32_t round4, const float *item_norms, float *out_val, int64_t *out_idx,
                                   void *workspace, int64_t workspace_bytes, tgcn_stream_t stream);
-/* out[i] = sqrt(sum_j max(|It[i][j]|, 2^-50)^2) (1 + 2^-12), +inf if not finite. */
+/* out[2 i] = |It[i]|_2 (elements floored at 2^-50), out[2 i + 1] = |It[i] - bf16(It[i])|_2 (the row's rounding residual under
+ * round-to-nearest-even), each times (1 + 2^-12); +inf if not finite. */
 int tgcn_item_norms_f32(const float *It, int32_t I, int32_t d, float *out, tgcn_stream_t stream);
 /* Diagnostic: how many of the B users of the LAST call that used `workspace` (either entry point, same B, I, d, k) took the
  * exact fallback (threshold too high, log overflow, fewer than k unmasked candidates).  Copies one int to the HOST pointer and

@@ -377,20 +377,25 @@ def test_prefilter_bound_under_worst_case_rounding(cuda, d):
 
 
 def test_item_norms(cuda):
-    """the item factors of the bound: never below the floored Euclidean norm, within 2^-11 above it; an infinite row gives +inf
-    (a NaN element needs nothing from the bound: the pair's bf16 score is NaN, which passes the test by itself)"""
+    """the item factors of the bound: the row norm (never below the floored Euclidean norm, within 2^-11 above it) and the norm
+    of the row's bf16 rounding residual (same margins; at most 2^-8 of the row norm); an infinite row gives +inf"""
     from textgcn_amd import scoring
     rng = np.random.default_rng(3)
     for n, d in ((50000, 64), (777, 128), (1000, 100), (5, 32), (3, 16)):
         it = (rng.standard_normal((n, d)) * 0.3).astype(np.float32)
         if n > 100:
             it[7, 3] = np.inf
-            it[9, 0] = np.nan
             it[11] = 0.0
+            it[13] = 0.375          # exactly representable in bf16: residual 0
         want = np.sqrt((np.maximum(np.abs(it.astype(np.float64)), 2.0 ** -50) ** 2).sum(axis=1))
-        got = scoring.item_norms(torch.from_numpy(it).to(cuda)).cpu().numpy().astype(np.float64)
+        t = torch.from_numpy(it)
+        resid = (t.double() - t.to(torch.bfloat16).double()).numpy()        # torch's conversion is round-to-nearest-even too
+        want_r = np.sqrt((np.maximum(np.abs(resid), 2.0 ** -58) ** 2).sum(axis=1))
+        got = scoring.item_norms(t.to(cuda)).cpu().numpy().astype(np.float64)
         fin = np.isfinite(want)
-        assert np.all(got[fin] >= want[fin]) and np.all(got[fin] <= want[fin] * (1 + 2.0 ** -11))
+        assert np.all(got[fin, 0] >= want[fin]) and np.all(got[fin, 0] <= want[fin] * (1 + 2.0 ** -11))
+        assert np.all(got[fin, 1] >= want_r[fin]) and np.all(got[fin, 1] <= want_r[fin] * (1 + 2.0 ** -11))
+        assert np.all(got[fin, 1] <= 2.0 ** -8 * got[fin, 0] * (1 + 2.0 ** -10))
         assert np.all(np.isposinf(got[np.isposinf(want)]))
 
 

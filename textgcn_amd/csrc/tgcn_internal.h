@@ -70,23 +70,33 @@ __device__ __forceinline__ float wave_max_all(float v)
 }
 
 // ---- the error bound of the bf16 candidate pass (tgcn_score_prefilter.hip holds the derivation) ----------------------------
+// Per row x two factors: nrm = |max(|x_j|, 2^-50)|_2 and res = |x - bf16(x)|_2 (the ACTUAL rounding residual of the conversion the
+// filter performs, v_cvt_pk_bf16_f32), each with a 2^-12 margin for its own fp32 arithmetic; non-finite -> +inf.
 constexpr float kNormFloor = 0x1p-50f;
+constexpr float kResFloor = 0x1p-58f;       // keeps the squares of tiny residuals out of the underflow range
+constexpr float kAccumBudget = 0x1p-11f;    // fp32 accumulation of the matrix pipe + the fp32 chain's own rounding, relative to |x||y|
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi)
+{
+    using f32x2_t = __attribute__((ext_vector_type(2))) float;
+    using bf16x2_t = __attribute__((ext_vector_type(2))) __bf16;
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));   // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+}
 __device__ __forceinline__ float floored_sq(float x)
 {
     const float f = fmaxf(fabsf(x), kNormFloor);
     return f * f;
 }
-// the two factors of the bound c |u~| |y~| from floored squared norms, each rounded up; a non-finite norm gives +inf (every
-// pair of that user / item is then kept as a candidate and decided by its fp32 score)
-__device__ __forceinline__ float bound_user_factor(float user_sq)
+__device__ __forceinline__ float residual_sq(float x)      // (x - bf16(x))^2, floored
 {
-    const float f = 0x1p-7f * (1.0f + 0x1p-4f) * sqrtf(user_sq) * (1.0f + 0x1p-12f);
-    return f < INFINITY ? f : INFINITY;      // (a NaN compares false)
+    const float r = x - __uint_as_float(pack_bf16(x, 0.0f) << 16);
+    const float f = fmaxf(fabsf(r), kResFloor);
+    return r == r ? f * f : INFINITY;                       // a NaN residual (non-finite x): +inf
 }
-__device__ __forceinline__ float bound_item_factor(float item_sq)
+__device__ __forceinline__ float bound_factor(float sq)    // sqrt with the margin; non-finite -> +inf
 {
-    const float f = sqrtf(item_sq) * (1.0f + 0x1p-12f);
-    return f < INFINITY ? f : INFINITY;
+    const float f = sqrtf(sq) * (1.0f + 0x1p-12f);
+    return f < INFINITY ? f : INFINITY;      // (a NaN compares false)
 }
 // smallest bf16 >= x for x >= 0 (or +inf), as the high half of a float: the bound's factors enter the bf16 product rounded UP
 __device__ __forceinline__ unsigned bf16_up_bits(float x)
@@ -101,8 +111,8 @@ int launch_score_dense_filter(const float *U, const int64_t *user_ids, int B, co
                               int tau_stride, void *logs, int *counts, int S, int items_per_split, int cap2, hipStream_t stream);
 // tgcn_score_prefilter.hip: candidates from a bf16 pass, rescored in fp32
 bool prefilter_supports(int d);
-int launch_item_norms(const float *It, int I, int d, float *norms, hipStream_t stream);
-int launch_user_bound(const float *U, const int64_t *user_ids, int B, int d, float *ubound, hipStream_t stream);
+int launch_item_norms(const float *It, int I, int d, float *norms /* [I][2] */, hipStream_t stream);
+int launch_user_bound(const float *U, const int64_t *user_ids, int B, int d, float *ubound /* [B][2] */, hipStream_t stream);
 int launch_prefilter(const float *U, const int64_t *user_ids, int B, const float *It, int I, int d, const float *tau, int tau_stride,
                      const float *ubound, const float *inorm, unsigned *mask, int Wh, int S, int items_per_split, hipStream_t stream);
 int launch_rescore(const float *U, const int64_t *user_ids, int B, const float *It, int d, const float *tau, int tau_stride,

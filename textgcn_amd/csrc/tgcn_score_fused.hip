@@ -482,8 +482,8 @@ constexpr int kMaskCache = 512;  // train items per user cached in LDS for the m
 // staged in LDS (coalesced load, mask applied by the lanes that own the train items), read back VPL values per lane, and
 // the maximum is extracted kTauRank times (per-lane max, wave max, the owning lane retires one copy).  Replaces the
 // k_mask + k_topk pair on the sample (28 us for 2048 x 1563 -> ~4 us) and zeroes the fallback counter for this call.
-// Prefilter mode (ubound != NULL): the user's factor c |x~_u| of tgcn_score_prefilter.hip's bound is written too -- the row is
-// fetched before the rounds and costs no extra launch.
+// Prefilter mode (ubound != NULL): the user's factors {n_u, r_u} of tgcn_score_prefilter.hip's bound are written too -- the row
+// is fetched before the rounds and costs no extra launch.
 template <int VPL>
 __global__ __launch_bounds__(256) void k_tau(const float *__restrict__ Ss, int m_ld, int B, int m, const int *__restrict__ mask_rowptr,
                                              const int *__restrict__ mask_items, float *__restrict__ tau, int *__restrict__ flagged,
@@ -523,11 +523,13 @@ __global__ __launch_bounds__(256) void k_tau(const float *__restrict__ Ss, int m
             row[j] = (ok && j < m) ? x[i] : -INFINITY;
         }
     }
-    float usq = 0.0f;
+    float usq = 0.0f, ursq = 0.0f;
     if (ubound && ok) {
         const float *__restrict__ p = U + (size_t)(user_ids ? user_ids[b] : b) * d;
-        for (int k = lane; k < d; k += kWave)
+        for (int k = lane; k < d; k += kWave) {
             usq += floored_sq(p[k]);
+            ursq += residual_sq(p[k]);
+        }
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
@@ -561,13 +563,15 @@ __global__ __launch_bounds__(256) void k_tau(const float *__restrict__ Ss, int m
     }
     if (ubound) {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1)
+        for (int o = 32; o > 0; o >>= 1) {
             usq += __shfl_xor(usq, o);
+            ursq += __shfl_xor(ursq, o);
+        }
     }
     if (ok && lane == 0) {
         tau[b] = t;
         if (ubound)
-            ubound[b] = bound_user_factor(usq);
+            *reinterpret_cast<float2 *>(ubound + 2 * (size_t)b) = make_float2(bound_factor(usq), bound_factor(ursq));
     }
 }
 
@@ -967,10 +971,10 @@ Plan make_plan(int B, int I, int d, int k)
     p.off_tauv = o, o += align256((size_t)B * kTauRank * sizeof(float));
     p.off_taui = o, o += align256((size_t)B * kTauRank * sizeof(int64_t));
     p.off_tau = o, o += align256((size_t)B * sizeof(float));
-    p.off_ubound = o, o += align256((size_t)B * sizeof(float));             // prefilter mode: the users' factors of the bound
+    p.off_ubound = o, o += align256((size_t)B * 2 * sizeof(float));         // prefilter mode: the users' factors of the bound
     p.off_inorm = o;                                                       // ... and the items' (unless the caller holds them)
     if (d <= 128)
-        o += align256((size_t)I * sizeof(float));
+        o += align256((size_t)I * 2 * sizeof(float));
     p.Wh = (I + kStage - 1) / kStage;
     p.off_mask = o;
     if (d <= 128)

@@ -8,19 +8,18 @@
 // path: results are bit-identical, only the cost of finding the candidates changes (gfx950: v_mfma_f32_32x32x16_bf16 retires
 // 16x the k-steps of v_mfma_f32_32x32x2_f32 per cycle).
 //
-// The bound.  a = bf16(x) by round-to-nearest-even (v_cvt_pk_bf16_f32): |a - x| <= 2^-8 max(|x|, 2^-50) (8 significant bits;
-// the floor covers fp32 denormals flushed on conversion).  With x~ = max(|x|, 2^-50) elementwise,
-//   |sum_j a_j b_j - sum_j x_j y_j| <= (2^-7 + 2^-16) sum_j x~_j y~_j <= (2^-7 + 2^-16) |x~|_2 |y~|_2       (Cauchy-Schwarz)
-// the matrix pipe's fp32 accumulation of the d <= 256 exact bf16 products and the fp32 chain's own rounding add at most
-// 2^-11 sum_j |x_j y_j| between them (budgeted ~30x above d 2^-23 + d 2^-24; products below 2^-126 that flush are below the
-// floor's 2^-108).  So with c = 2^-7 (1 + 2^-4):
-//   score(u, i) > tau_u   ==>   approx(u, i) + c |x~_u|_2 |y~_i|_2 > tau_u.
-// The second term is computed BY the matrix pipe: one more 16-wide k-step whose only non-zero operands are the two factors
-// c |x~_u| and |y~_i| (fp32 sums of squares of the floored values, square root, a 2^-12 margin, rounded UP to bf16), so the
-// test stays one compare of the accumulator against tau_u.  The bound is per PAIR: one item row of enormous norm becomes a
-// candidate for everybody but does not loosen anybody else's test (with max_i |y~_i| in its place one such row floods every
-// user's list and hands the whole call to the exact fallback).  Non-finite data: a non-finite norm becomes +inf, the
-// accumulator +inf or NaN, and the test is !(acc <= tau) -- the pair is kept and decided by its fp32 score.
+// The bound.  With a = bf16(x), b = bf16(y) (round-to-nearest-even, v_cvt_pk_bf16_f32) and the residuals r_x = x - a, r_y = y - b
+// (exact in fp32):   x.y - a.b = x.r_y + r_x.b,   so   |x.y - a.b| <= |x|_2 |r_y|_2 + |r_x|_2 (|y|_2 + |r_y|_2)    (Cauchy-Schwarz)
+// with the ACTUAL residual norms of the two rows (worst case 2^-8 of the row norm, ~0.4 of that on ordinary data).  The matrix
+// pipe's fp32 accumulation of the d <= 128 exact bf16 products and the fp32 chain's own rounding add at most 2^-11 |x|_2 |y|_2
+// between them (budgeted ~30x above d 2^-23 + d 2^-24).  So
+//   score(u, i) > tau_u   ==>   approx(u, i) + n_u r_i + r_u (n_i + r_i) + 2^-11 n_u n_i > tau_u,
+// n = norm of the row (elements floored at 2^-50), r = norm of its residual (floored at 2^-58), each with a 2^-12 margin.  The
+// added terms are computed BY the matrix pipe: one more 16-wide k-step whose only non-zero operands are
+// [n_u, r_u, 2^-11 n_u] and [r_i, n_i + r_i, n_i], each rounded UP to bf16, so the test stays one compare of the accumulator
+// against tau_u.  The bound is per PAIR: one item row of enormous norm becomes a candidate for everybody but does not loosen
+// anybody else's test.  Non-finite data: a non-finite factor becomes +inf, the accumulator +inf or NaN, and the test is
+// !(acc <= tau) -- the pair is kept and decided by its fp32 score.
 #include <type_traits>
 
 #include "tgcn_internal.h"
@@ -30,20 +29,12 @@ namespace tgcn {
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
-using f32x2 = __attribute__((ext_vector_type(2))) float;
-using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
 constexpr int kPreWaves = 8;        // waves (x 32 users) per workgroup of the bf16 filter: every item row a workgroup stages is
                                    // fetched from L2 once per 256 users (with 128, the 16 user tiles of a 2048-user call pull
                                    // 205 MB through L2 for a 12.8 MB table; 16 384-user calls gained 7 %, 2 M items 15 %)
 constexpr int kStage = 64;         // items per LDS stage
-
-__device__ __forceinline__ unsigned pack_bf16(float lo, float hi)
-{
-    const f32x2 v = {lo, hi};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));   // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
-}
 
 __device__ __forceinline__ float wave_sum_f(float v)
 {
@@ -53,7 +44,7 @@ __device__ __forceinline__ float wave_sum_f(float v)
     return v;
 }
 
-// ---- item factors: norms[i] = |y~_i| (rounded up) ------------------------------------------------------------------------
+// ---- item factors: norms[i] = {n_i, r_i} ---------------------------------------------------------------------------------
 // G = d / 4 lanes per row (a power of two <= 32): one 16-byte piece per lane, 64 / G rows per wave instruction, four in flight
 template <int G>
 __device__ __forceinline__ void norm_rows_pow2(const float *__restrict__ It, int I, int d, int wave, int n_waves, int lane,
@@ -69,12 +60,15 @@ __device__ __forceinline__ void norm_rows_pow2(const float *__restrict__ It, int
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             float t = (floored_sq(v[u].x) + floored_sq(v[u].y)) + (floored_sq(v[u].z) + floored_sq(v[u].w));
+            float e = (residual_sq(v[u].x) + residual_sq(v[u].y)) + (residual_sq(v[u].z) + residual_sq(v[u].w));
 #pragma unroll
-            for (int o = G / 2; o > 0; o >>= 1)
+            for (int o = G / 2; o > 0; o >>= 1) {
                 t += __shfl_xor(t, o);
+                e += __shfl_xor(e, o);
+            }
             const int r = r0 + u * R + sub;
             if (q == 0 && r < I)
-                norms[r] = bound_item_factor(t);
+                *reinterpret_cast<float2 *>(norms + 2 * (size_t)r) = make_float2(bound_factor(t), bound_factor(e));
         }
     }
 }
@@ -94,17 +88,20 @@ __global__ __launch_bounds__(256) void k_item_norms(const float *__restrict__ It
     else {
         for (int r = wave; r < I; r += n_waves) {
             const float *__restrict__ p = It + (size_t)r * d;
-            float s = 0.0f;
-            for (int k = lane; k < d; k += kWave)
+            float s = 0.0f, e = 0.0f;
+            for (int k = lane; k < d; k += kWave) {
                 s += floored_sq(p[k]);
+                e += residual_sq(p[k]);
+            }
             s = wave_sum_f(s);
+            e = wave_sum_f(e);
             if (lane == 0)
-                norms[r] = bound_item_factor(s);
+                *reinterpret_cast<float2 *>(norms + 2 * (size_t)r) = make_float2(bound_factor(s), bound_factor(e));
         }
     }
 }
 
-// ---- user factors c |x~_u| (rounded up): one wave per user (catalogues too large for k_tau, which writes them itself) -------
+// ---- user factors {n_u, r_u}: one wave per user (catalogues too large for k_tau, which writes them itself) ------------------
 __global__ __launch_bounds__(256) void k_user_bound(const float *__restrict__ U, const int64_t *__restrict__ user_ids, int B, int d,
                                                     float *__restrict__ ubound)
 {
@@ -113,12 +110,15 @@ __global__ __launch_bounds__(256) void k_user_bound(const float *__restrict__ U,
     if (b >= B)
         return;
     const float *__restrict__ p = U + (size_t)(user_ids ? user_ids[b] : b) * d;
-    float s = 0.0f;
-    for (int k = lane; k < d; k += kWave)
+    float s = 0.0f, e = 0.0f;
+    for (int k = lane; k < d; k += kWave) {
         s += floored_sq(p[k]);
+        e += residual_sq(p[k]);
+    }
     s = wave_sum_f(s);
+    e = wave_sum_f(e);
     if (lane == 0)
-        ubound[b] = bound_user_factor(s);
+        *reinterpret_cast<float2 *>(ubound + 2 * (size_t)b) = make_float2(bound_factor(s), bound_factor(e));
 }
 
 // ---- the bf16 filter ------------------------------------------------------------------------------------------------------
@@ -128,8 +128,8 @@ struct PreArgs {
     const float *__restrict__ It;
     const float *__restrict__ tau;      // tau of user b at tau[b * tau_stride]
     int tau_stride;
-    const float *__restrict__ ubound;   // c |x~_u|  (k_tau / k_user_bound)
-    const float *__restrict__ inorm;    // |y~_i|    (k_item_norms)
+    const float *__restrict__ ubound;   // [B][2] {n_u, r_u}  (k_tau / k_user_bound)
+    const float *__restrict__ inorm;    // [I][2] {n_i, r_i}  (k_item_norms)
     unsigned *__restrict__ mask;    // [B padded to 256][2][Wh] pass bits: word (user, h, unit), register t of the unit on bit 31 - t
     int Wh;
     int B, I, d, items_per_split;
@@ -195,19 +195,23 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
         }
     };
 
-    // the item rows' factors |y~_i| of the bound travel with the stage: element 0 of the row's 16-byte pad chunk, zeros behind.
-    // One load per thread (thread t < ST owns row t of the stage; the others repeat a row and store nothing)
+    // the item rows' factors of the bound travel with the stage: [r_i, n_i + r_i, n_i] rounded up to bf16 in the first three
+    // elements of the row's 16-byte pad chunk, zeros behind.  One load per thread (thread t < ST owns row t of the stage; the
+    // others repeat a row and store nothing)
     static_assert(ST <= T, "one norm per thread");
-    auto load_norm = [&](int row0, int n_rows) { return a.inorm[min(row0 + min((int)threadIdx.x, ST - 1), n_rows - 1)]; };
-    auto store_norm = [&](unsigned char *dst, float nn) {
+    auto load_norm = [&](int row0, int n_rows) {
+        return *reinterpret_cast<const float2 *>(a.inorm + 2 * (size_t)min(row0 + min((int)threadIdx.x, ST - 1), n_rows - 1));
+    };
+    auto store_norm = [&](unsigned char *dst, float2 nn) {
         if (threadIdx.x < ST)
-            *reinterpret_cast<uint4 *>(dst + threadIdx.x * RB + 32 * KS) = make_uint4(bf16_up_bits(nn), 0u, 0u, 0u);
+            *reinterpret_cast<uint4 *>(dst + threadIdx.x * RB + 32 * KS) =
+                make_uint4(bf16_up_bits(nn.y) | (bf16_up_bits((nn.x + nn.y) * (1.0f + 0x1p-20f)) << 16), bf16_up_bits(nn.x), 0u, 0u);
     };
 
     const int user = u0 + w * 32 + r32;
     const bool user_ok = user < a.B;
     float4 nxt[N];
-    float nxt_n = 0.0f;
+    float2 nxt_n = make_float2(0.0f, 0.0f);
     {   // the whole user tile and the first item stage are requested together: one round trip for the ids, one for the rows
         float4 v[UT / kStage][NU];
 #pragma unroll
@@ -222,10 +226,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
             store(smem + piece * kStage * RB, v[piece]);
     }
     const float tau = user_ok ? a.tau[(size_t)user * a.tau_stride] : INFINITY;
-    // the extra k-step's B operand: c |x~_u| in element 0 of the h = 0 half, zeros elsewhere (both halves of the A operand
-    // read the row's pad chunk, so the step adds exactly c |x~_u| |y~_i| to the accumulator)
-    const float ub = user_ok ? a.ubound[user] : 0.0f;
-    const bf16x8 bfx = __builtin_bit_cast(bf16x8, make_uint4(h == 0 ? bf16_up_bits(ub) : 0u, 0u, 0u, 0u));
+    // the extra k-step's B operand: [n_u, r_u, 2^-11 n_u] in the first three elements of the h = 0 half, zeros elsewhere (both
+    // halves of the A operand read the row's pad chunk, so the step adds n_u r_i + r_u (n_i + r_i) + 2^-11 n_u n_i)
+    const float2 ub = user_ok ? *reinterpret_cast<const float2 *>(a.ubound + 2 * (size_t)user) : make_float2(0.0f, 0.0f);
+    const bf16x8 bfx = __builtin_bit_cast(bf16x8, h == 0 ? make_uint4(bf16_up_bits(ub.x) | (bf16_up_bits(ub.y) << 16),
+                                                                       bf16_up_bits(ub.x * kAccumBudget), 0u, 0u)
+                                                         : make_uint4(0u, 0u, 0u, 0u));
     __syncthreads();
     bf16x8 bfr[KS];
 #pragma unroll

@@ -114,11 +114,11 @@ def fallback_count(dev, b, n_items, d, k, slot=0):
 
 
 def item_norms(items_emb):
-    """[I] floats: the item factors |y~_i| of the prefilter's error bound (tgcn_item_norms_f32).  Compute them once per item
-    table and hand them to score_topk(prefilter=True, item_norm=...)."""
+    """[I, 2] floats: the item factors (row norm, norm of the row's bf16 rounding residual) of the prefilter's error bound
+    (tgcn_item_norms_f32).  Compute them once per item table and hand them to score_topk(prefilter=True, item_norm=...)."""
     dev = _dev(items_emb)
     _f32c(items_emb, 'items_emb')
-    out = torch.empty(items_emb.shape[0], dtype=torch.float32, device=dev)
+    out = torch.empty((items_emb.shape[0], 2), dtype=torch.float32, device=dev)
     rc = _capi.lib().tgcn_item_norms_f32(_capi.ptr(items_emb), items_emb.shape[0], items_emb.shape[1], _capi.ptr(out),
                                          _capi.current_stream(dev))
     _capi.check(rc, 'tgcn_item_norms_f32')
@@ -172,9 +172,9 @@ def score_topk(users_emb, items_emb, k, user_ids=None, mask_rowptr=None, mask_it
     need = lib.tgcn_score_topk_workspace_bytes(b, n_items, d, int(k))
     ws = _workspace(dev, max(need, 256), slot)
     if prefilter:
-        if item_norm is not None and (item_norm.dtype != torch.float32 or item_norm.numel() != n_items or item_norm.device != dev
+        if item_norm is not None and (item_norm.dtype != torch.float32 or item_norm.numel() != 2 * n_items or item_norm.device != dev
                                       or not item_norm.is_contiguous()):
-            raise TypeError('item_norm must be the [I] float32 tensor of item_norms(items_emb) on the same device')
+            raise TypeError('item_norm must be the [I, 2] float32 tensor of item_norms(items_emb) on the same device')
         rc = lib.tgcn_score_topk_prefilter_f32(_capi.ptr(users_emb), _capi.ptr(user_ids), b, _capi.ptr(items_emb), n_items, d,
                                                _capi.ptr(mask_rowptr), _capi.ptr(mask_items), int(k), 1 if round4 else 0,
                                                _capi.ptr(item_norm), _capi.ptr(val), _capi.ptr(idx), _capi.ptr(ws), ws.numel(),
