@@ -114,7 +114,8 @@ bool prefilter_supports(int d);
 int launch_item_norms(const float *It, int I, int d, float *norms /* [I][2] */, hipStream_t stream);
 int launch_user_bound(const float *U, const int64_t *user_ids, int B, int d, float *ubound /* [B][2] */, hipStream_t stream);
 int launch_prefilter(const float *U, const int64_t *user_ids, int B, const float *It, int I, int d, const float *tau, int tau_stride,
-                     const float *ubound, const float *inorm, unsigned *mask, int Wh, int S, int items_per_split, hipStream_t stream);
+                     const float *ubound, const float *inorm, unsigned *mask, int Wh, int S, int items_per_split, bool wide,
+                     hipStream_t stream);
 int launch_rescore(const float *U, const int64_t *user_ids, int B, const float *It, int d, const float *tau, int tau_stride,
                    const unsigned *mask, int Wh, void *lists, int *totals, int list_cap, hipStream_t stream);
 int launch_topk(const float *S, int64_t lds, int B, int I, int k, int do_round, float *out_val, int64_t *out_idx,

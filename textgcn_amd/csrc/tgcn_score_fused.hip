@@ -1133,12 +1133,18 @@ int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const fl
         unsigned *mask = reinterpret_cast<unsigned *>(ws + p.off_mask);
         if (tau_stride != 1 && (rc = launch_user_bound(U, user_ids, B, d, ubound, s)) != TGCN_OK)
             return rc;       // (the k_tau launch wrote the users' factors itself)
-        // its own item splits: pass bits are indexed by unit, not by split, so the grid may be finer than k_select's 32 segments.
-        // Measured (2048 users, rocprofv3): d = 128, 60 k items 68.6 -> 62.2 us with 1024-item splits; d = 64, 50 k items
-        // 37.5 -> 41.4 us (the 256-user tile is re-staged per workgroup): finer only for the wide rows
-        const int ips_pre = (d > 64 && I <= (1 << 18)) ? 1024 : p.items_per_split;
+        // its own item splits: pass bits are indexed by unit, not by split, so the grid need not be k_select's 32 segments.
+        // Measured (rocprofv3): d = 128, 60 k items, 2048 users 68.6 -> 62.2 us with 1024-item splits.  d = 64: calls with
+        // plenty of workgroups take splits of 256-item multiples (one aligned 16-byte store of mask words per lane and stage:
+        // 16 384 users 208 -> 181 us); a 2048-user call keeps its 32 splits (28 would cost it 35.5 -> 39 us).
+        const bool wide = B > 4096;
+        int ips_pre = p.items_per_split;
+        if (d > 64 && I <= (1 << 18))
+            ips_pre = 1024;
+        else if (wide)
+            ips_pre = ((p.items_per_split + 255) / 256) * 256;
         if ((rc = launch_prefilter(U, user_ids, B, It, I, d, tau_ptr, tau_stride, ubound, inorm, mask, p.Wh, (I + ips_pre - 1) / ips_pre,
-                                   ips_pre, s)) != TGCN_OK)
+                                   ips_pre, wide, s)) != TGCN_OK)
             return rc;
         rc = launch_rescore(U, user_ids, B, It, d, tau_ptr, tau_stride, mask, p.Wh, fa.logs, totals, p.S * 2 * p.cap2, s);
     } else if (d <= 128) {

@@ -141,7 +141,7 @@ struct PreArgs {
 // Output: one pass bit per (user, item), a 32-bit word per lane and 64-item unit (no branch, no append in the loop: with
 // lane-private logs the loop spent ~2000 issue cycles per unit on compare-and-branch and appends against 256 cycles of MFMA).
 // A stage's rows are requested one whole stage ahead; d <= 64 walks 256-item stages.
-template <int KS, bool FULLK, int ST, int WAVES>
+template <int KS, bool FULLK, int ST, int WAVES, bool WIDE>
 __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
 {
     constexpr int T = WAVES * 64;              // threads; WAVES x 32 users per workgroup share every item stage
@@ -248,16 +248,34 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
     // EVERY test (the loop-carried state merges the pending tau load with the stage prefetch), which serialises the prefetch
     asm volatile("" ::"v"(tau), "v"(bfx));
     int buf = 0;
-    // one stage: the rows of the next one are requested at its start and converted into the other LDS buffer at its end.  All
-    // loads and stores unconditional (rows past the split clamp to its last one; a buffer nobody reads takes the copies): a
-    // branch around them would leave the wait-count pass with vmcnt(0).  (Requesting TWO stages ahead, with a second register
-    // set, was measured: no change -- 33.2 vs 32.4 us at d = 64, 56.1 vs 55.4 at d = 128.)
+    // (Requesting the rows TWO stages ahead, with a second register set, was measured: no change -- 33.2 vs 32.4 us at d = 64,
+    // 56.1 vs 55.4 at d = 128.)
     // one 64-item unit: c0/c1 <- its accumulators; the pass bits of the PREVIOUS unit (q0/q1, a full unit: only the last unit
     // of the catalogue can be partial, and the last unit of a split is drained after the loop) are formed between the MFMAs --
     // a compare into vcc and an add-with-carry per register (bits = 2 bits + pass, register t on bit 31 - t), ~6 of them in the
     // shadow of every MFMA pair.  With the tests AFTER the unit's MFMAs the two waves of a SIMD, synchronised by the stage
     // barrier, run their matrix phases together and their vector phases together: PMC at 16 384 users -- matrix pipe 28 % busy,
     // vector instructions 37 %, and they did not overlap (203 us).
+    // The words of a stage's units are adjacent in the (user, row half) row.  WIDE: they leave as ONE store per lane and stage
+    // (16 bytes at d <= 64, 8 at d <= 128) -- the host then makes the splits multiples of the stage, so the stores are aligned
+    // (dword-aligned 16-byte stores work, at 35 -> 50 us for the launch).  16 384 users x 50 000 items: 208 -> 181 us.  A
+    // 2048-user call has too few workgroups to give up four of its 32 splits for that (35.5 -> 39 us): it keeps one 4-byte
+    // store per unit.
+    constexpr int UPS = ST / kStage;          // units (= words) per stage
+    struct __attribute__((packed, aligned(4))) Words { unsigned v[UPS]; };
+    Words wb;
+#pragma unroll
+    for (int i = 0; i < UPS; ++i)
+        wb.v[i] = 0u;
+    auto flush_words = [&](int t) {                        // the split ended on unit t: the words of its unfinished stage
+        const int k = ((t - i_beg) >> 6) % UPS;
+        if (k != UPS - 1) {
+            for (int i = 0; i <= k; ++i)
+                mrow[(t >> 6) - k + i] = wb.v[i];
+        } else {
+            *reinterpret_cast<Words *>(mrow + ((t >> 6) - (UPS - 1))) = wb;
+        }
+    };
     auto unit = [&](auto prev_tag, int t0, int un, f32x16 &c0, f32x16 &c1, const f32x16 &q0, const f32x16 &q1, int t_prev) {
         constexpr bool PREV = decltype(prev_tag)::value;
         constexpr int STEPS = KS + 1;                  // k-steps incl. the bound's
@@ -290,8 +308,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
             c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[s], bb, c1, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (PREV)
-            mrow[t_prev >> 6] = user_ok ? bits : 0u;
+        if constexpr (PREV) {
+            if constexpr (WIDE)
+                wb.v[(un + UPS - 1) % UPS] = user_ok ? bits : 0u;     // (un is a constant of the unrolled stage loop)
+            else
+                mrow[t_prev >> 6] = user_ok ? bits : 0u;
+        }
     };
     // the last unit of the split (possibly the partial last unit of the catalogue: rows past i_end are clamped copies)
     auto drain = [&](const f32x16 &q0, const f32x16 &q1, int t_prev) {
@@ -303,7 +325,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             bits = (bits << 1) | ((32 + (r & 3) + 8 * (r >> 2) + 4 * h < lim && !(q1[r] <= tau)) ? 1u : 0u);
-        mrow[t_prev >> 6] = user_ok ? bits : 0u;
+        if constexpr (WIDE) {
+            wb.v[((t_prev - i_beg) >> 6) % UPS] = user_ok ? bits : 0u;
+            flush_words(t_prev);
+        } else {
+            mrow[t_prev >> 6] = user_ok ? bits : 0u;
+        }
     };
     using Yes = std::true_type;
     using No = std::false_type;
@@ -311,18 +338,25 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
     static_assert((ST / kStage) % 2 == 0, "units per stage");
     int t_last = i_beg;
     bool last_is_a = true;
-    for (int s0 = i_beg; s0 < i_end; s0 += ST) {
+    // one stage: the rows of the next one are requested at its start and converted into the other LDS buffer at its end.  All
+    // loads and stores of the loop body unconditional (a branch around them would leave the wait-count pass with vmcnt(0)):
+    // rows past the split clamp to its last one, a buffer nobody reads takes the copies, and the first stage -- which has no
+    // previous stage's words to store -- is its own instance of the body.
+    auto stage = [&](auto first_tag, int s0) {
+        constexpr bool FIRST = decltype(first_tag)::value;
         load(nxt, a.It, nullptr, s0 + ST, i_end);
         nxt_n = load_norm(s0 + ST, i_end);
 #pragma unroll
-        for (int un = 0; un < ST / kStage; un += 2) {
+        for (int un = 0; un < UPS; un += 2) {
             const int t0 = s0 + un * kStage;     // first item of this 64-item unit
-            if (t0 >= i_end)
+            if (un > 0 && t0 >= i_end)
                 break;
-            if (t0 == i_beg)
+            if (FIRST && un == 0)
                 unit(No{}, t0, un, A0, A1, B0, B1, 0);
             else
                 unit(Yes{}, t0, un, A0, A1, B0, B1, t0 - kStage);
+            if (WIDE && !FIRST && un == 0)     // the previous stage's words are complete: one store per lane
+                *reinterpret_cast<Words *>(mrow + (t0 >> 6) - UPS) = wb;
             t_last = t0, last_is_a = true;
             if (t0 + kStage >= i_end)
                 break;
@@ -333,7 +367,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
         store_norm(smem + (buf ^ 1) * ST * RB, nxt_n);
         __syncthreads();
         buf ^= 1;
-    }
+    };
+    stage(Yes{}, i_beg);
+    for (int s0 = i_beg + ST; s0 < i_end; s0 += ST)
+        stage(No{}, s0);
     if (last_is_a)
         drain(A0, A1, t_last);
     else
@@ -549,19 +586,29 @@ int launch_user_bound(const float *U, const int64_t *user_ids, int B, int d, flo
 bool prefilter_supports(int d) { return d <= 128; }
 
 int launch_prefilter(const float *U, const int64_t *user_ids, int B, const float *It, int I, int d, const float *tau, int tau_stride,
-                     const float *ubound, const float *inorm, unsigned *mask, int Wh, int S, int items_per_split, hipStream_t s)
+                     const float *ubound, const float *inorm, unsigned *mask, int Wh, int S, int items_per_split, bool wide,
+                     hipStream_t s)
 {
     PreArgs a{U, user_ids, It, tau, tau_stride, ubound, inorm, mask, Wh, B, I, d, items_per_split};
     constexpr int UT = kPreWaves * 32;
     const dim3 grid((B + UT - 1) / UT, S), block(kPreWaves * 64);
+    wide = wide && items_per_split % 256 == 0;         // (a stage's words as one aligned store: the splits must be stage multiples)
+#define TGCN_PRE_LAUNCH(KS, FULLK, ST)                                                                          \
+    do {                                                                                                        \
+        if (wide)                                                                                               \
+            hipLaunchKernelGGL((k_score_prefilter<KS, FULLK, ST, kPreWaves, true>), grid, block, 0, s, a);      \
+        else                                                                                                    \
+            hipLaunchKernelGGL((k_score_prefilter<KS, FULLK, ST, kPreWaves, false>), grid, block, 0, s, a);     \
+    } while (0)
     if (d == 64)
-        hipLaunchKernelGGL((k_score_prefilter<4, true, 256, kPreWaves>), grid, block, 0, s, a);
+        TGCN_PRE_LAUNCH(4, true, 256);
     else if (d < 64)
-        hipLaunchKernelGGL((k_score_prefilter<4, false, 256, kPreWaves>), grid, block, 0, s, a);
+        TGCN_PRE_LAUNCH(4, false, 256);
     else if (d == 128)
-        hipLaunchKernelGGL((k_score_prefilter<8, true, 128, kPreWaves>), grid, block, 0, s, a);
+        TGCN_PRE_LAUNCH(8, true, 128);
     else
-        hipLaunchKernelGGL((k_score_prefilter<8, false, 128, kPreWaves>), grid, block, 0, s, a);
+        TGCN_PRE_LAUNCH(8, false, 128);
+#undef TGCN_PRE_LAUNCH
     return check_launch("k_score_prefilter");
 }
 
