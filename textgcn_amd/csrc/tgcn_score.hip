@@ -173,7 +173,7 @@ struct DenseFilterArgs {
 };
 
 template <bool FULLK>
-__global__ __launch_bounds__(256) void k_score_dense_filter(const DenseFilterArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_score_dense_filter(const DenseFilterArgs a)
 {
     __shared__ __attribute__((aligned(16))) float smem[2 * kTile * kLdsRow];
     __shared__ int scnt[kTile];
@@ -200,38 +200,8 @@ __global__ __launch_bounds__(256) void k_score_dense_filter(const DenseFilterArg
     for (int r = 0; r < 16; ++r)
         asm volatile("" ::"v"(tau_r[r]));   // arrived before the loops (see filter_pipelined in tgcn_score_fused.hip)
     const int cap = 2 * a.cap2;
-    bool first = true;
-    for (int i0 = i_beg; i0 < i_end; i0 += kTile) {
-        f32x16 acc[4];
-#pragma unroll
-        for (int n = 0; n < 4; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                acc[n][r] = 0.0f;
-        for (int k0 = 0; k0 < a.d; k0 += kKC) {
-            if (!first)
-                __syncthreads();
-            first = false;
-            stage_tile<FULLK>(ldsU, a.U, a.user_ids, u0, a.B, k0, a.d);
-            stage_tile<FULLK>(ldsI, a.It, nullptr, i0, a.I, k0, a.d);
-            __syncthreads();
-            const float *pu = ldsU + (w * 32 + r32) * kLdsRow + 2 * h;
-            const float *pi = ldsI + r32 * kLdsRow + 2 * h;
-#pragma unroll 4
-            for (int q = 0; q < kKC / 4; ++q) {
-                const float2 a2 = *reinterpret_cast<const float2 *>(pu + q * 4);
-                float2 b2[4];
-#pragma unroll
-                for (int n = 0; n < 4; ++n)
-                    b2[n] = *reinterpret_cast<const float2 *>(pi + n * 32 * kLdsRow + q * 4);
-#pragma unroll
-                for (int n = 0; n < 4; ++n)
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.x, b2[n].x, acc[n], 0, 0, 0);
-#pragma unroll
-                for (int n = 0; n < 4; ++n)
-                    acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.y, b2[n].y, acc[n], 0, 0, 0);
-            }
-        }
+    // threshold epilogue of one finished tile
+    auto epilogue = [&](const f32x16 (&acc)[4], int i0) {
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
             const int item = i0 + n * 32 + r32;
@@ -246,6 +216,99 @@ __global__ __launch_bounds__(256) void k_score_dense_filter(const DenseFilterArg
                     }
                 }
             }
+        }
+    };
+    auto mfma_chunk = [&](f32x16 (&acc)[4]) {
+        const float *pu = ldsU + (w * 32 + r32) * kLdsRow + 2 * h;
+        const float *pi = ldsI + r32 * kLdsRow + 2 * h;
+#pragma unroll 4
+        for (int q = 0; q < kKC / 4; ++q) {
+            const float2 a2 = *reinterpret_cast<const float2 *>(pu + q * 4);
+            float2 b2[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                b2[n] = *reinterpret_cast<const float2 *>(pi + n * 32 * kLdsRow + q * 4);
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.x, b2[n].x, acc[n], 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2.y, b2[n].y, acc[n], 0, 0, 0);
+        }
+    };
+    if constexpr (FULLK) {
+        // (tile, K chunk) steps flattened; the operands of step s + 1 are requested into registers before the MFMAs of step s and
+        // stored to LDS after them: a step's global round trip hides under 128 MFMAs per wave instead of standing between two
+        // barriers.  Every load unconditional (the step past the end repeats the last one, rows past the table clamp): with a
+        // branch around the prefetch -- round 1's attempt, 320 vs 226 ms -- hipcc waits for it with vmcnt(0) where it is issued.
+        constexpr int N = (kTile * kKC / 4) / 256;
+        const int n_chunks = a.d / kKC;
+        const int n_steps = ((i_end - i_beg + kTile - 1) / kTile) * n_chunks;
+        const int t = threadIdx.x;
+        size_t urow[N];          // the user rows of the tile do not change with the step: ids read once
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int r = min(u0 + ((i * 256 + t) >> 4), a.B - 1);
+            urow[i] = (size_t)(a.user_ids ? a.user_ids[r] : (int64_t)r) * a.d;
+        }
+        float4 vu[N], vi[N];
+        auto request = [&](int step_) {
+            const int step = min(step_, n_steps - 1);
+            const int i0 = i_beg + (step / n_chunks) * kTile, k = (step % n_chunks) * kKC + (t & 15) * 4;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                vu[i] = *reinterpret_cast<const float4 *>(a.U + urow[i] + k);
+                vi[i] = *reinterpret_cast<const float4 *>(a.It + (size_t)min(i0 + ((i * 256 + t) >> 4), a.I - 1) * a.d + k);
+            }
+        };
+        auto to_lds = [&](float *dst, const float4 (&v)[N]) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const int f = i * 256 + t;
+                float *o = dst + (f >> 4) * kLdsRow + (f & 15) * 4;
+                *reinterpret_cast<float2 *>(o) = make_float2(v[i].x, v[i].z);
+                *reinterpret_cast<float2 *>(o + 2) = make_float2(v[i].y, v[i].w);
+            }
+        };
+        f32x16 acc[4];
+        request(0);
+        for (int step = 0; step < n_steps; ++step) {
+            const int chunk = step % n_chunks;
+            if (chunk == 0) {
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc[n][r] = 0.0f;
+            }
+            __syncthreads();          // the previous step's LDS reads are done (and scnt is zero before the first epilogue)
+            to_lds(ldsU, vu);
+            to_lds(ldsI, vi);
+            __syncthreads();
+            request(step + 1);
+            mfma_chunk(acc);
+            if (chunk == n_chunks - 1)
+                epilogue(acc, i_beg + (step / n_chunks) * kTile);
+        }
+    } else {
+        bool first = true;
+        for (int i0 = i_beg; i0 < i_end; i0 += kTile) {
+            f32x16 acc[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[n][r] = 0.0f;
+            for (int k0 = 0; k0 < a.d; k0 += kKC) {
+                if (!first)
+                    __syncthreads();
+                first = false;
+                stage_tile<FULLK>(ldsU, a.U, a.user_ids, u0, a.B, k0, a.d);
+                stage_tile<FULLK>(ldsI, a.It, nullptr, i0, a.I, k0, a.d);
+                __syncthreads();
+                mfma_chunk(acc);
+            }
+            epilogue(acc, i0);
         }
     }
     __syncthreads();
