@@ -169,9 +169,7 @@ __global__ __launch_bounds__(256) void k_score_filter(const FilterArgs a)
     __syncthreads();
     int buf = 0;
     for (int s0 = i_beg; s0 < i_end; s0 += kStage) {
-        const bool more = s0 + kStage < i_end;
-        if (more)
-            load_rows<DQ, FULLK>(nxt, a.It, nullptr, s0 + kStage, i_end, a.d);
+        load_rows<DQ, FULLK>(nxt, a.It, nullptr, s0 + kStage, i_end, a.d);      // unconditional (clamped rows): see filter_pipelined
         const float *pi = smem + buf * kStage * ROW + r32 * ROW + 2 * h;
         f32x16 acc0, acc1;
 #pragma unroll
@@ -247,8 +245,7 @@ __global__ __launch_bounds__(256) void k_score_filter(const FilterArgs a)
                 }
             }
         }
-        if (more)
-            store_rows<DQ>(smem + (buf ^ 1) * kStage * ROW, nxt);
+        store_rows<DQ>(smem + (buf ^ 1) * kStage * ROW, nxt);
         __syncthreads();
         buf ^= 1;
     }
@@ -339,8 +336,9 @@ __device__ __forceinline__ void filter_pipelined(const FilterArgs &a)
         constexpr bool FIRST = decltype(first_tag)::value;
         constexpr bool LAST = decltype(last_tag)::value;
         const int stage0 = s0 - half * kStage;          // first item of this LDS stage
-        const bool more = stage0 + ST < i_end;
-        if (FIRST && more)
+        // the next stage's rows: requested unconditionally (rows past the split clamp to its last one; a buffer nobody reads takes
+        // the copies) -- a branch around the prefetch leaves hipcc's wait-count pass unable to count the loads in flight
+        if (FIRST)
             load_rows<DQ, FULLK, ST>(nxt, a.It, nullptr, stage0 + ST, i_end, a.d);
         const float *pi = smem + (buf * ST + half * kStage) * ROW + r32 * ROW + 2 * h;
 #pragma unroll
@@ -391,8 +389,7 @@ __device__ __forceinline__ void filter_pipelined(const FilterArgs &a)
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (LAST) {
-            if (more)
-                store_rows<DQ, ST>(smem + (buf ^ 1) * ST * ROW, nxt);
+            store_rows<DQ, ST>(smem + (buf ^ 1) * ST * ROW, nxt);
             __syncthreads();
             buf ^= 1;
         }
