@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TGCN_ABI_VERSION 5
+#define TGCN_ABI_VERSION 6
 
 #define TGCN_OK 0
 #define TGCN_ERR_ARG (-1)         /* bad argument (null pointer, size, unsupported d/k ...) */

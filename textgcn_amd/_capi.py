@@ -8,7 +8,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_ui
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, '_lib', 'libtgcn.so')
 
-TGCN_ABI_VERSION = 5
+TGCN_ABI_VERSION = 6
 TGCN_COMM_ID_BYTES = 128
 SPMM_AUTO, SPMM_WAVE_PER_ROW = 0, 1
 
