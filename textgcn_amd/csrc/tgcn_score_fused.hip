@@ -469,7 +469,7 @@ struct SelectArgs {
     int64_t *__restrict__ out_idx;
     int *__restrict__ flagged;  // [1 + B]: count, then the flagged user rows (count zeroed by the caller each call)
     int B, S, cap2, k, do_round;
-    const int *__restrict__ totals;   // flat mode (k_rescore's output): user b's entries are logs[b * S * 2 * cap2 + 0 .. totals[b])
+    const int *__restrict__ totals;   // k_select_flat (k_rescore's output): user b's entries are logs[b * S * 2 * cap2 + 0 .. totals[b])
 };
 
 constexpr int kMaskCache = 512;  // train items per user cached in LDS for the membership test
@@ -609,6 +609,11 @@ __device__ __forceinline__ void wave_sort_desc(float &v, int &i, int lane)
     }
 }
 
+// the k best of VPL (key, index) pairs per lane (key 0 = dropped / padding), sorted into lanes 0..k-1
+template <int VPL>
+__device__ __forceinline__ void select_core(const unsigned (&key)[VPL], const int (&idx)[VPL], int k, int lane, float &out_v,
+                                            int &out_i, float2 *__restrict__ pack);
+
 template <int VPL>
 __device__ __forceinline__ void select_from_lds(const float2 *__restrict__ cand, int n, int k, int lane, float &out_v, int &out_i,
                                                 float2 *__restrict__ pack)
@@ -622,6 +627,13 @@ __device__ __forceinline__ void select_from_lds(const float2 *__restrict__ cand,
         idx[s] = __float_as_int(t.y);
         key[s] = idx[s] == INT_MAX ? 0u : ordered_key(t.x);      // dropped / padding: below every real score (key >= 1)
     }
+    select_core<VPL>(key, idx, k, lane, out_v, out_i, pack);
+}
+
+template <int VPL>
+__device__ __forceinline__ void select_core(const unsigned (&key)[VPL], const int (&idx)[VPL], int k, int lane, float &out_v,
+                                            int &out_i, float2 *__restrict__ pack)
+{
     // T = k-th largest key: the largest T with |{key >= T}| >= k
     unsigned T = 0;
     for (int bit = 31; bit >= 0; --bit) {
@@ -704,46 +716,27 @@ __global__ __launch_bounds__(256) void k_select(const SelectArgs a)
     // for both instead of two
     const int m_first = (cached && lane < me - mb) ? a.mask_items[mb + lane] : 0;
     const int n_seg = a.S * 2;   // <= 64: one segment per lane
-    bool overflow = false;
-    int n = 0, cnt = 0, off = 0;
-    if (a.totals) {
-        n = a.totals[b];
-        overflow = n > min(kSelCap, n_seg * a.cap2);
-    } else {
-        cnt = lane < n_seg ? a.counts[(size_t)b * n_seg + lane] : 0;
-        overflow = __any(cnt > a.cap2);
-        cnt = min(cnt, a.cap2);
-        // exclusive prefix of the counts over lanes
-        off = cnt;
+    int cnt = lane < n_seg ? a.counts[(size_t)b * n_seg + lane] : 0;
+    bool overflow = __any(cnt > a.cap2);
+    cnt = min(cnt, a.cap2);
+    // exclusive prefix of the counts over lanes
+    int off = cnt;
 #pragma unroll
-        for (int o = 1; o < kWave; o <<= 1) {
-            const int t = __shfl_up(off, o);
-            if (lane >= o)
-                off += t;
-        }
-        n = __builtin_amdgcn_readlane(off, kWave - 1);
-        off -= cnt;
-        if (n > kSelCap)
-            overflow = true;
+    for (int o = 1; o < kWave; o <<= 1) {
+        const int t = __shfl_up(off, o);
+        if (lane >= o)
+            off += t;
     }
+    const int n = __builtin_amdgcn_readlane(off, kWave - 1);
+    off -= cnt;
+    if (n > kSelCap)
+        overflow = true;
     bool ok = !overflow;
     float out_v = -INFINITY;
     int out_i = INT_MAX;
     if (ok) {
         float2 *cand = scand[w];
-        if (a.totals) {
-            const float2 *__restrict__ lg = a.logs + (size_t)b * n_seg * a.cap2;
-            for (int j0 = 0; j0 < n; j0 += 8 * kWave) {      // eight coalesced loads in flight (n > 0 inside the loop)
-                float2 t[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    t[u] = lg[min(j0 + u * kWave + lane, n - 1)];
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    if (j0 + u * kWave + lane < n)
-                        cand[j0 + u * kWave + lane] = t[u];
-            }
-        } else {
+        {
             const float2 *__restrict__ lg = a.logs + ((size_t)b * n_seg + min(lane, n_seg - 1)) * a.cap2;
             int longest = cnt;
 #pragma unroll
@@ -793,6 +786,78 @@ __global__ __launch_bounds__(256) void k_select(const SelectArgs a)
             else
                 select_from_lds<kSelVPL>(cand, n, a.k, lane, out_v, out_i, spack[w]);
         }
+    }
+    if (!ok && lane == 0)
+        a.flagged[1 + atomicAdd(a.flagged, 1)] = b;
+    if (ok && lane < a.k) {
+        a.out_val[(size_t)b * a.k + lane] = a.do_round ? round4(out_v) : out_v;
+        a.out_idx[(size_t)b * a.k + lane] = out_i;
+    }
+}
+
+// k_select for k_rescore's flat lists (totals[b] entries at logs[b * S * 2 * cap2 ...]): the candidates go from global memory
+// straight into registers (16 per lane at most) -- no 8 KB LDS staging array per wave, so the launch is not held to three
+// workgroups per CU by it -- and the train items are dropped there.
+__global__ __launch_bounds__(256) void k_select_flat(const SelectArgs a)
+{
+    __shared__ float2 spack[4][kWave];
+    __shared__ int smask[4][kMaskCache];
+    const int lane = lane_id();
+    const int w = threadIdx.x >> 6;
+    const int b = uniform(blockIdx.x * 4 + w);
+    if (b >= a.B)
+        return;
+    int mb = 0, me = 0;
+    if (a.mask_rowptr) {
+        mb = a.mask_rowptr[b];
+        me = a.mask_rowptr[b + 1];
+    }
+    const bool cached = (me - mb) <= kMaskCache;
+    const int m_first = (cached && lane < me - mb) ? a.mask_items[mb + lane] : 0;
+    const int list_cap = a.S * 2 * a.cap2;
+    const int n = a.totals[b];
+    bool ok = n <= min(kSelCap, list_cap) && n > 0;
+    float out_v = -INFINITY;
+    int out_i = INT_MAX;
+    if (ok) {
+        const float2 *__restrict__ lg = a.logs + (size_t)b * list_cap;
+        auto run = [&](auto vpl_tag) {
+            constexpr int VPL = decltype(vpl_tag)::value;
+            float2 t[VPL];
+#pragma unroll
+            for (int s = 0; s < VPL; ++s)
+                t[s] = lg[min(lane + kWave * s, n - 1)];       // unconditional (clamped) loads, all in flight
+            if (cached) {
+                if (lane < me - mb)
+                    smask[w][lane] = m_first;
+                for (int j = kWave + lane; j < me - mb; j += kWave)
+                    smask[w][j] = a.mask_items[mb + j];
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+            unsigned key[VPL];
+            int idx[VPL];
+            int n_valid = 0;
+#pragma unroll
+            for (int s = 0; s < VPL; ++s) {
+                const int si = __float_as_int(t[s].y);
+                bool on = lane + kWave * s < n;
+                if (on && (cached ? sorted_contains(smask[w], 0, me - mb, si) : sorted_contains(a.mask_items, mb, me, si)))
+                    on = false;     // a train item (base_model.py:257-258 sets them to -inf)
+                idx[s] = on ? si : INT_MAX;
+                key[s] = on ? ordered_key(t[s].x) : 0u;
+                n_valid += __popcll(__ballot(on));
+            }
+            ok = n_valid >= a.k;
+            if (ok)
+                select_core<VPL>(key, idx, a.k, lane, out_v, out_i, spack[w]);
+        };
+        if (n <= 4 * kWave)
+            run(std::integral_constant<int, 4>{});
+        else if (n <= 8 * kWave)
+            run(std::integral_constant<int, 8>{});
+        else
+            run(std::integral_constant<int, kSelVPL>{});
     }
     if (!ok && lane == 0)
         a.flagged[1 + atomicAdd(a.flagged, 1)] = b;
@@ -1164,7 +1229,10 @@ int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const fl
 
     // 3. exact selection from the logs; 4. exact rescoring of flagged users
     SelectArgs sa{fa.logs, fa.counts, mask_rowptr, mask_items, out_val, out_idx, flagged, B, p.S, p.cap2, k, round4, totals};
-    hipLaunchKernelGGL(k_select, dim3((B + 3) / 4), dim3(256), 0, s, sa);
+    if (sa.totals)
+        hipLaunchKernelGGL(k_select_flat, dim3((B + 3) / 4), dim3(256), 0, s, sa);
+    else
+        hipLaunchKernelGGL(k_select, dim3((B + 3) / 4), dim3(256), 0, s, sa);
     if ((rc = check_launch("k_select")) != TGCN_OK)
         return rc;
     BruteArgs ba{U, user_ids, It, mask_rowptr, mask_items, flagged, reinterpret_cast<float2 *>(ws + p.off_parts), done, p.flag_cap,
