@@ -428,3 +428,31 @@ def test_prefilter_keeps_the_fallback_rare(cuda, b, i, d):
             scoring.score_topk(ue, ie, 40, prefilter=mode, slot=7)
             counts[mode] = scoring.fallback_count(cuda, b, i, d, 40, slot=7)
         assert counts[False] <= 2 and counts[True] <= 4, counts
+
+
+def test_prefilter_identical_over_random_shapes(cuda):
+    """A sweep of shapes, widths, k, mask sizes and value scales (seeded): both entry points against each other, bit for bit --
+    heavy-tailed norms, sparse rows and near-ties included."""
+    from textgcn_amd import scoring
+    rng = np.random.default_rng(2024)
+    for trial in range(14):
+        b = int(rng.integers(1, 700))
+        i = int(rng.integers(8193, 40000))
+        d = int(rng.choice([8, 24, 32, 50, 64, 64, 96, 100, 128, 128]))
+        k = int(rng.integers(1, 65))
+        scale_u = np.exp(rng.normal(0, 1.5, size=(b, 1))).astype(np.float32)        # log-normal row scales: heavy-tailed norms
+        scale_i = np.exp(rng.normal(0, 1.5, size=(i, 1))).astype(np.float32)
+        u = (rng.standard_normal((b, d)) * scale_u * 0.1).astype(np.float32)
+        it = (rng.standard_normal((i, d)) * scale_i * 0.1).astype(np.float32)
+        if trial % 3 == 0:
+            it[rng.random((i, d)) < 0.7] = 0.0                                        # sparse rows
+        if trial % 4 == 1:
+            it[1::3] = it[0::3][: len(it[1::3])]                                      # exact ties
+        rp, items = _rand_mask(rng, b, i, 0, int(rng.integers(1, 200)))
+        ud, itd = torch.from_numpy(u).to(cuda), torch.from_numpy(it).to(cuda)
+        rpd, imd = torch.from_numpy(rp.astype(np.int32)).to(cuda), torch.from_numpy(items.astype(np.int32)).to(cuda)
+        rv, ri = scoring.score_topk(ud, itd, k, mask_rowptr=rpd, mask_items=imd, round4=False)
+        pv, pi = scoring.score_topk(ud, itd, k, mask_rowptr=rpd, mask_items=imd, round4=False, prefilter=True)
+        torch.cuda.synchronize()
+        assert torch.equal(pi, ri), (trial, b, i, d, k, int((pi != ri).sum()))
+        assert np.array_equal(bits(pv.cpu().numpy()), bits(rv.cpu().numpy())), (trial, b, i, d, k)
