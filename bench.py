@@ -527,6 +527,8 @@ def main():
     ap.add_argument('--shard', default='rows', choices=['rows', 'features'],
                     help="N > 1: 'rows' = 1-D row partition with per-layer RCCL all-gathers (the north-star design, default); "
                          "'features' = every rank holds all rows and d/N columns: no per-layer exchange, one all-gather at the end")
+    ap.add_argument('--no-feature-partition', action='store_true',
+                    help='N > 1: skip the second timing of the forward under the feature (column) partition')
     ap.add_argument('--force-sharded', action='store_true',
                     help='N = 1 only: run the N > 1 code path (row blocks, chunked RCCL all-gathers on a 1-rank communicator, '
                          'per-rank scoring, all-reduced timing) on the one GPU -- a rehearsal of the multi-GPU run, not a headline')
@@ -650,6 +652,23 @@ def main():
                    'graph_build_s': round(build_s, 1)},
         'roofline': roofline,
     }
+    if sharded and args.shard == 'rows' and d % world == 0 and d // world in (8, 16, 32, 64) and not args.no_feature_partition:
+        # the same forward under the feature partition (every rank: all rows, d / world columns, no per-layer exchange, one
+        # all-gather at the end), timed the same way in the same run: the record's `value` stays the row partition's
+        cp = ColumnShardedPropagator(graph, d, rank, world, dev, split_threshold=thr, force_collective=args.force_sharded)
+        e_cols = cp.local_e0(e0)
+
+        def step_cols():
+            return cp.assemble(cp.forward(e_cols, K, exact=args.exact))
+        tc_dev, tc_wall = time_steps(step_cols, args.steps, args.warmup, barrier)
+        tc = reduce_max_sum([max(tc_wall, tc_dev)])[0][0]
+        result['feature_partition'] = {
+            'what': f'all rows, {cp.dl} of {d} columns per rank, no per-layer exchange, one RCCL all-gather of the combined table per '
+                    f'forward (ColumnShardedPropagator); bit-identical to the row partition',
+            'value': args.steps * K * graph.nnz / tc, 'unit': 'edges/s', 'ms_per_step': tc / args.steps * 1e3}
+        cp.close()
+        del cp, e_cols
+        torch.cuda.empty_cache()
     if sharded:
         result['config']['scaling_note'] = 'fixed total work (BASELINE config 4) split over the ranks; N = 1 of the same workload: ' \
                                            'bench.py --gpus 1 reports it as the sub-record c4_1gpu'
