@@ -454,6 +454,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     filter_pipelined<16, FULLK, kStage>(a);
 }
 
+// the same loop with the registers of two waves per SIMD (no spills): a call of a few thousand users has two workgroups per CU
+// whatever the budget, and without the 168-register squeeze it runs 0.62 instead of 0.60 T pairs/s end to end (2048 users,
+// config 2); calls that fill the chip several times over keep the third wave (16 384 users: 0.69 against 0.67)
+template <bool FULLK>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_score_filter16_small(const FilterArgs a)
+{
+    filter_pipelined<16, FULLK, kStage>(a);
+}
+
 template <bool FULLK>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_score_filter32(const FilterArgs a)
 {
@@ -1211,8 +1220,12 @@ int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const fl
         rc = launch_rescore(U, user_ids, B, It, d, tau_ptr, tau_stride, mask, p.Wh, fa.logs, totals, p.S * 2 * p.cap2, s);
     } else if (d <= 128) {
         const dim3 grid((B + kUsersPerWG - 1) / kUsersPerWG, p.S);
-        if (d == 64)
+        if (d == 64 && B <= 4096)
+            hipLaunchKernelGGL((k_score_filter16_small<true>), grid, dim3(256), 0, s, fa);
+        else if (d == 64)
             hipLaunchKernelGGL((k_score_filter16<true>), grid, dim3(256), 0, s, fa);
+        else if (d < 64 && B <= 4096)
+            hipLaunchKernelGGL((k_score_filter16_small<false>), grid, dim3(256), 0, s, fa);
         else if (d < 64)
             hipLaunchKernelGGL((k_score_filter16<false>), grid, dim3(256), 0, s, fa);
         else if (d == 128)
