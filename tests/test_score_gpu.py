@@ -256,10 +256,11 @@ def test_fused_topk_vs_oracle_sample(cuda, oracle):
     s = oracle.score_dense(u, it)
     oracle.mask_train(s, rp, items)
     rv, ri = oracle.topk(s, k, round4=True)
-    v, idx = scoring.score_topk(torch.from_numpy(u).to(cuda), torch.from_numpy(it).to(cuda), k,
-                                mask_rowptr=torch.from_numpy(rp.astype(np.int32)).to(cuda),
-                                mask_items=torch.from_numpy(items.astype(np.int32)).to(cuda), round4=True)
-    assert np.array_equal(idx.cpu().numpy(), ri) and np.array_equal(bits(v.cpu().numpy()), bits(rv))
+    for prefilter in (False, True):        # both entry points directly against the oracle
+        v, idx = scoring.score_topk(torch.from_numpy(u).to(cuda), torch.from_numpy(it).to(cuda), k,
+                                    mask_rowptr=torch.from_numpy(rp.astype(np.int32)).to(cuda),
+                                    mask_items=torch.from_numpy(items.astype(np.int32)).to(cuda), round4=True, prefilter=prefilter)
+        assert np.array_equal(idx.cpu().numpy(), ri) and np.array_equal(bits(v.cpu().numpy()), bits(rv)), prefilter
 
 
 @pytest.mark.parametrize('b,i,d,k', [(70, 20000, 64, 100), (33, 9000, 128, 150), (9, 300, 64, 130), (5, 200, 48, 65)])
@@ -312,7 +313,7 @@ def test_fused_topk_at_config3_scoring_shape(cuda, oracle):
     rp = np.zeros(b + 1, dtype=np.int64)
     np.cumsum([len(t) for t in lists], out=rp[1:])
     items = np.concatenate(lists)
-    v, idx = _fused_vs_dense(cuda, u, it, k, mask=(rp, items))
+    v, idx = _fused_vs_dense(cuda, u, it, k, mask=(rp, items))      # (runs the prefiltered entry point too, same bits required)
     rows = rng.choice(b, size=48, replace=False)
     rv, ri = _oracle_topk_rows(oracle, u, it, rp, items, rows, k)
     assert np.array_equal(idx.cpu().numpy()[rows], ri)
