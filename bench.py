@@ -239,14 +239,14 @@ def scoring_region(ue, ie, batches, k_top, dev, barrier, prefilter=False):
     side = [torch.cuda.Stream(dev) for _ in range(N_SCORE_STREAMS)]
 
     def score_all(bts):   # the predict step of base_model.py:254-263, fused (tgcn_score_topk_f32)
-        norm = scoring.item_norms(ie) if prefilter else None
+        pack = scoring.item_pack(ie) if prefilter else None
         for st in side:
             st.wait_stream(main)
         keep = []
         for j, (ids, rp, it) in enumerate(bts):
             with torch.cuda.stream(side[j % N_SCORE_STREAMS]):
                 keep.append(scoring.score_topk(ue, ie, k_top, user_ids=ids, mask_rowptr=rp, mask_items=it, round4=True,
-                                               slot=j % N_SCORE_STREAMS, prefilter=prefilter, item_norm=norm))
+                                               slot=j % N_SCORE_STREAMS, prefilter=prefilter, item_pack=pack))
         for st in side:
             main.wait_stream(st)
         return keep

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TGCN_ABI_VERSION 6
+#define TGCN_ABI_VERSION 7
 
 #define TGCN_OK 0
 #define TGCN_ERR_ARG (-1)         /* bad argument (null pointer, size, unsupported d/k ...) */
@@ -163,13 +163,19 @@ int tgcn_score_topk_f32(const float *U, const int64_t *user_ids, int32_t B, cons
  * {i : score > tau_u}; every kept pair gets its k-ordered fp32 fmaf score and is dropped again unless score > tau_u.  Results
  * are bit-identical to tgcn_score_topk_f32 (indices, scores, tie order, fallback); only the cost of finding the candidates
  * changes.  Applies to d <= 128 and I > 8192; any other shape runs tgcn_score_topk_f32's own path.  Same workspace.
- * `item_norms`: device pointer to the 2 I item factors of the bound as written by tgcn_item_norms_f32 for this item table
- * (the table is fixed across the batches of a predict call), or NULL: computed inside the call. */
+ * `item_pack`: device pointer to the packed item operand written by tgcn_item_pack_bf16 for this item table (the table is
+ * fixed across the batches of a predict call), or NULL: packed inside the call, into the workspace. */
 int tgcn_score_topk_prefilter_f32(const float *U, const int64_t *user_ids, int32_t B, const float *It, int32_t I,
                                   int32_t d, const int32_t *mask_rowptr, const int32_t *mask_items, int32_t k,
-                                  int32_t round4, const float *item_norms, float *out_val, int64_t *out_idx,
+                                  int32_t round4, const void *item_pack, float *out_val, int64_t *out_idx,
                                   void *workspace, int64_t workspace_bytes, tgcn_stream_t stream);
-/* out[2 i] = |It[i]|_2 (elements floored at 2^-50), out[2 i + 1] = |It[i] - bf16(It[i])|_2 (the row's rounding residual under
+/* The item operand of the bf16 pass: per item row its bf16 image (round-to-nearest-even, zero-padded to 64 or 128 elements)
+ * followed by the row's factors of the error bound, 144 (d <= 64) or 272 (d <= 128) bytes per row -- the exact bytes the filter
+ * kernel stages, so a stage is one contiguous copy.  tgcn_item_pack_bytes: size of `out` (0: no bf16 pass for this width, the
+ * prefilter entry then runs the fp32 path and ignores `item_pack`; < 0: bad argument).  `out` 16-byte aligned. */
+int64_t tgcn_item_pack_bytes(int32_t I, int32_t d);
+int tgcn_item_pack_bf16(const float *It, int32_t I, int32_t d, void *out, tgcn_stream_t stream);
+/* Diagnostic (the factors the pack carries, in fp32): out[2 i] = |It[i]|_2 (elements floored at 2^-50), out[2 i + 1] = |It[i] - bf16(It[i])|_2 (the row's rounding residual under
  * round-to-nearest-even), each times (1 + 2^-12); +inf if not finite. */
 int tgcn_item_norms_f32(const float *It, int32_t I, int32_t d, float *out, tgcn_stream_t stream);
 /* Diagnostic: how many of the B users of the LAST call that used `workspace` (either entry point, same B, I, d, k) took the

@@ -78,6 +78,12 @@ def test_c_abi_rejects_bad_arguments_with_message(built_lib):
     rc = lib.tgcn_score_topk_prefilter_f32(None, None, 4, None, 100, 64, None, None, 10, 0, None, None, None, None, 0, None)
     assert rc == -1
     assert lib.tgcn_score_topk_prefilter_f32(None, None, 0, None, 100, 64, None, None, 10, 0, None, None, None, None, 0, None) == 0
+    assert lib.tgcn_item_pack_bytes(50000, 64) == 50000 * 144 and lib.tgcn_item_pack_bytes(60000, 128) == 60000 * 272
+    assert lib.tgcn_item_pack_bytes(100, 50) == 100 * 144 and lib.tgcn_item_pack_bytes(100, 960) == 0 and lib.tgcn_item_pack_bytes(-1, 64) < 0
+    rc = lib.tgcn_item_pack_bf16(None, 10, 64, None, None)
+    assert rc == -1 and b'NULL' in lib.tgcn_last_error()
+    rc = lib.tgcn_item_pack_bf16(None, 10, 960, None, None)
+    assert rc == -1 and b'width' in lib.tgcn_last_error()
     rc = lib.tgcn_item_norms_f32(None, 10, 64, None, None)
     assert rc == -1 and b'NULL' in lib.tgcn_last_error()
     rc = lib.tgcn_score_topk_fallback_count(None, 4, 100, 64, 10, None, None)

@@ -176,11 +176,11 @@ def _fused_vs_dense(cuda, u, it, k, mask=None, user_ids=None, round4=True):
     torch.cuda.synchronize()
     assert torch.equal(i, ri), (i != ri).sum().item()
     assert np.array_equal(bits(v.cpu().numpy()), bits(rv.cpu().numpy()))
-    # the bf16-prefiltered entry point (tgcn_score_topk_prefilter_f32): the same bits, with the item norm computed inside the
+    # the bf16-prefiltered entry point (tgcn_score_topk_prefilter_f32): the same bits, with the item operand packed inside the
     # call and handed in
-    for norm in (None, scoring.item_norms(itd)):
+    for pack in (None, scoring.item_pack(itd)):
         pv, pi = scoring.score_topk(ud, itd, k, user_ids=ids, mask_rowptr=rp, mask_items=it_, round4=round4, prefilter=True,
-                                    item_norm=norm)
+                                    item_pack=pack)
         torch.cuda.synchronize()
         assert torch.equal(pi, ri), ('prefilter', (pi != ri).sum().item())
         assert np.array_equal(bits(pv.cpu().numpy()), bits(rv.cpu().numpy()))
@@ -398,6 +398,32 @@ def test_item_norms(cuda):
         assert np.all(got[fin, 1] >= want_r[fin]) and np.all(got[fin, 1] <= want_r[fin] * (1 + 2.0 ** -11))
         assert np.all(got[fin, 1] <= 2.0 ** -8 * got[fin, 0] * (1 + 2.0 ** -10))
         assert np.all(np.isposinf(got[np.isposinf(want)]))
+
+
+def test_item_pack(cuda):
+    """the packed item operand: row i = the bf16 image of the row (round-to-nearest-even, zeros behind d) and, in the 16-byte chunk
+    behind it, [r_i, n_i + r_i, n_i] each rounded UP to bf16 from the factors tgcn_item_norms_f32 reports"""
+    from textgcn_amd import scoring
+    rng = np.random.default_rng(4)
+    for n, d in ((50000, 64), (777, 128), (1000, 100), (333, 50), (5, 32), (3, 16)):
+        it = (rng.standard_normal((n, d)) * 0.3).astype(np.float32)
+        if n > 100:
+            it[11] = 0.0
+            it[13] = 0.375
+        t = torch.from_numpy(it).to(cuda)
+        width = 64 if d <= 64 else 128
+        pack = scoring.item_pack(t).cpu().numpy().reshape(n, 2 * width + 16)
+        rows = pack[:, :2 * width].copy().view(np.uint16)
+        want = np.zeros((n, width), dtype=np.uint16)
+        want[:, :d] = torch.from_numpy(it).to(torch.bfloat16).view(torch.int16).numpy().view(np.uint16)
+        assert np.array_equal(rows, want)
+        chunk = pack[:, 2 * width:].copy().view(np.uint16)
+        assert not chunk[:, 3:].any()
+        f = (chunk[:, :3].astype(np.uint32) << 16).view(np.float32).astype(np.float64)      # r, n + r, n as bf16 values
+        norms = scoring.item_norms(t).cpu().numpy().astype(np.float64)
+        for got, ref in ((f[:, 0], norms[:, 1]), (f[:, 1], norms[:, 0] + norms[:, 1]), (f[:, 2], norms[:, 0])):
+            assert np.all(got >= ref) and np.all(got <= ref * (1 + 2.0 ** -7) * (1 + 2.0 ** -19))
+    assert scoring.item_pack(torch.zeros(10, 960, device=cuda)) is None
 
 
 def test_prefilter_outlier_item_does_not_flood_the_lists(cuda):

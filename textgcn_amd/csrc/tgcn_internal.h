@@ -113,11 +113,12 @@ int launch_score_dense_filter(const float *U, const int64_t *user_ids, int B, co
 bool prefilter_supports(int d);
 int launch_item_norms(const float *It, int I, int d, float *norms /* [I][2] */, hipStream_t stream);
 int launch_user_bound(const float *U, const int64_t *user_ids, int B, int d, float *ubound /* [B][2] */, hipStream_t stream);
-int launch_prefilter(const float *U, const int64_t *user_ids, int B, const float *It, int I, int d, const float *tau, int tau_stride,
-                     const float *ubound, const float *inorm, unsigned *mask, int Wh, int S, int items_per_split, bool wide,
-                     hipStream_t stream);
+size_t item_pack_bytes(int I, int d);      // 0: no bf16 candidate pass for this width
+int launch_item_pack(const float *It, int I, int d, void *pack, hipStream_t stream);
+int launch_prefilter(const float *U, const int64_t *user_ids, int B, const void *ipack, int I, int d, const float *tau, int tau_stride,
+                     const float *ubound, unsigned *mask, int Wh, int S, int items_per_split, bool wide, hipStream_t stream);
 int launch_rescore(const float *U, const int64_t *user_ids, int B, const float *It, int d, const float *tau, int tau_stride,
-                   const unsigned *mask, int Wh, void *lists, int *totals, int list_cap, hipStream_t stream);
+                   const unsigned *mask, int Wh, int n_units, void *lists, int *totals, int list_cap, hipStream_t stream);
 int launch_topk(const float *S, int64_t lds, int B, int I, int k, int do_round, float *out_val, int64_t *out_idx,
                 hipStream_t stream);
 int launch_mask(float *S, int64_t lds, int B, int I, const int *mask_rowptr, const int *mask_items, int item_div,

@@ -1007,9 +1007,9 @@ __global__ __launch_bounds__(kBruteWaves * 64) void k_brute_part(const BruteArgs
 
 struct Plan {
     int S, items_per_split, cap2, m, m_ld;  // m = sampled items
-    int Wh;                                 // 64-item units of the catalogue (d <= 128: the filters emit pass bits)
+    int Wh;                                 // mask words per (user, row half): the 64-item units of the catalogue, padded to 4
     size_t off_mask;
-    size_t off_sample, off_tauv, off_taui, off_tau, off_ubound, off_inorm, off_logs, off_counts, off_parts, off_flags, off_done, off_totals, total;
+    size_t off_sample, off_tauv, off_taui, off_tau, off_ubound, off_ipack, off_logs, off_counts, off_parts, off_flags, off_done, off_totals, total;
     int flag_cap;
     bool small;
 };
@@ -1043,10 +1043,9 @@ Plan make_plan(int B, int I, int d, int k)
     p.off_taui = o, o += align256((size_t)B * kTauRank * sizeof(int64_t));
     p.off_tau = o, o += align256((size_t)B * sizeof(float));
     p.off_ubound = o, o += align256((size_t)B * 2 * sizeof(float));         // prefilter mode: the users' factors of the bound
-    p.off_inorm = o;                                                       // ... and the items' (unless the caller holds them)
-    if (d <= 128)
-        o += align256((size_t)I * 2 * sizeof(float));
-    p.Wh = (I + kStage - 1) / kStage;
+    p.off_ipack = o;                                                       // ... and the packed item operand (unless the caller
+    o += align256(item_pack_bytes(I, d));                                  //     holds it: tgcn_item_pack_bf16)
+    p.Wh = ((I + kStage - 1) / kStage + 3) & ~3;   // words per row half, padded: every half starts on a 16-byte boundary
     p.off_mask = o;
     if (d <= 128)
         o += align256((size_t)((B + 255) / 256) * 256 * 2 * p.Wh * sizeof(unsigned));   // rows of the bf16 filter's padded users
@@ -1117,12 +1116,12 @@ extern "C" int64_t tgcn_score_topk_workspace_bytes(int32_t B, int32_t I, int32_t
 
 namespace {
 // prefilter: candidates from the bf16 pass of tgcn_score_prefilter.hip, rescored in fp32 (same results; d <= 128, d % 4 == 0,
-// otherwise the fp32 filter runs).  item_norms: device pointer to the I item factors of the bound (tgcn_item_norms_f32), or
-// NULL: computed by this call.
+// otherwise the fp32 filter runs).  item_pack: device pointer to the packed item operand (tgcn_item_pack_bf16), or NULL: packed by
+// this call.
 int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const float *It, int32_t I, int32_t d,
                     const int32_t *mask_rowptr, const int32_t *mask_items, int32_t k, int32_t round4, float *out_val,
                     int64_t *out_idx, void *workspace, int64_t workspace_bytes, tgcn_stream_t stream, bool prefilter,
-                    const float *item_norm)
+                    const void *item_pack)
 {
     TGCN_REQUIRE(B >= 0 && I >= 0, "negative size");
     TGCN_REQUIRE(d > 0 && d <= 4096, "d out of range");
@@ -1152,12 +1151,11 @@ int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const fl
     // prefilter mode: the item-side factor of the bound, unless the caller holds it
     prefilter = prefilter && prefilter_supports(d);
     float *ubound = prefilter ? reinterpret_cast<float *>(ws + p.off_ubound) : nullptr;
-    const float *inorm = item_norm;
-    if (prefilter && !inorm) {
-        float *np = reinterpret_cast<float *>(ws + p.off_inorm);
-        if ((rc = launch_item_norms(It, I, d, np, s)) != TGCN_OK)
+    const void *ipack = item_pack;
+    if (prefilter && !ipack) {
+        if ((rc = launch_item_pack(It, I, d, ws + p.off_ipack, s)) != TGCN_OK)
             return rc;
-        inorm = np;
+        ipack = ws + p.off_ipack;
     }
     // 1. tau from a strided item sample
     float *Ss = reinterpret_cast<float *>(ws + p.off_sample);
@@ -1211,13 +1209,13 @@ int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const fl
         const bool wide = B > 4096;
         int ips_pre = p.items_per_split;
         if (d > 64 && I <= (1 << 18))
-            ips_pre = 1024;
+            ips_pre = 1024;      // (768 / 1280 / 2048 with the packed operand: 54 / 53 / 56 us against 46)
         else if (wide)
             ips_pre = ((p.items_per_split + 255) / 256) * 256;
-        if ((rc = launch_prefilter(U, user_ids, B, It, I, d, tau_ptr, tau_stride, ubound, inorm, mask, p.Wh, (I + ips_pre - 1) / ips_pre,
+        if ((rc = launch_prefilter(U, user_ids, B, ipack, I, d, tau_ptr, tau_stride, ubound, mask, p.Wh, (I + ips_pre - 1) / ips_pre,
                                    ips_pre, wide, s)) != TGCN_OK)
             return rc;
-        rc = launch_rescore(U, user_ids, B, It, d, tau_ptr, tau_stride, mask, p.Wh, fa.logs, totals, p.S * 2 * p.cap2, s);
+        rc = launch_rescore(U, user_ids, B, It, d, tau_ptr, tau_stride, mask, p.Wh, (I + kStage - 1) / kStage, fa.logs, totals, p.S * 2 * p.cap2, s);
     } else if (d <= 128) {
         const dim3 grid((B + kUsersPerWG - 1) / kUsersPerWG, p.S);
         if (d == 64 && B <= 4096)
@@ -1271,11 +1269,11 @@ extern "C" int tgcn_score_topk_f32(const float *U, const int64_t *user_ids, int3
 
 extern "C" int tgcn_score_topk_prefilter_f32(const float *U, const int64_t *user_ids, int32_t B, const float *It, int32_t I,
                                              int32_t d, const int32_t *mask_rowptr, const int32_t *mask_items, int32_t k,
-                                             int32_t round4, const float *item_norm, float *out_val, int64_t *out_idx,
+                                             int32_t round4, const void *item_pack, float *out_val, int64_t *out_idx,
                                              void *workspace, int64_t workspace_bytes, tgcn_stream_t stream)
 {
     return score_topk_impl(U, user_ids, B, It, I, d, mask_rowptr, mask_items, k, round4, out_val, out_idx, workspace,
-                           workspace_bytes, stream, true, item_norm);
+                           workspace_bytes, stream, true, item_pack);
 }
 
 extern "C" int tgcn_score_topk_fallback_count(const void *workspace, int32_t B, int32_t I, int32_t d, int32_t k, int32_t *out_host,
@@ -1292,6 +1290,23 @@ extern "C" int tgcn_score_topk_fallback_count(const void *workspace, int32_t B, 
         hipStreamSynchronize(s) != hipSuccess)
         return check_launch("tgcn_score_topk_fallback_count");
     return TGCN_OK;
+}
+
+extern "C" int64_t tgcn_item_pack_bytes(int32_t I, int32_t d)
+{
+    return (I < 0 || d <= 0) ? -1 : (int64_t)item_pack_bytes(I, d);
+}
+
+extern "C" int tgcn_item_pack_bf16(const float *It, int32_t I, int32_t d, void *out, tgcn_stream_t stream)
+{
+    TGCN_REQUIRE(I >= 0, "negative size");
+    TGCN_REQUIRE(d > 0 && d <= 4096, "d out of range");
+    TGCN_REQUIRE(prefilter_supports(d), "no bf16 candidate pass for this width (tgcn_item_pack_bytes() == 0)");
+    if (I == 0)
+        return TGCN_OK;
+    TGCN_REQUIRE(It && out, "NULL pointer");
+    TGCN_REQUIRE(((size_t)out & 15) == 0, "out must be 16-byte aligned");
+    return launch_item_pack(It, I, d, out, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int tgcn_item_norms_f32(const float *It, int32_t I, int32_t d, float *out, tgcn_stream_t stream)

@@ -30,6 +30,7 @@ namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
 constexpr int kPreWaves = 8;        // waves (x 32 users) per workgroup of the bf16 filter: every item row a workgroup stages is
                                    // fetched from L2 once per 256 users (with 128, the 16 user tiles of a 2048-user call pull
@@ -101,6 +102,78 @@ __global__ __launch_bounds__(256) void k_item_norms(const float *__restrict__ It
     }
 }
 
+// ---- the item operand of the filter, packed once per item table --------------------------------------------------------------
+// Row i of the pack is the LDS image of item i in the filter's stages: 16 KS bf16 elements (the row, round-to-nearest-even, zeros
+// behind d) followed by a 16-byte chunk [r_i, n_i + r_i, n_i] rounded UP to bf16 (the A operand of the bound's k-step), zeros
+// behind -- RB = 32 KS + 16 bytes, KS = 4 (d <= 64) or 8 (d <= 128).  A stage of the filter is then ST RB CONTIGUOUS bytes: 16-byte
+// loads straight into 16-byte LDS stores, half the bytes of the fp32 rows and no conversion in the loop (the filter took 35 us
+// with the fp32 rows converted per stage, 26 with the staging removed altogether -- profiles/r02_experiments.md).
+__device__ __forceinline__ uint4 bound_chunk(float n, float r)
+{
+    return make_uint4(bf16_up_bits(r) | (bf16_up_bits((n + r) * (1.0f + 0x1p-20f)) << 16), bf16_up_bits(n), 0u, 0u);
+}
+
+template <int G>      // d = 4 G = 16 KS exactly: G lanes per row, one float4 each
+__device__ __forceinline__ void pack_rows_pow2(const float *__restrict__ It, int I, int wave, int n_waves, int lane,
+                                               unsigned char *__restrict__ pack)
+{
+    constexpr int R = kWave / G, d = 4 * G, RB = 8 * G + 16;
+    const int sub = lane / G, q = lane % G;
+    for (int r0 = wave * 4 * R; r0 < I; r0 += n_waves * 4 * R) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            v[u] = *reinterpret_cast<const float4 *>(It + (size_t)min(r0 + u * R + sub, I - 1) * d + 4 * q);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float t = (floored_sq(v[u].x) + floored_sq(v[u].y)) + (floored_sq(v[u].z) + floored_sq(v[u].w));
+            float e = (residual_sq(v[u].x) + residual_sq(v[u].y)) + (residual_sq(v[u].z) + residual_sq(v[u].w));
+#pragma unroll
+            for (int o = G / 2; o > 0; o >>= 1) {
+                t += __shfl_xor(t, o);
+                e += __shfl_xor(e, o);
+            }
+            const int r = r0 + u * R + sub;
+            if (r < I) {
+                unsigned char *row = pack + (size_t)r * RB;
+                *reinterpret_cast<uint2 *>(row + 8 * q) = make_uint2(pack_bf16(v[u].x, v[u].y), pack_bf16(v[u].z, v[u].w));
+                if (q == 0)
+                    *reinterpret_cast<uint4 *>(row + 8 * G) = bound_chunk(bound_factor(t), bound_factor(e));
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_item_pack(const float *__restrict__ It, int I, int d, unsigned char *__restrict__ pack)
+{
+    const int lane = lane_id();
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+    if (d == 64) {
+        pack_rows_pow2<16>(It, I, wave, n_waves, lane, pack);
+    } else if (d == 128) {
+        pack_rows_pow2<32>(It, I, wave, n_waves, lane, pack);
+    } else {      // any other width: a wave per row, two elements per lane
+        const int KS = d <= 64 ? 4 : 8, RB = 32 * KS + 16;
+        for (int r = wave; r < I; r += n_waves) {
+            const float *__restrict__ p = It + (size_t)r * d;
+            unsigned char *row = pack + (size_t)r * RB;
+            float s = 0.0f, e = 0.0f;
+            for (int k = lane; k < 16 * KS; k += kWave) {
+                const float x = k < d ? p[k] : 0.0f;
+                if (k < d) {
+                    s += floored_sq(x);
+                    e += residual_sq(x);
+                }
+                reinterpret_cast<unsigned short *>(row)[k] = (unsigned short)(pack_bf16(x, 0.0f) & 0xffffu);
+            }
+            s = wave_sum_f(s);
+            e = wave_sum_f(e);
+            if (lane == 0)
+                *reinterpret_cast<uint4 *>(row + 32 * KS) = bound_chunk(bound_factor(s), bound_factor(e));
+        }
+    }
+}
+
 // ---- user factors {n_u, r_u}: one wave per user (catalogues too large for k_tau, which writes them itself) ------------------
 __global__ __launch_bounds__(256) void k_user_bound(const float *__restrict__ U, const int64_t *__restrict__ user_ids, int B, int d,
                                                     float *__restrict__ ubound)
@@ -125,11 +198,11 @@ __global__ __launch_bounds__(256) void k_user_bound(const float *__restrict__ U,
 struct PreArgs {
     const float *__restrict__ U;
     const int64_t *__restrict__ user_ids;
-    const float *__restrict__ It;
+    const unsigned char *__restrict__ ipack;   // [I][RB] packed item rows (k_item_pack)
+    size_t pack_bytes;
     const float *__restrict__ tau;      // tau of user b at tau[b * tau_stride]
     int tau_stride;
     const float *__restrict__ ubound;   // [B][2] {n_u, r_u}  (k_tau / k_user_bound)
-    const float *__restrict__ inorm;    // [I][2] {n_i, r_i}  (k_item_norms)
     unsigned *__restrict__ mask;    // [B padded to 256][2][Wh] pass bits: word (user, h, unit), register t of the unit on bit 31 - t
     int Wh;
     int B, I, d, items_per_split;
@@ -140,7 +213,9 @@ struct PreArgs {
 // (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5), so a lane's 16 results belong to one user and its threshold is one register.
 // Output: one pass bit per (user, item), a 32-bit word per lane and 64-item unit (no branch, no append in the loop: with
 // lane-private logs the loop spent ~2000 issue cycles per unit on compare-and-branch and appends against 256 cycles of MFMA).
-// A stage's rows are requested one whole stage ahead; d <= 64 walks 256-item stages.
+// A stage's rows are requested one whole stage ahead, as the contiguous bytes of the item pack; d <= 64 walks 256-item stages.
+// (Stages converted from the fp32 table inside the loop: 33 / 180 us at 2048 / 16 384 users, d = 64; from the pack 28 / 145;
+// d = 128: 57 / 343 -> 45 / 300.)
 template <int KS, bool FULLK, int ST, int WAVES, bool WIDE>
 __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
 {
@@ -148,10 +223,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
     constexpr int UT = WAVES * 32;
     constexpr int DQ = 4 * KS;                 // float4 pieces per source row
     constexpr int RB = 32 * KS + 16;           // LDS row stride in bytes: bf16 row + 16 (conflict-free ds_read_b128 of a column slice)
-    constexpr int N = (ST * DQ) / T;           // float4 pieces per thread per item stage
+    constexpr int NP = (ST * RB / 16 + T - 1) / T;   // 16-byte pieces of a packed item stage per thread (the last round reaches
+    constexpr int SB = NP * T * 16;                  // past the stage: the buffers are SB bytes apart and the tail is never read)
     constexpr int NU = (kStage * DQ) / T;      // ... per 64-user piece of the user tile
     static_assert(ST % kStage == 0 && 2 * ST >= UT && (kStage * DQ) % T == 0, "the user tile passes through the stage buffers");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * ST * RB];
+    static_assert(SB >= ST * RB && 2 * SB >= UT * RB, "stage buffers (the user tile passes through both)");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * SB];
     const int lane = lane_id();
     const int w = threadIdx.x >> 6;
     const int r32 = lane & 31;
@@ -195,32 +272,30 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
         }
     };
 
-    // the item rows' factors of the bound travel with the stage: [r_i, n_i + r_i, n_i] rounded up to bf16 in the first three
-    // elements of the row's 16-byte pad chunk, zeros behind.  One load per thread (thread t < ST owns row t of the stage; the
-    // others repeat a row and store nothing)
-    static_assert(ST <= T, "one norm per thread");
-    auto load_norm = [&](int row0, int n_rows) {
-        return *reinterpret_cast<const float2 *>(a.inorm + 2 * (size_t)min(row0 + min((int)threadIdx.x, ST - 1), n_rows - 1));
+    // an item stage: ST RB contiguous bytes of the pack (the rows already bf16, the factors of the bound -- [r_i, n_i + r_i, n_i]
+    // rounded up to bf16 -- in each row's 16-byte pad chunk), copied piece for piece.  Every load unconditional: pieces past the
+    // stage are the next rows (or, at the end of the table, its last 16 bytes) and land in the buffer's unread tail.
+    auto load_stage = [&](u32x4 (&v)[NP], int row0) {
+        const size_t base = (size_t)row0 * RB + (size_t)threadIdx.x * 16;
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+            v[i] = *reinterpret_cast<const u32x4 *>(a.ipack + min(base + (size_t)i * T * 16, a.pack_bytes - 16));
     };
-    auto store_norm = [&](unsigned char *dst, float2 nn) {
-        if (threadIdx.x < ST)
-            *reinterpret_cast<uint4 *>(dst + threadIdx.x * RB + 32 * KS) =
-                make_uint4(bf16_up_bits(nn.y) | (bf16_up_bits((nn.x + nn.y) * (1.0f + 0x1p-20f)) << 16), bf16_up_bits(nn.x), 0u, 0u);
+    auto store_stage = [&](unsigned char *dst, const u32x4 (&v)[NP]) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+            *reinterpret_cast<u32x4 *>(dst + (i * T + threadIdx.x) * 16) = v[i];
     };
 
     const int user = u0 + w * 32 + r32;
     const bool user_ok = user < a.B;
-    float4 nxt[N];
-    float2 nxt_n = make_float2(0.0f, 0.0f);
+    u32x4 nxt[NP];
     {   // the whole user tile and the first item stage are requested together: one round trip for the ids, one for the rows
         float4 v[UT / kStage][NU];
 #pragma unroll
         for (int piece = 0; piece < UT / kStage; ++piece)
             load(v[piece], a.U, a.user_ids, u0 + piece * kStage, a.B);
-        if (i_beg < i_end) {
-            load(nxt, a.It, nullptr, i_beg, i_end);
-            nxt_n = load_norm(i_beg, i_end);
-        }
+        load_stage(nxt, min(i_beg, a.I - 1));
 #pragma unroll
         for (int piece = 0; piece < UT / kStage; ++piece)
             store(smem + piece * kStage * RB, v[piece]);
@@ -241,15 +316,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
     __syncthreads();
     if (i_beg >= i_end)
         return;
-    store(smem, nxt);
-    store_norm(smem, nxt_n);
+    store_stage(smem, nxt);
     __syncthreads();
     // tau has arrived before the loop: a first use inside it makes hipcc's wait-count pass put s_waitcnt vmcnt(0) in front of
     // EVERY test (the loop-carried state merges the pending tau load with the stage prefetch), which serialises the prefetch
     asm volatile("" ::"v"(tau), "v"(bfx));
     int buf = 0;
     // (Requesting the rows TWO stages ahead, with a second register set, was measured: no change -- 33.2 vs 32.4 us at d = 64,
-    // 56.1 vs 55.4 at d = 128.)
+    // 56.1 vs 55.4 at d = 128.  The stage registers are a native vector type: as an array of HIP's uint4 structs the compiler
+    // kept them in scratch memory and waited for every load right behind its issue -- 46 us instead of 28.)
     // one 64-item unit: c0/c1 <- its accumulators; the pass bits of the PREVIOUS unit (q0/q1, a full unit: only the last unit
     // of the catalogue can be partial, and the last unit of a split is drained after the loop) are formed between the MFMAs --
     // a compare into vcc and an add-with-carry per register (bits = 2 bits + pass, register t on bit 31 - t), ~6 of them in the
@@ -258,28 +333,38 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
     // vector instructions 37 %, and they did not overlap (203 us).
     // The words of a stage's units are adjacent in the (user, row half) row.  WIDE: they leave as ONE store per lane and stage
     // (16 bytes at d <= 64, 8 at d <= 128) -- the host then makes the splits multiples of the stage, so the stores are aligned
-    // (dword-aligned 16-byte stores work, at 35 -> 50 us for the launch).  16 384 users x 50 000 items: 208 -> 181 us.  A
-    // 2048-user call has too few workgroups to give up four of its 32 splits for that (35.5 -> 39 us): it keeps one 4-byte
-    // store per unit.
+    // (dword-aligned 16-byte stores work, at 35 -> 50 us for the launch).  16 384 users x 50 000 items: 208 -> 181 us; with the
+    // row halves padded to 16-byte multiples (Wh % 4 == 0: before, every second half sat on an 8-byte boundary) and the words of
+    // the stage in registers instead of a dynamically indexed (= scratch) struct, 168 -> 145 us.  A 2048-user call has too few
+    // workgroups to give up four of its 32 splits for that (35.5 -> 39 us): it keeps one 4-byte store per unit.
     constexpr int UPS = ST / kStage;          // units (= words) per stage
     struct __attribute__((packed, aligned(4))) Words { unsigned v[UPS]; };
-    Words wb;
+    unsigned wv[UPS];              // (every index a constant after unrolling: a dynamically indexed copy lives in scratch memory)
 #pragma unroll
     for (int i = 0; i < UPS; ++i)
-        wb.v[i] = 0u;
+        wv[i] = 0u;
+    auto store_words = [&](unsigned *dst) {
+        Words t;
+#pragma unroll
+        for (int i = 0; i < UPS; ++i)
+            t.v[i] = wv[i];
+        *reinterpret_cast<Words *>(dst) = t;
+    };
     auto flush_words = [&](int t) {                        // the split ended on unit t: the words of its unfinished stage
         const int k = ((t - i_beg) >> 6) % UPS;
         if (k != UPS - 1) {
-            for (int i = 0; i <= k; ++i)
-                mrow[(t >> 6) - k + i] = wb.v[i];
+#pragma unroll
+            for (int i = 0; i < UPS - 1; ++i)
+                if (i <= k)
+                    mrow[(t >> 6) - k + i] = wv[i];
         } else {
-            *reinterpret_cast<Words *>(mrow + ((t >> 6) - (UPS - 1))) = wb;
+            store_words(mrow + ((t >> 6) - (UPS - 1)));
         }
     };
     auto unit = [&](auto prev_tag, int t0, int un, f32x16 &c0, f32x16 &c1, const f32x16 &q0, const f32x16 &q1, int t_prev) {
         constexpr bool PREV = decltype(prev_tag)::value;
         constexpr int STEPS = KS + 1;                  // k-steps incl. the bound's
-        const unsigned char *pi = smem + ((buf * ST + un * kStage) + r32) * RB;
+        const unsigned char *pi = smem + buf * SB + (un * kStage + r32) * RB;
         unsigned bits = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r)
@@ -310,7 +395,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
         }
         if constexpr (PREV) {
             if constexpr (WIDE)
-                wb.v[(un + UPS - 1) % UPS] = user_ok ? bits : 0u;     // (un is a constant of the unrolled stage loop)
+                wv[(un + UPS - 1) % UPS] = user_ok ? bits : 0u;     // (un is a constant of the unrolled stage loop)
             else
                 mrow[t_prev >> 6] = user_ok ? bits : 0u;
         }
@@ -326,7 +411,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
         for (int r = 0; r < 16; ++r)
             bits = (bits << 1) | ((32 + (r & 3) + 8 * (r >> 2) + 4 * h < lim && !(q1[r] <= tau)) ? 1u : 0u);
         if constexpr (WIDE) {
-            wb.v[((t_prev - i_beg) >> 6) % UPS] = user_ok ? bits : 0u;
+            const int kk = ((t_prev - i_beg) >> 6) % UPS;
+#pragma unroll
+            for (int i = 0; i < UPS; ++i)
+                wv[i] = i == kk ? (user_ok ? bits : 0u) : wv[i];
             flush_words(t_prev);
         } else {
             mrow[t_prev >> 6] = user_ok ? bits : 0u;
@@ -344,8 +432,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
     // previous stage's words to store -- is its own instance of the body.
     auto stage = [&](auto first_tag, int s0) {
         constexpr bool FIRST = decltype(first_tag)::value;
-        load(nxt, a.It, nullptr, s0 + ST, i_end);
-        nxt_n = load_norm(s0 + ST, i_end);
+        load_stage(nxt, s0 + ST);
 #pragma unroll
         for (int un = 0; un < UPS; un += 2) {
             const int t0 = s0 + un * kStage;     // first item of this 64-item unit
@@ -356,15 +443,14 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
             else
                 unit(Yes{}, t0, un, A0, A1, B0, B1, t0 - kStage);
             if (WIDE && !FIRST && un == 0)     // the previous stage's words are complete: one store per lane
-                *reinterpret_cast<Words *>(mrow + (t0 >> 6) - UPS) = wb;
+                store_words(mrow + (t0 >> 6) - UPS);
             t_last = t0, last_is_a = true;
             if (t0 + kStage >= i_end)
                 break;
             unit(Yes{}, t0 + kStage, un + 1, B0, B1, A0, A1, t0);
             t_last = t0 + kStage, last_is_a = false;
         }
-        store(smem + (buf ^ 1) * ST * RB, nxt);
-        store_norm(smem + (buf ^ 1) * ST * RB, nxt_n);
+        store_stage(smem + (buf ^ 1) * SB, nxt);
         __syncthreads();
         buf ^= 1;
     };
@@ -395,7 +481,7 @@ struct RescoreArgs {
     const float *__restrict__ tau;
     int tau_stride;
     const unsigned *__restrict__ mask;
-    int Wh;
+    int Wh, n_units;                 // words per row half (a multiple of 4), of which the first n_units = ceil(I / 64) are written
     float2 *__restrict__ lists;     // [B][list_cap]
     int *__restrict__ totals;       // [B]
     int B, d, list_cap;
@@ -444,6 +530,13 @@ __global__ __launch_bounds__(256) void k_rescore(const RescoreArgs a)
 #pragma unroll
             for (int i = 0; i < kChunkWords; ++i)
                 word[i] = j0 + i < n_words ? mrow[j0 + i] : 0u;
+        }
+        if (a.Wh != a.n_units) {      // the row halves are padded to 16-byte multiples: nothing ever wrote the pad words
+#pragma unroll
+            for (int i = 0; i < kChunkWords; ++i) {
+                const int j = j0 + i;
+                word[i] = (j >= a.Wh ? j - a.Wh : j) < a.n_units ? word[i] : 0u;
+            }
         }
         int mine = 0;
 #pragma unroll
@@ -571,6 +664,8 @@ __global__ __launch_bounds__(256) void k_rescore(const RescoreArgs a)
 
 }  // namespace
 
+bool prefilter_supports(int d) { return d <= 128; }
+
 int launch_item_norms(const float *It, int I, int d, float *norms, hipStream_t s)
 {
     hipLaunchKernelGGL(k_item_norms, dim3(min(1024, (I + 63) / 64)), dim3(256), 0, s, It, I, d, norms);
@@ -583,13 +678,19 @@ int launch_user_bound(const float *U, const int64_t *user_ids, int B, int d, flo
     return check_launch("k_user_bound");
 }
 
-bool prefilter_supports(int d) { return d <= 128; }
+size_t item_pack_bytes(int I, int d) { return prefilter_supports(d) ? (size_t)I * (d <= 64 ? 144 : 272) : 0; }
 
-int launch_prefilter(const float *U, const int64_t *user_ids, int B, const float *It, int I, int d, const float *tau, int tau_stride,
-                     const float *ubound, const float *inorm, unsigned *mask, int Wh, int S, int items_per_split, bool wide,
-                     hipStream_t s)
+int launch_item_pack(const float *It, int I, int d, void *pack, hipStream_t s)
 {
-    PreArgs a{U, user_ids, It, tau, tau_stride, ubound, inorm, mask, Wh, B, I, d, items_per_split};
+    hipLaunchKernelGGL(k_item_pack, dim3(min(1024, (I + 63) / 64)), dim3(256), 0, s, It, I, d, static_cast<unsigned char *>(pack));
+    return check_launch("k_item_pack");
+}
+
+int launch_prefilter(const float *U, const int64_t *user_ids, int B, const void *ipack, int I, int d, const float *tau, int tau_stride,
+                     const float *ubound, unsigned *mask, int Wh, int S, int items_per_split, bool wide, hipStream_t s)
+{
+    PreArgs a{U, user_ids, static_cast<const unsigned char *>(ipack), item_pack_bytes(I, d), tau, tau_stride, ubound, mask, Wh, B, I, d,
+              items_per_split};
     constexpr int UT = kPreWaves * 32;
     const dim3 grid((B + UT - 1) / UT, S), block(kPreWaves * 64);
     wide = wide && items_per_split % 256 == 0;         // (a stage's words as one aligned store: the splits must be stage multiples)
@@ -613,9 +714,9 @@ int launch_prefilter(const float *U, const int64_t *user_ids, int B, const float
 }
 
 int launch_rescore(const float *U, const int64_t *user_ids, int B, const float *It, int d, const float *tau, int tau_stride,
-                   const unsigned *mask, int Wh, void *lists, int *totals, int list_cap, hipStream_t s)
+                   const unsigned *mask, int Wh, int n_units, void *lists, int *totals, int list_cap, hipStream_t s)
 {
-    RescoreArgs a{U, user_ids, It, tau, tau_stride, mask, Wh, static_cast<float2 *>(lists), totals, B, d, list_cap};
+    RescoreArgs a{U, user_ids, It, tau, tau_stride, mask, Wh, n_units, static_cast<float2 *>(lists), totals, B, d, list_cap};
     if ((d & 3) == 0)
         hipLaunchKernelGGL(k_rescore<true>, dim3((B + 3) / 4), dim3(256), 0, s, a);
     else

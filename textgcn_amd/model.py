@@ -494,7 +494,7 @@ class LightGCN(nn.Module):
         # candidates from the bf16 pass, scores and order from the fp32 chains: the same lists bit for bit (scoring.score_topk);
         # the item-side factor of its error bound is computed once for the whole predict call
         prefilter = bool(getattr(self, 'score_prefilter', True)) and not custom
-        item_norm = scoring.item_norms(items_emb) if prefilter and len(users) else None
+        item_pack = scoring.item_pack(items_emb) if prefilter and len(users) else None
         for n, j in enumerate(range(0, len(users), step)):
             batch = users[j:j + step]
             ids = torch.from_numpy(batch).to(self.device)
@@ -509,7 +509,7 @@ class LightGCN(nn.Module):
                     v, i = scoring.topk(rating, kmax, round4=True)       # base_model.py:261-263
                 else:        # base_model.py:254-263 in one fused pass: gather + GEMM + mask + top-k + round
                     v, i = scoring.score_topk(users_emb, items_emb, kmax, user_ids=ids, mask_rowptr=rp, mask_items=it,
-                                              round4=True, slot=slot, prefilter=prefilter, item_norm=item_norm)
+                                              round4=True, slot=slot, prefilter=prefilter, item_pack=item_pack)
             for t in (ids, rp, it, v, i):
                 t.record_stream(side)
             y_val.append(v)

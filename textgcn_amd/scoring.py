@@ -113,9 +113,25 @@ def fallback_count(dev, b, n_items, d, k, slot=0):
     return out.value
 
 
+def item_pack(items_emb):
+    """The item operand of the prefilter's bf16 pass (tgcn_item_pack_bf16): per row its bf16 image and the row's factors of the
+    error bound, as a uint8 tensor.  Pack once per item table and hand it to score_topk(prefilter=True, item_pack=...).
+    None for widths the bf16 pass does not take (score_topk then runs the fp32 path)."""
+    dev = _dev(items_emb)
+    _f32c(items_emb, 'items_emb')
+    n_items, d = items_emb.shape
+    need = _capi.lib().tgcn_item_pack_bytes(n_items, d)
+    if need <= 0:
+        return None
+    out = torch.empty(need, dtype=torch.uint8, device=dev)
+    rc = _capi.lib().tgcn_item_pack_bf16(_capi.ptr(items_emb), n_items, d, _capi.ptr(out), _capi.current_stream(dev))
+    _capi.check(rc, 'tgcn_item_pack_bf16')
+    return out
+
+
 def item_norms(items_emb):
     """[I, 2] floats: the item factors (row norm, norm of the row's bf16 rounding residual) of the prefilter's error bound
-    (tgcn_item_norms_f32).  Compute them once per item table and hand them to score_topk(prefilter=True, item_norm=...)."""
+    (tgcn_item_norms_f32; diagnostic -- the pack carries them, rounded up to bf16)."""
     dev = _dev(items_emb)
     _f32c(items_emb, 'items_emb')
     out = torch.empty((items_emb.shape[0], 2), dtype=torch.float32, device=dev)
@@ -126,12 +142,12 @@ def item_norms(items_emb):
 
 
 def score_topk(users_emb, items_emb, k, user_ids=None, mask_rowptr=None, mask_items=None, round4=False, slot=0, prefilter=False,
-               item_norm=None):
+               item_pack=None):
     """Fused predict step: top-k over all items of the masked scores (tgcn_score_topk_f32).  Same result as
     score_dense -> mask_train -> topk, without the [B, I] matrix.  mask_* is a CSR over the batch rows.
     `slot` selects the scratch buffer: use distinct slots for calls issued on different streams.
     `prefilter`: find the candidates with the bf16 pass and rescore them in fp32 (tgcn_score_topk_prefilter_f32) -- the same
-    result bit for bit; `item_norm` = item_norms(items_emb) when the table is shared by many calls."""
+    result bit for bit; `item_pack` = item_pack(items_emb) when the table is shared by many calls."""
     dev = _dev(users_emb)
     _f32c(users_emb, 'users_emb'), _f32c(items_emb, 'items_emb')
     if users_emb.shape[1] != items_emb.shape[1]:
@@ -161,7 +177,7 @@ def score_topk(users_emb, items_emb, k, user_ids=None, mask_rowptr=None, mask_it
             kk = min(MAX_K_PER_PASS, k - k0)
             v, i = score_topk(users_emb, items_emb, kk, user_ids, rowptr.to(torch.int32),
                               (keys % n_items).to(torch.int32) if keys.numel() else torch.zeros(1, dtype=torch.int32, device=dev),
-                              round4, slot, prefilter, item_norm)
+                              round4, slot, prefilter, item_pack)
             vals.append(v), idxs.append(i)
             keys = torch.sort(torch.cat([keys, (rows[:, None] * n_items + i).reshape(-1)]))[0]
             rowptr = rowptr + kk * torch.arange(b + 1, device=dev, dtype=torch.int64)
@@ -172,12 +188,12 @@ def score_topk(users_emb, items_emb, k, user_ids=None, mask_rowptr=None, mask_it
     need = lib.tgcn_score_topk_workspace_bytes(b, n_items, d, int(k))
     ws = _workspace(dev, max(need, 256), slot)
     if prefilter:
-        if item_norm is not None and (item_norm.dtype != torch.float32 or item_norm.numel() != 2 * n_items or item_norm.device != dev
-                                      or not item_norm.is_contiguous()):
-            raise TypeError('item_norm must be the [I, 2] float32 tensor of item_norms(items_emb) on the same device')
+        if item_pack is not None and (item_pack.dtype != torch.uint8 or item_pack.numel() != lib.tgcn_item_pack_bytes(n_items, d)
+                                      or item_pack.device != dev or not item_pack.is_contiguous()):
+            raise TypeError('item_pack must be the uint8 tensor of item_pack(items_emb) on the same device')
         rc = lib.tgcn_score_topk_prefilter_f32(_capi.ptr(users_emb), _capi.ptr(user_ids), b, _capi.ptr(items_emb), n_items, d,
                                                _capi.ptr(mask_rowptr), _capi.ptr(mask_items), int(k), 1 if round4 else 0,
-                                               _capi.ptr(item_norm), _capi.ptr(val), _capi.ptr(idx), _capi.ptr(ws), ws.numel(),
+                                               _capi.ptr(item_pack), _capi.ptr(val), _capi.ptr(idx), _capi.ptr(ws), ws.numel(),
                                                _capi.current_stream(dev))
         _capi.check(rc, 'tgcn_score_topk_prefilter_f32')
         return val, idx

@@ -14,7 +14,7 @@ b = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
 g = torch.Generator().manual_seed(0)
 ue = (torch.randn(b, d, generator=g) * 0.1).to(dev)
 ie = (torch.randn(50000, d, generator=g) * 0.1).to(dev)
-norm = scoring.item_norms(ie)
+pack = scoring.item_pack(ie)
 for _ in range(3):
-    scoring.score_topk(ue, ie, 40, prefilter=True, item_norm=norm)
+    scoring.score_topk(ue, ie, 40, prefilter=True, item_pack=pack)
 torch.cuda.synchronize()

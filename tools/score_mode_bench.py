@@ -48,9 +48,9 @@ def main():
             rp = np.zeros(b + 1, dtype=np.int32)
             np.cumsum([len(r) for r in rows], out=rp[1:])
             batches.append((ids, torch.from_numpy(rp).to(dev), torch.from_numpy(np.concatenate(rows)).to(dev)))
-        norm = scoring.item_norms(ie)
-        modes = {'fp32': dict(prefilter=False), 'prefilter': dict(prefilter=True, item_norm=None),
-                 'prefilter+norm': dict(prefilter=True, item_norm=norm)}
+        pack = scoring.item_pack(ie)
+        modes = {'fp32': dict(prefilter=False), 'prefilter': dict(prefilter=True, item_pack=None),
+                 'prefilter+pack': dict(prefilter=True, item_pack=pack)}
         ref = None
         for mode, kw in modes.items():
             for n_streams in [int(x) for x in args.streams.split(',')]:
