@@ -78,6 +78,8 @@ def test_c_abi_rejects_bad_arguments_with_message(built_lib):
     rc = lib.tgcn_score_topk_prefilter_f32(None, None, 4, None, 100, 64, None, None, 10, 0, None, None, None, None, 0, None)
     assert rc == -1
     assert lib.tgcn_score_topk_prefilter_f32(None, None, 0, None, 100, 64, None, None, 10, 0, None, None, None, None, 0, None) == 0
+    rc = lib.tgcn_score_topk_prefilter_f32(8, None, 4, 8, 100, 64, None, None, 10, 0, 24, 8, 8, None, 0, None)
+    assert rc == -1 and b'item_pack' in lib.tgcn_last_error()
     assert lib.tgcn_item_pack_bytes(50000, 64) == 50000 * 144 and lib.tgcn_item_pack_bytes(60000, 128) == 60000 * 272
     assert lib.tgcn_item_pack_bytes(100, 50) == 100 * 144 and lib.tgcn_item_pack_bytes(100, 960) == 0 and lib.tgcn_item_pack_bytes(-1, 64) < 0
     rc = lib.tgcn_item_pack_bf16(None, 10, 64, None, None)

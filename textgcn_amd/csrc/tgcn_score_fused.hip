@@ -1132,6 +1132,7 @@ int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const fl
     TGCN_REQUIRE(U && It && out_val && out_idx, "NULL pointer");
     TGCN_REQUIRE(!mask_rowptr || mask_items, "mask_rowptr without mask_items");
     TGCN_REQUIRE(B <= 65535 * kUsersPerWG, "B too large for one launch");
+    TGCN_REQUIRE(((size_t)item_pack & 15) == 0, "item_pack must be 16-byte aligned");
     const Plan p = make_plan(B, I, d, k);
     TGCN_REQUIRE(workspace && workspace_bytes >= (int64_t)p.total, "workspace too small (tgcn_score_topk_workspace_bytes)");
     TGCN_REQUIRE(((size_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
