@@ -112,6 +112,8 @@ int launch_score_dense_filter(const float *U, const int64_t *user_ids, int B, co
 // tgcn_score_prefilter.hip: candidates from a bf16 pass, rescored in fp32
 bool prefilter_supports(int d);
 int launch_item_norms(const float *It, int I, int d, float *norms /* [I][2] */, hipStream_t stream);
+int launch_sample_bf16(const float *U, const int64_t *user_ids, int B, const float *It, int m, int d, int stride, float *S, int64_t ld,
+                       hipStream_t stream);      // d <= 128
 int launch_user_bound(const float *U, const int64_t *user_ids, int B, int d, float *ubound /* [B][2] */, hipStream_t stream);
 size_t item_pack_bytes(int I, int d);      // 0: no bf16 candidate pass for this width
 int launch_item_pack(const float *It, int I, int d, void *pack, hipStream_t stream);

@@ -1166,7 +1166,9 @@ int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const fl
     int *flagged = reinterpret_cast<int *>(ws + p.off_flags);
     int *done = reinterpret_cast<int *>(ws + p.off_done);
     int *totals = prefilter ? reinterpret_cast<int *>(ws + p.off_totals) : nullptr;
-    if ((rc = launch_score_dense(U, user_ids, B, It, p.m, d, kSampleStride, Ss, p.m_ld, s)) != TGCN_OK)
+    // (the sample is only ranked -- tau is a bar, never a result: up to d = 128 it comes from the bf16 pipe in both entry points)
+    if ((rc = prefilter_supports(d) ? launch_sample_bf16(U, user_ids, B, It, p.m, d, kSampleStride, Ss, p.m_ld, s)
+                        : launch_score_dense(U, user_ids, B, It, p.m, d, kSampleStride, Ss, p.m_ld, s)) != TGCN_OK)
         return rc;
     const float *tau_ptr;
     int tau_stride;

@@ -463,6 +463,102 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
         drain(B0, B1, t_last);
 }
 
+// ---- the threshold sample on the bf16 pipe ----------------------------------------------------------------------------------
+// S[b][j] ~ <U[b], It[j * stride]> for the m sampled items, operands rounded to bf16, fp32 accumulation: k_tau only RANKS these
+// scores (tau is a bar for the candidate search, never a result: a tau that comes out too high sends the user to the exact
+// fallback, one that comes out low costs candidates), so the sample does not need the fp32 chain.  Users on MFMA rows here
+// (A operand), items on columns: accumulator register t of lane l holds (user (t & 3) + 8 (t >> 2) + 4 (l >> 5), item l & 31),
+// so one store instruction writes 128 contiguous bytes of two user rows.  One workgroup = 256 users x 128 sampled items, no
+// loop: 16 384 users x 1563 samples took 61 us as an fp32 GEMM (k_score_dense on every 32nd item row).
+struct SampleArgs {
+    const float *__restrict__ U;
+    const int64_t *__restrict__ user_ids;
+    const float *__restrict__ It;
+    float *__restrict__ S;
+    int64_t ld;
+    int B, m, d, stride;
+};
+
+template <int KS, bool FULLK>
+__global__ __launch_bounds__(512) void k_sample_bf16(const SampleArgs a)
+{
+    constexpr int T = 512, UT = 256, SI = 128;     // threads, users and sampled items per workgroup
+    constexpr int DQ = 4 * KS, RB = 32 * KS + 16;
+    constexpr int NU = UT * DQ / T, NI = SI * DQ / T;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[(UT + SI) * RB];
+    const int lane = lane_id();
+    const int w = threadIdx.x >> 6;
+    const int r32 = lane & 31;
+    const int h = lane >> 5;
+    const int u0 = blockIdx.x * UT;
+    const int j0 = blockIdx.y * SI;
+    float4 vu[NU], vi[NI];
+    size_t ru[NU], ri[NI];
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+        const int r = min(u0 + (i * T + (int)threadIdx.x) / DQ, a.B - 1);
+        ru[i] = a.user_ids ? (size_t)a.user_ids[r] : (size_t)r;
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+        ri[i] = (size_t)min(j0 + (i * T + (int)threadIdx.x) / DQ, a.m - 1) * a.stride;
+    auto fetch = [&](const float *__restrict__ p, int k) {
+        if constexpr (FULLK)
+            return *reinterpret_cast<const float4 *>(p + k);
+        else
+            return make_float4(k + 0 < a.d ? p[k + 0] : 0.0f, k + 1 < a.d ? p[k + 1] : 0.0f, k + 2 < a.d ? p[k + 2] : 0.0f,
+                               k + 3 < a.d ? p[k + 3] : 0.0f);
+    };
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+        vi[i] = fetch(a.It + ri[i] * a.d, ((i * T + (int)threadIdx.x) % DQ) * 4);
+#pragma unroll
+    for (int i = 0; i < NU; ++i)
+        vu[i] = fetch(a.U + ru[i] * a.d, ((i * T + (int)threadIdx.x) % DQ) * 4);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int f = i * T + threadIdx.x;
+        *reinterpret_cast<uint2 *>(smem + (UT + f / DQ) * RB + (f % DQ) * 8) = make_uint2(pack_bf16(vi[i].x, vi[i].y), pack_bf16(vi[i].z, vi[i].w));
+    }
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+        const int f = i * T + threadIdx.x;
+        *reinterpret_cast<uint2 *>(smem + (f / DQ) * RB + (f % DQ) * 8) = make_uint2(pack_bf16(vu[i].x, vu[i].y), pack_bf16(vu[i].z, vu[i].w));
+    }
+    __syncthreads();
+    bf16x8 fu[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+        fu[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(smem + (w * 32 + r32) * RB + 32 * s + 16 * h));
+#pragma unroll
+    for (int un = 0; un < SI / 64; ++un) {
+        f32x16 c0, c1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            c0[r] = 0.0f, c1[r] = 0.0f;
+        const unsigned char *pi = smem + (UT + un * 64 + r32) * RB;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const bf16x8 f0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pi + 32 * s + 16 * h));
+            const bf16x8 f1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pi + 32 * RB + 32 * s + 16 * h));
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fu[s], f0, c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fu[s], f1, c1, 0, 0, 0);
+        }
+        const int j = j0 + un * 64 + r32;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int user = u0 + w * 32 + (t & 3) + 8 * (t >> 2) + 4 * h;
+            if (user < a.B) {
+                float *__restrict__ row = a.S + (size_t)user * a.ld;
+                if (j < a.m)
+                    row[j] = c0[t];
+                if (j + 32 < a.m)
+                    row[j + 32] = c1[t];
+            }
+        }
+    }
+}
+
 // ---- candidates from the pass bits, fp32 scores, compact lists -----------------------------------------------------------
 // One WAVE per user, no workgroup-level synchronisation.  (1) the user's 2 Wh mask words are read 32 per lane at a time (all
 // loads of a chunk in flight together), counted, scanned once per chunk, and the set bits become item ids in LDS (more than
@@ -670,6 +766,22 @@ int launch_item_norms(const float *It, int I, int d, float *norms, hipStream_t s
 {
     hipLaunchKernelGGL(k_item_norms, dim3(min(1024, (I + 63) / 64)), dim3(256), 0, s, It, I, d, norms);
     return check_launch("k_item_norms");
+}
+
+int launch_sample_bf16(const float *U, const int64_t *user_ids, int B, const float *It, int m, int d, int stride, float *S, int64_t ld,
+                       hipStream_t s)
+{
+    SampleArgs a{U, user_ids, It, S, ld, B, m, d, stride};
+    const dim3 grid((B + 255) / 256, (m + 127) / 128), block(512);
+    if (d == 64)
+        hipLaunchKernelGGL((k_sample_bf16<4, true>), grid, block, 0, s, a);
+    else if (d < 64)
+        hipLaunchKernelGGL((k_sample_bf16<4, false>), grid, block, 0, s, a);
+    else if (d == 128)
+        hipLaunchKernelGGL((k_sample_bf16<8, true>), grid, block, 0, s, a);
+    else
+        hipLaunchKernelGGL((k_sample_bf16<8, false>), grid, block, 0, s, a);
+    return check_launch("k_sample_bf16");
 }
 
 int launch_user_bound(const float *U, const int64_t *user_ids, int B, int d, float *ubound, hipStream_t s)
