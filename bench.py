@@ -446,7 +446,14 @@ def records_c3_c5(dev, want_c5=True, cpu=True):
     with torch.no_grad():
         ltr.embedding_user.weight.copy_(e0[:n_u])
         ltr.embedding_item.weight.copy_(e0[n_u:])
+    ltr.score_prefilter = False   # the record's own numbers: fp32 MFMA filter (as for c3); the bf16-candidate path beside them
     t_ltr = _timed(lambda: ltr.predict_tensors(users), 1) - t_fwd
+    v_f, i_f = ltr.predict_tensors(users)
+    ltr.score_prefilter = True    # the class default
+    v_p, i_p = ltr.predict_tensors(users)
+    same5 = bool(torch.equal(i_f, i_p) and torch.equal(v_f, v_p))
+    del v_f, i_f, v_p, i_p
+    t_ltr_pre = _timed(lambda: ltr.predict_tensors(users), 1) - t_fwd
     kf = d + 2 * t
     c5 = {'metric': 'scored user-item pairs/sec (ltr_linear: 5 text/embedding features + Linear(5,1) folded into one K=960 GEMM, '
                     'mask + top-40, full catalogue)', 'value': pairs / t_ltr, 'unit': 'pairs/s', 'n_gpus': 1, 'ms_total': t_ltr * 1e3,
@@ -455,7 +462,11 @@ def records_c3_c5(dev, want_c5=True, cpu=True):
                      'through': 'textgcn_amd.LTRLinear.predict_tensors'},
           'roofline': {'bound': 'mfma', 'achieved': round(2.0 * kf * pairs / t_ltr / 1e12, 2), 'peak': MFMA_F32_PEAK_TF,
                        'unit': 'TFLOP/s', 'frac': round(2.0 * kf * pairs / t_ltr / 1e12 / MFMA_F32_PEAK_TF, 4), 'traffic': None,
-                       'algorithmic_flops': 2.0 * kf * pairs}}
+                       'algorithmic_flops': 2.0 * kf * pairs},
+          'bf16_candidates': {'what': 'LTRLinear.score_prefilter = True (the class default): the folded K = 960 operands through '
+                                      'tgcn_score_topk_prefilter_f32 (k_score_prefilter_wide + fp32 chains)',
+                              'value': pairs / t_ltr_pre, 'unit': 'pairs/s', 'ms_total': t_ltr_pre * 1e3,
+                              'identical_to_fp32_path': same5}}
     if cpu:
         from oracle import torch_port
         nb = 256

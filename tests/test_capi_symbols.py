@@ -81,10 +81,10 @@ def test_c_abi_rejects_bad_arguments_with_message(built_lib):
     rc = lib.tgcn_score_topk_prefilter_f32(8, None, 4, 8, 100, 64, None, None, 10, 0, 24, 8, 8, None, 0, None)
     assert rc == -1 and b'item_pack' in lib.tgcn_last_error()
     assert lib.tgcn_item_pack_bytes(50000, 64) == 50000 * 144 and lib.tgcn_item_pack_bytes(60000, 128) == 60000 * 272
-    assert lib.tgcn_item_pack_bytes(100, 50) == 100 * 144 and lib.tgcn_item_pack_bytes(100, 960) == 0 and lib.tgcn_item_pack_bytes(-1, 64) < 0
+    assert lib.tgcn_item_pack_bytes(100, 50) == 100 * 144 and lib.tgcn_item_pack_bytes(100, 960) == 100 * (2 * 960 + 16) and lib.tgcn_item_pack_bytes(100, 2048) == 0 and lib.tgcn_item_pack_bytes(-1, 64) < 0
     rc = lib.tgcn_item_pack_bf16(None, 10, 64, None, None)
     assert rc == -1 and b'NULL' in lib.tgcn_last_error()
-    rc = lib.tgcn_item_pack_bf16(None, 10, 960, None, None)
+    rc = lib.tgcn_item_pack_bf16(None, 10, 2048, None, None)
     assert rc == -1 and b'width' in lib.tgcn_last_error()
     rc = lib.tgcn_item_norms_f32(None, 10, 64, None, None)
     assert rc == -1 and b'NULL' in lib.tgcn_last_error()

@@ -405,13 +405,13 @@ def test_item_pack(cuda):
     behind it, [r_i, n_i + r_i, n_i] each rounded UP to bf16 from the factors tgcn_item_norms_f32 reports"""
     from textgcn_amd import scoring
     rng = np.random.default_rng(4)
-    for n, d in ((50000, 64), (777, 128), (1000, 100), (333, 50), (5, 32), (3, 16)):
+    for n, d in ((50000, 64), (777, 128), (1000, 100), (333, 50), (5, 32), (3, 16), (300, 200), (300, 960), (300, 896), (100, 1000)):
         it = (rng.standard_normal((n, d)) * 0.3).astype(np.float32)
         if n > 100:
             it[11] = 0.0
             it[13] = 0.375
         t = torch.from_numpy(it).to(cuda)
-        width = 64 if d <= 64 else 128
+        width = 64 if d <= 64 else 128 if d <= 128 else 256 if d <= 256 else 512 if d <= 512 else 1024 if d <= 832 else 896 if d <= 896 else 960 if d <= 960 else 1024
         pack = scoring.item_pack(t).cpu().numpy().reshape(n, 2 * width + 16)
         rows = pack[:, :2 * width].copy().view(np.uint16)
         want = np.zeros((n, width), dtype=np.uint16)
@@ -423,7 +423,7 @@ def test_item_pack(cuda):
         norms = scoring.item_norms(t).cpu().numpy().astype(np.float64)
         for got, ref in ((f[:, 0], norms[:, 1]), (f[:, 1], norms[:, 0] + norms[:, 1]), (f[:, 2], norms[:, 0])):
             assert np.all(got >= ref) and np.all(got <= ref * (1 + 2.0 ** -7) * (1 + 2.0 ** -19))
-    assert scoring.item_pack(torch.zeros(10, 960, device=cuda)) is None
+    assert scoring.item_pack(torch.zeros(10, 2048, device=cuda)) is None and scoring.item_pack(torch.zeros(10, 132, device=cuda)) is None
 
 
 def test_prefilter_outlier_item_does_not_flood_the_lists(cuda):
@@ -439,6 +439,26 @@ def test_prefilter_outlier_item_does_not_flood_the_lists(cuda):
     ud, itd = torch.from_numpy(u).to(cuda), torch.from_numpy(it).to(cuda)
     scoring.score_topk(ud, itd, k, prefilter=True, slot=7)
     assert scoring.fallback_count(cuda, b, i, d, k, slot=7) <= 2
+
+
+def test_prefilter_wide_rows_identical(cuda):
+    """Rows wider than 128 (the folded ltr_linear operands and every pack width of k_score_prefilter_wide: 256, 512, 896, 960,
+    1024 elements; d % 8 == 0) -- both entry points bit for bit, ragged user tiles, partial last units, masks, ties, an outlier row;
+    widths the bf16 pass does not take (d % 8 != 0, d > 1024) run the fp32 path behind the same entry point."""
+    from textgcn_amd import scoring
+    rng = np.random.default_rng(77)
+    for trial, d in enumerate([136, 256, 264, 512, 520, 840, 896, 960, 1000, 1024, 204, 1032]):
+        b = int(rng.integers(1, 400))
+        i = int(rng.integers(8193, 14000))
+        k = int(rng.integers(1, 65))
+        u = (rng.standard_normal((b, d)) * 0.1).astype(np.float32)
+        it = (rng.standard_normal((i, d)) * 0.1 * np.exp(rng.normal(0, 1.0, size=(i, 1)))).astype(np.float32)
+        if trial % 3 == 1:
+            it[1::3] = it[0::3][: len(it[1::3])]
+        if trial % 4 == 2:
+            it[17] = -50.0
+        assert (scoring.item_pack(torch.from_numpy(it[:4]).to(cuda)) is None) == (d % 8 != 0 or d > 1024)
+        _fused_vs_dense(cuda, u, it, k, mask=_rand_mask(rng, b, i, 0, 60), round4=bool(trial % 2))
 
 
 @pytest.mark.parametrize('b,i,d', [(2048, 50000, 64), (2048, 60000, 128)])

@@ -1047,7 +1047,7 @@ Plan make_plan(int B, int I, int d, int k)
     o += align256(item_pack_bytes(I, d));                                  //     holds it: tgcn_item_pack_bf16)
     p.Wh = ((I + kStage - 1) / kStage + 3) & ~3;   // words per row half, padded: every half starts on a 16-byte boundary
     p.off_mask = o;
-    if (d <= 128)
+    if (prefilter_supports(d))
         o += align256((size_t)((B + 255) / 256) * 256 * 2 * p.Wh * sizeof(unsigned));   // rows of the bf16 filter's padded users
     p.off_logs = o, o += align256((size_t)B * p.S * 2 * p.cap2 * sizeof(float2));
     p.off_counts = o, o += align256((size_t)B * p.S * 2 * sizeof(int));
@@ -1115,7 +1115,7 @@ extern "C" int64_t tgcn_score_topk_workspace_bytes(int32_t B, int32_t I, int32_t
 }
 
 namespace {
-// prefilter: candidates from the bf16 pass of tgcn_score_prefilter.hip, rescored in fp32 (same results; d <= 128, d % 4 == 0,
+// prefilter: candidates from the bf16 pass of tgcn_score_prefilter.hip, rescored in fp32 (same results; d <= 128, or d <= 1024 with d % 8 == 0;
 // otherwise the fp32 filter runs).  item_pack: device pointer to the packed item operand (tgcn_item_pack_bf16), or NULL: packed by
 // this call.
 int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const float *It, int32_t I, int32_t d,
@@ -1167,7 +1167,7 @@ int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const fl
     int *done = reinterpret_cast<int *>(ws + p.off_done);
     int *totals = prefilter ? reinterpret_cast<int *>(ws + p.off_totals) : nullptr;
     // (the sample is only ranked -- tau is a bar, never a result: up to d = 128 it comes from the bf16 pipe in both entry points)
-    if ((rc = prefilter_supports(d) ? launch_sample_bf16(U, user_ids, B, It, p.m, d, kSampleStride, Ss, p.m_ld, s)
+    if ((rc = d <= 128 ? launch_sample_bf16(U, user_ids, B, It, p.m, d, kSampleStride, Ss, p.m_ld, s)
                         : launch_score_dense(U, user_ids, B, It, p.m, d, kSampleStride, Ss, p.m_ld, s)) != TGCN_OK)
         return rc;
     const float *tau_ptr;
@@ -1211,7 +1211,11 @@ int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const fl
         // 16 384 users 208 -> 181 us); a 2048-user call keeps its 32 splits (28 would cost it 35.5 -> 39 us).
         const bool wide = B > 4096;
         int ips_pre = p.items_per_split;
-        if (d > 64 && I <= (1 << 18))
+        if (d > 128) {       // wide rows: ~1024 workgroups of 128 users, each long enough to amortise its 128 x d user tile
+            const int tiles = (B + 127) / 128;
+            const int S_w = max(1, min(1024 / tiles, I / 512));
+            ips_pre = (((I + S_w - 1) / S_w + kStage - 1) / kStage) * kStage;
+        } else if (d > 64 && I <= (1 << 18))
             ips_pre = 1024;      // (768 / 1280 / 2048 with the packed operand: 54 / 53 / 56 us against 46)
         else if (wide)
             ips_pre = ((p.items_per_split + 255) / 256) * 256;

@@ -108,6 +108,13 @@ __global__ __launch_bounds__(256) void k_item_norms(const float *__restrict__ It
 // behind -- RB = 32 KS + 16 bytes, KS = 4 (d <= 64) or 8 (d <= 128).  A stage of the filter is then ST RB CONTIGUOUS bytes: 16-byte
 // loads straight into 16-byte LDS stores, half the bytes of the fp32 rows and no conversion in the loop (the filter took 35 us
 // with the fp32 rows converted per stage, 26 with the staging removed altogether -- profiles/r02_experiments.md).
+// 16-wide k-steps of a packed row: 4 (d <= 64), 8 (d <= 128), then the widths the wide filter is built for
+// (wide rows: the instantiated widths of k_score_prefilter_wide -- 256, 512, 896, 960, 1024 elements)
+__host__ __device__ __forceinline__ int pack_ksteps(int d)
+{
+    return d <= 64 ? 4 : d <= 128 ? 8 : d <= 256 ? 16 : d <= 512 ? 32 : d <= 832 ? 64 : d <= 896 ? 56 : d <= 960 ? 60 : 64;
+}
+
 __device__ __forceinline__ uint4 bound_chunk(float n, float r)
 {
     return make_uint4(bf16_up_bits(r) | (bf16_up_bits((n + r) * (1.0f + 0x1p-20f)) << 16), bf16_up_bits(n), 0u, 0u);
@@ -152,8 +159,8 @@ __global__ __launch_bounds__(256) void k_item_pack(const float *__restrict__ It,
         pack_rows_pow2<16>(It, I, wave, n_waves, lane, pack);
     } else if (d == 128) {
         pack_rows_pow2<32>(It, I, wave, n_waves, lane, pack);
-    } else {      // any other width: a wave per row, two elements per lane
-        const int KS = d <= 64 ? 4 : 8, RB = 32 * KS + 16;
+    } else {      // any other width: a wave per row
+        const int KS = pack_ksteps(d), RB = 32 * KS + 16;
         for (int r = wave; r < I; r += n_waves) {
             const float *__restrict__ p = It + (size_t)r * d;
             unsigned char *row = pack + (size_t)r * RB;
@@ -463,6 +470,142 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
         drain(B0, B1, t_last);
 }
 
+// ---- the bf16 filter for wide rows (128 < d <= 1024, d % 8 == 0: the folded ltr_linear operands, K = 896 / 960) -----------
+// Same test, same pass bits, same pack (rows of 32 KS + 16 bytes).  The users' fragments stay in registers for the whole launch
+// (32 users per wave, 4 KS registers per lane: one wave per SIMD with the 512-register budget), the items pass through LDS in
+// stages of 64 rows x 256 elements (the K chunks of a 64-item unit follow each other, the accumulators persist across them), and
+// the bound's k-step and the tests follow the unit's last chunk -- 32 tests against 2 KS + 2 MFMAs, so nothing is deferred here.
+template <int KS>
+__global__ __launch_bounds__(256) void k_score_prefilter_wide(const PreArgs a)
+{
+    constexpr int T = 256, UT = 128;
+    constexpr int RBG = 32 * KS + 16;          // pack row
+    constexpr int CK = 16;                     // k-steps per LDS stage
+    constexpr int NCH = (KS + CK - 1) / CK;
+    constexpr int RBL = 32 * CK + 16;          // LDS row: 512 bytes of the chunk + 16 (conflict-free ds_read_b128 down a column slice)
+    constexpr int NP = kStage * 32 * CK / 16 / T;      // 16-byte pieces of a stage per thread (8)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2][kStage * RBL];
+    __shared__ __attribute__((aligned(16))) uint4 sfac[2][kStage];          // the rows' factor chunks (bound step), per unit
+    const int lane = lane_id();
+    const int w = threadIdx.x >> 6;
+    const int r32 = lane & 31;
+    const int h = lane >> 5;
+    const int u0 = blockIdx.x * UT;
+    const int i_beg = blockIdx.y * a.items_per_split;
+    const int i_end = min(a.I, i_beg + a.items_per_split);
+    if (i_beg >= i_end)
+        return;
+    const int user = u0 + w * 32 + r32;
+    const bool user_ok = user < a.B;
+
+    // stage (unit t0, chunk ch): piece p of thread = row p / 32, 16-byte column p % 32 of the chunk; every load unconditional
+    // (addresses past the pack clamp to its last 16 bytes; columns past the row belong to k-steps that do not exist)
+    auto load_stage = [&](u32x4 (&v)[NP], u32x4 &fac, int t0, int ch) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int pc = i * T + threadIdx.x;
+            const size_t off = (size_t)(t0 + pc / 32) * RBG + (size_t)ch * (32 * CK) + (size_t)(pc % 32) * 16;
+            v[i] = *reinterpret_cast<const u32x4 *>(a.ipack + min(off, a.pack_bytes - 16));
+        }
+        const size_t foff = (size_t)(t0 + min((int)threadIdx.x, kStage - 1)) * RBG + 32 * KS;
+        fac = *reinterpret_cast<const u32x4 *>(a.ipack + min(foff, a.pack_bytes - 16));
+    };
+    auto store_stage = [&](int buf, const u32x4 (&v)[NP], const u32x4 &fac, int fac_buf /* < 0: not a unit's first chunk */) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int pc = i * T + threadIdx.x;
+            *reinterpret_cast<u32x4 *>(smem[buf] + (pc / 32) * RBL + (pc % 32) * 16) = v[i];
+        }
+        if (fac_buf >= 0 && threadIdx.x < kStage)
+            *reinterpret_cast<u32x4 *>(&sfac[fac_buf][threadIdx.x]) = fac;
+    };
+    u32x4 nxt[NP], nfac;
+    load_stage(nxt, nfac, i_beg, 0);
+
+    // the users' fragments: k-step s of lane (r32, h) = elements 16 s + 8 h .. + 7 of user r32's row, straight from global memory
+    bf16x8 bfr[KS];
+    {
+        const float *__restrict__ urow = a.U + (size_t)(a.user_ids ? a.user_ids[min(user, a.B - 1)] : (int64_t)min(user, a.B - 1)) * a.d;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int k0 = 16 * s + 8 * h;
+            const float4 x = *reinterpret_cast<const float4 *>(urow + min(k0, a.d - 8));
+            const float4 y = *reinterpret_cast<const float4 *>(urow + min(k0, a.d - 8) + 4);
+            const bool in = k0 < a.d && user_ok;
+            bfr[s] = __builtin_bit_cast(bf16x8, make_uint4(in ? pack_bf16(x.x, x.y) : 0u, in ? pack_bf16(x.z, x.w) : 0u,
+                                                          in ? pack_bf16(y.x, y.y) : 0u, in ? pack_bf16(y.z, y.w) : 0u));
+            if (s % 8 == 7)
+                __builtin_amdgcn_sched_barrier(0);     // (eight steps' loads in flight, not all of them: they would not fit)
+        }
+    }
+    const float tau = user_ok ? a.tau[(size_t)user * a.tau_stride] : INFINITY;
+    const float2 ub = user_ok ? *reinterpret_cast<const float2 *>(a.ubound + 2 * (size_t)user) : make_float2(0.0f, 0.0f);
+    const bf16x8 bfx = __builtin_bit_cast(bf16x8, h == 0 ? make_uint4(bf16_up_bits(ub.x) | (bf16_up_bits(ub.y) << 16),
+                                                                       bf16_up_bits(ub.x * kAccumBudget), 0u, 0u)
+                                                         : make_uint4(0u, 0u, 0u, 0u));
+    unsigned *__restrict__ mrow = a.mask + ((size_t)user * 2 + h) * a.Wh;
+    store_stage(0, nxt, nfac, 0);
+    __syncthreads();
+    asm volatile("" ::"v"(tau), "v"(bfx));
+    int buf = 0, fbuf = 0;          // unit n reads its factor chunks from sfac[n & 1]
+    for (int t0 = i_beg; t0 < i_end; t0 += kStage) {
+        f32x16 c0, c1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            c0[r] = 0.0f, c1[r] = 0.0f;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            // request the next stage: the unit's next chunk, or the first chunk of the next unit (past the split: a copy nobody reads)
+            if (ch + 1 < NCH)
+                load_stage(nxt, nfac, t0, ch + 1);
+            else
+                load_stage(nxt, nfac, t0 + kStage, 0);
+            const unsigned char *pi = smem[buf] + r32 * RBL + 16 * h;
+            // fragments two k-steps ahead of their MFMAs, and no further (scheduling barriers): left to itself the compiler hoists
+            // the whole chunk's LDS reads and spills the users' fragments
+            const int NS = KS - ch * CK < CK ? KS - ch * CK : CK;      // k-steps of this chunk (a constant once unrolled)
+            bf16x8 f0[CK], f1[CK];
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                if (s < NS) {
+                    f0[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pi + 32 * s));
+                    f1[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pi + 32 * RBL + 32 * s));
+                }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < CK; ++s)
+                if (s < NS) {
+                    if (s + 2 < NS) {
+                        f0[s + 2] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pi + 32 * (s + 2)));
+                        f1[s + 2] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pi + 32 * RBL + 32 * (s + 2)));
+                    }
+                    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0[s], bfr[ch * CK + s], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1[s], bfr[ch * CK + s], c1, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            if (ch == NCH - 1) {     // the bound's k-step (both halves read the row's factor chunk) and the tests
+                const bf16x8 g0 = __builtin_bit_cast(bf16x8, sfac[fbuf][r32]);
+                const bf16x8 g1 = __builtin_bit_cast(bf16x8, sfac[fbuf][32 + r32]);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, bfx, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1, bfx, c1, 0, 0, 0);
+            }
+            store_stage(buf ^ 1, nxt, nfac, ch + 1 < NCH ? -1 : (fbuf ^ 1));
+            __syncthreads();
+            buf ^= 1;
+        }
+        fbuf ^= 1;
+        const int lim = i_end - t0;
+        unsigned bits = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            bits = (bits << 1) | (((r & 3) + 8 * (r >> 2) + 4 * h < lim && !(c0[r] <= tau)) ? 1u : 0u);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            bits = (bits << 1) | ((32 + (r & 3) + 8 * (r >> 2) + 4 * h < lim && !(c1[r] <= tau)) ? 1u : 0u);
+        mrow[t0 >> 6] = user_ok ? bits : 0u;
+    }
+}
+
 // ---- the threshold sample on the bf16 pipe ----------------------------------------------------------------------------------
 // S[b][j] ~ <U[b], It[j * stride]> for the m sampled items, operands rounded to bf16, fp32 accumulation: k_tau only RANKS these
 // scores (tau is a bar for the candidate search, never a result: a tau that comes out too high sends the user to the exact
@@ -585,6 +728,7 @@ struct RescoreArgs {
 
 constexpr int kUserCap = 1536;      // candidates of a user held in LDS
 constexpr int kOverflow = 1 << 20;  // a total beyond any list: k_select hands the user to the fallback
+constexpr int kMaxPreD = 1024;      // widest row of the prefiltered path
 constexpr int kKB = 32;             // floats of a row per LDS tile
 constexpr int kTileRow = kKB + 1;   // padded: lane = row reads are conflict-free
 constexpr int kChunkWords = 32;     // mask words per lane per chunk
@@ -594,7 +738,7 @@ __global__ __launch_bounds__(256) void k_rescore(const RescoreArgs a)
 {
     __shared__ int ids_all[4][kUserCap];
     __shared__ float tiles[4][kWave * kTileRow];
-    __shared__ __attribute__((aligned(16))) float su_all[4][128];   // the user's row (d <= 128 on this path)
+    __shared__ __attribute__((aligned(16))) float su_all[4][kMaxPreD];   // the user's row
     const int lane = lane_id();
     const int w = threadIdx.x >> 6;
     const int b = blockIdx.x * 4 + w;
@@ -760,7 +904,7 @@ __global__ __launch_bounds__(256) void k_rescore(const RescoreArgs a)
 
 }  // namespace
 
-bool prefilter_supports(int d) { return d <= 128; }
+bool prefilter_supports(int d) { return d <= 128 || (d <= kMaxPreD && d % 8 == 0); }
 
 int launch_item_norms(const float *It, int I, int d, float *norms, hipStream_t s)
 {
@@ -790,7 +934,7 @@ int launch_user_bound(const float *U, const int64_t *user_ids, int B, int d, flo
     return check_launch("k_user_bound");
 }
 
-size_t item_pack_bytes(int I, int d) { return prefilter_supports(d) ? (size_t)I * (d <= 64 ? 144 : 272) : 0; }
+size_t item_pack_bytes(int I, int d) { return prefilter_supports(d) ? (size_t)I * (32 * pack_ksteps(d) + 16) : 0; }
 
 int launch_item_pack(const float *It, int I, int d, void *pack, hipStream_t s)
 {
@@ -803,6 +947,21 @@ int launch_prefilter(const float *U, const int64_t *user_ids, int B, const void 
 {
     PreArgs a{U, user_ids, static_cast<const unsigned char *>(ipack), item_pack_bytes(I, d), tau, tau_stride, ubound, mask, Wh, B, I, d,
               items_per_split};
+    if (d > 128) {       // wide rows: 128 users per workgroup, the users' fragments in registers
+        const dim3 grid((B + 127) / 128, S), block(256);
+        const int ks = pack_ksteps(d);
+        if (ks <= 16)
+            hipLaunchKernelGGL((k_score_prefilter_wide<16>), grid, block, 0, s, a);
+        else if (ks <= 32)
+            hipLaunchKernelGGL((k_score_prefilter_wide<32>), grid, block, 0, s, a);
+        else if (ks == 56)
+            hipLaunchKernelGGL((k_score_prefilter_wide<56>), grid, block, 0, s, a);
+        else if (ks == 60)
+            hipLaunchKernelGGL((k_score_prefilter_wide<60>), grid, block, 0, s, a);
+        else
+            hipLaunchKernelGGL((k_score_prefilter_wide<64>), grid, block, 0, s, a);
+        return check_launch("k_score_prefilter_wide");
+    }
     constexpr int UT = kPreWaves * 32;
     const dim3 grid((B + UT - 1) / UT, S), block(kPreWaves * 64);
     wide = wide && items_per_split % 256 == 0;         // (a stage's words as one aligned store: the splits must be stage multiples)

@@ -173,6 +173,9 @@ class LTRLinear(LightGCN):
         users_emb, items_emb = self.representation
         users_emb, items_emb = users_emb.contiguous(), items_emb.contiguous()
         ia = self._pack_items(items_emb)
+        # the folded operands are 896 / 960 wide: the bf16 candidate pass takes them too (same lists as the fp32 path, bit for bit)
+        prefilter = bool(self.score_prefilter) and len(users_np) > 0
+        pack = scoring.item_pack(ia) if prefilter else None
         y_val, y_idx = [], []
         main = torch.cuda.current_stream(self.device)
         streams = self._predict_streams()       # chunks round-robin on a few streams, as in LightGCN.predict_tensors
@@ -186,7 +189,8 @@ class LTRLinear(LightGCN):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 ua = self._fold_users(users_emb, ids, ids)
-                v, i = scoring.score_topk(ua, ia, kmax, mask_rowptr=rp, mask_items=it, round4=True, slot=slot)
+                v, i = scoring.score_topk(ua, ia, kmax, mask_rowptr=rp, mask_items=it, round4=True, slot=slot, prefilter=prefilter,
+                                          item_pack=pack)
             for t in (ids, rp, it, ua, v, i):
                 t.record_stream(side)
             y_val.append(v)

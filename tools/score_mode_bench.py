@@ -21,6 +21,8 @@ SHAPES = {   # users per call, calls, items, d
     'c3': (16384, 6, 60_000, 128),
     'c3small': (2048, 12, 60_000, 128),
     'c4': (2048, 6, 2_000_000, 64),
+    'c5': (8192, 4, 60_000, 960),          # the folded ltr_linear operands (K = 128 + 2 x 384 + bias column)
+    'c5small': (2048, 8, 60_000, 960),
 }
 
 
