@@ -162,16 +162,18 @@ int tgcn_score_topk_f32(const float *U, const int64_t *user_ids, int32_t B, cons
  * approx(u, i) + bound(u, i) > tau_u, with a proven bound on the bf16 error (tgcn_score_prefilter.hip), keeps a superset of
  * {i : score > tau_u}; every kept pair gets its k-ordered fp32 fmaf score and is dropped again unless score > tau_u.  Results
  * are bit-identical to tgcn_score_topk_f32 (indices, scores, tie order, fallback); only the cost of finding the candidates
- * changes.  Applies to d <= 128 and I > 8192; any other shape runs tgcn_score_topk_f32's own path.  Same workspace.
+ * changes.  Applies to I > 8192 and d <= 128, or d <= 1024 with d % 8 == 0 (the folded ltr_linear operands, K = 896 / 960);
+ * any other shape runs tgcn_score_topk_f32's own path.  Same workspace.
  * `item_pack`: device pointer to the packed item operand written by tgcn_item_pack_bf16 for this item table (the table is
  * fixed across the batches of a predict call), or NULL: packed inside the call, into the workspace. */
 int tgcn_score_topk_prefilter_f32(const float *U, const int64_t *user_ids, int32_t B, const float *It, int32_t I,
                                   int32_t d, const int32_t *mask_rowptr, const int32_t *mask_items, int32_t k,
                                   int32_t round4, const void *item_pack, float *out_val, int64_t *out_idx,
                                   void *workspace, int64_t workspace_bytes, tgcn_stream_t stream);
-/* The item operand of the bf16 pass: per item row its bf16 image (round-to-nearest-even, zero-padded to 64 or 128 elements)
+/* The item operand of the bf16 pass: per item row its bf16 image (round-to-nearest-even, zero-padded to the width the filter walks)
  * followed by the row's factors of the error bound, 144 (d <= 64) or 272 (d <= 128) bytes per row -- the exact bytes the filter
- * kernel stages, so a stage is one contiguous copy.  tgcn_item_pack_bytes: size of `out` (0: no bf16 pass for this width, the
+ * kernel stages, so a stage is one contiguous copy; wider rows (d % 8 == 0, d <= 1024) are padded to 256 / 512 / 896 / 960 / 1024
+ * elements: 2 x that + 16 bytes per row.  tgcn_item_pack_bytes: size of `out` (0: no bf16 pass for this width, the
  * prefilter entry then runs the fp32 path and ignores `item_pack`; < 0: bad argument).  `out` 16-byte aligned. */
 int64_t tgcn_item_pack_bytes(int32_t I, int32_t d);
 int tgcn_item_pack_bf16(const float *It, int32_t I, int32_t d, void *out, tgcn_stream_t stream);

@@ -354,7 +354,7 @@ def test_fused_topk_very_large_catalogue(cuda):
     _fused_vs_dense(cuda, u, it, k, mask=(rp, items))
 
 
-@pytest.mark.parametrize('d', [64, 128, 32])
+@pytest.mark.parametrize('d', [64, 128, 32, 960, 1024])
 def test_prefilter_bound_under_worst_case_rounding(cuda, d):
     """Data built against the bf16 bound: every element sits just below a bf16 rounding boundary with the signs aligned, so the
     approximate score of the planted winners is lower than their fp32 score by nearly the whole bound (2^-7 |u| |i|) while

@@ -119,6 +119,11 @@ size_t item_pack_bytes(int I, int d);      // 0: no bf16 candidate pass for this
 int launch_item_pack(const float *It, int I, int d, void *pack, hipStream_t stream);
 int launch_prefilter(const float *U, const int64_t *user_ids, int B, const void *ipack, int I, int d, const float *tau, int tau_stride,
                      const float *ubound, unsigned *mask, int Wh, int S, int items_per_split, bool wide, hipStream_t stream);
+int pack_row_bytes(int d);                 // bytes of a packed item row; its 16-byte factor chunk is the last one
+int launch_prefilter_wide(const float *U, const int64_t *user_ids, int B, const void *ipack, int I, int d, const float *tau, int tau_stride,
+                          const float *ubound, void *logs, int *counts, int S, int items_per_split, int cap2, hipStream_t stream);
+int launch_rescore_list(const float *U, const int64_t *user_ids, int B, const float *It, int d, const float *tau, int tau_stride,
+                        const int *surv, const int *surv_n, int surv_cap, void *lists, int *totals, int list_cap, hipStream_t stream);
 int launch_rescore(const float *U, const int64_t *user_ids, int B, const float *It, int d, const float *tau, int tau_stride,
                    const unsigned *mask, int Wh, int n_units, void *lists, int *totals, int list_cap, hipStream_t stream);
 int launch_topk(const float *S, int64_t lds, int B, int I, int k, int do_round, float *out_val, int64_t *out_idx,

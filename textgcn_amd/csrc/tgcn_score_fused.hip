@@ -705,6 +705,157 @@ __device__ __forceinline__ void select_core(const unsigned (&key)[VPL], const in
     out_i = i;
 }
 
+// ---- a second, tight threshold from the LOGGED approximate scores (wide rows: tgcn_score_prefilter.hip logs them) ----------
+// The wide bf16 filter leaves, per user, the pairs with approx + bound > tau_u and their raised scores R_i = approx_i + bound_i.
+// bound_i is recomputed here from the same bf16 factors, so L_i = R_i - 2 bound_i (less a rounding margin) <= score_i <= R_i.
+// tau2 = the k-th largest L_i among the user's unmasked candidates: at least k unmasked items score >= tau2, so an item with
+// R_i < tau2 has k items strictly above it and cannot be in the top k -- it is dropped WITHOUT an fp32 chain.  What survives
+// (the top k and whatever lies within the error band of the k-th score: ~70 of ~350 at K = 960) goes to k_rescore as an id list;
+// from there the path is the narrow rows' (scores > tau_u kept, k_select_flat, fallback).  Non-finite R or bound: survives,
+// never counted towards k.  One wave per user; train items are dropped here already.
+struct RefineArgs {
+    const float2 *__restrict__ logs;   // [B][2 S][cap2]
+    const int *__restrict__ counts;    // [B][2 S]
+    const int *__restrict__ mask_rowptr;
+    const int *__restrict__ mask_items;
+    const float *__restrict__ ubound;  // [B][2] {n_u, r_u}
+    const unsigned char *__restrict__ ipack;
+    int row_bytes;                     // packed item row; the factor chunk [r_i, n_i + r_i, n_i] (bf16) is its last 16 bytes
+    int *__restrict__ surv;            // [B][surv_cap]
+    int *__restrict__ surv_n;          // [B]; kRefineOverflow: the user takes the exact fallback
+    int surv_cap;
+    int B, S, cap2, k;
+};
+constexpr int kRefineOverflow = 1 << 20;
+constexpr int kRefineCap = 2048;      // logged candidates per user k_refine takes (more: exact fallback)
+
+__global__ __launch_bounds__(256) void k_refine(const RefineArgs a)
+{
+    __shared__ float2 scand[4][kRefineCap];
+    __shared__ int smask[4][kMaskCache];
+    const int lane = lane_id();
+    const int w = threadIdx.x >> 6;
+    const int b = uniform(blockIdx.x * 4 + w);
+    if (b >= a.B)
+        return;
+    int mb = 0, me = 0;
+    if (a.mask_rowptr) {
+        mb = a.mask_rowptr[b];
+        me = a.mask_rowptr[b + 1];
+    }
+    const bool cached = (me - mb) <= kMaskCache;
+    const int n_seg = a.S * 2;   // <= 64: one segment per lane
+    int cnt = lane < n_seg ? a.counts[(size_t)b * n_seg + lane] : 0;
+    bool overflow = __any(cnt > a.cap2);
+    cnt = min(cnt, a.cap2);
+    int off = cnt;
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const int t = __shfl_up(off, o);
+        if (lane >= o)
+            off += t;
+    }
+    const int n = __builtin_amdgcn_readlane(off, kWave - 1);
+    off -= cnt;
+    if (overflow || n > min(kRefineCap, a.surv_cap)) {
+        if (lane == 0)
+            a.surv_n[b] = kRefineOverflow;
+        return;
+    }
+    float2 *cand = scand[w];
+    {
+        const float2 *__restrict__ lg = a.logs + ((size_t)b * n_seg + min(lane, n_seg - 1)) * a.cap2;
+        int longest = cnt;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+            longest = max(longest, __shfl_xor(longest, o));
+        for (int j0 = 0; j0 < longest; j0 += 8) {
+            float2 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                t[u] = lg[min(j0 + u, a.cap2 - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (j0 + u < cnt)
+                    cand[off + j0 + u] = t[u];
+        }
+    }
+    if (cached)
+        for (int j = lane; j < me - mb; j += kWave)
+            smask[w][j] = a.mask_items[mb + j];
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    // the user's factors as the filter's bound step saw them (rounded up to bf16)
+    const float2 ub = *reinterpret_cast<const float2 *>(a.ubound + 2 * (size_t)b);
+    const float nu = __uint_as_float(bf16_up_bits(ub.x) << 16), ru = __uint_as_float(bf16_up_bits(ub.y) << 16);
+    const float nb = __uint_as_float(bf16_up_bits(ub.x * kAccumBudget) << 16);
+    auto run = [&](auto vpl_tag) {
+        constexpr int VPL = decltype(vpl_tag)::value;
+        unsigned keyL[VPL], keyR[VPL];
+        int idx[VPL];
+        bool live[VPL];
+        uint2 fac[VPL];
+#pragma unroll
+        for (int t = 0; t < VPL; ++t) {
+            const float2 c = cand[min(lane + kWave * t, n - 1)];
+            idx[t] = __float_as_int(c.y);
+            keyR[t] = __float_as_uint(c.x);      // (the raw score for now)
+            fac[t] = *reinterpret_cast<const uint2 *>(a.ipack + (size_t)idx[t] * a.row_bytes + (a.row_bytes - 16));
+        }
+        int n_valid = 0;
+#pragma unroll
+        for (int t = 0; t < VPL; ++t) {
+            live[t] = lane + kWave * t < n &&
+                      !(cached ? sorted_contains(smask[w], 0, me - mb, idx[t]) : sorted_contains(a.mask_items, mb, me, idx[t]));
+            const float R = __uint_as_float(keyR[t]);
+            const float ri = __uint_as_float(fac[t].x << 16), nri = __uint_as_float(fac[t].x & 0xFFFF0000u), ni = __uint_as_float(fac[t].y << 16);
+            const float bound = (nu * ri + ru * nri + nb * ni) * (1.0f + 0x1p-20f);
+            const float L = R - 2.0f * bound - 0x1p-21f * (fabsf(R) + bound);
+            const bool fin = fabsf(R) < INFINITY && bound < INFINITY;      // (false for NaN too)
+            keyL[t] = live[t] && fin ? ordered_key(L) : 0u;                 // 0: does not count towards k
+            keyR[t] = fin ? ordered_key(R) : 0xFFFFFFFFu;                   // non-finite: survives whatever tau2 is
+            n_valid += __popcll(__ballot(live[t] && fin));
+        }
+        // T = the k-th largest keyL (0 when fewer than k count: everything survives and the later stages decide)
+        unsigned T = 0;
+        if (n_valid >= a.k) {
+            for (int bit = 31; bit >= 0; --bit) {
+                const unsigned c = T | (1u << bit);
+                int cn = 0;
+#pragma unroll
+                for (int t = 0; t < VPL; ++t)
+                    cn += __popcll(__ballot(keyL[t] >= c));
+                if (cn >= a.k)
+                    T = c;
+            }
+        }
+        int base = 0;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        int *__restrict__ out = a.surv + (size_t)b * a.surv_cap;
+#pragma unroll
+        for (int t = 0; t < VPL; ++t) {
+            const bool take = live[t] && keyR[t] >= T;
+            const unsigned long long m = __ballot(take);
+            if (take)
+                out[base + __popcll(m & lt)] = idx[t];
+            base += __popcll(m);
+        }
+        if (lane == 0)
+            a.surv_n[b] = base;
+    };
+    if (n == 0) {
+        if (lane == 0)
+            a.surv_n[b] = 0;
+    } else if (n <= 4 * kWave)
+        run(std::integral_constant<int, 4>{});
+    else if (n <= 8 * kWave)
+        run(std::integral_constant<int, 8>{});
+    else if (n <= 16 * kWave)
+        run(std::integral_constant<int, 16>{});
+    else
+        run(std::integral_constant<int, kRefineCap / kWave>{});
+}
+
 __global__ __launch_bounds__(256) void k_select(const SelectArgs a)
 {
     __shared__ float2 scand[4][kSelCap];
@@ -1009,7 +1160,7 @@ struct Plan {
     int S, items_per_split, cap2, m, m_ld;  // m = sampled items
     int Wh;                                 // mask words per (user, row half): the 64-item units of the catalogue, padded to 4
     size_t off_mask;
-    size_t off_sample, off_tauv, off_taui, off_tau, off_ubound, off_ipack, off_logs, off_counts, off_parts, off_flags, off_done, off_totals, total;
+    size_t off_sample, off_tauv, off_taui, off_tau, off_ubound, off_ipack, off_logs, off_counts, off_parts, off_flags, off_done, off_totals, off_surv, off_surv_n, total;
     int flag_cap;
     bool small;
 };
@@ -1035,6 +1186,8 @@ Plan make_plan(int B, int I, int d, int k)
     p.items_per_split = (((I + S - 1) / S + gran - 1) / gran) * gran;
     p.S = (I + p.items_per_split - 1) / p.items_per_split;
     p.cap2 = max(32, 1024 / (2 * p.S));
+    if (d > 128 && prefilter_supports(d))
+        p.cap2 = max(p.cap2, 64);      // the wide bf16 filter logs its (more numerous) raised candidates in these segments
     p.m = (I + kSampleStride - 1) / kSampleStride;
     p.m_ld = (p.m + 3) & ~3;  // row stride of the sample score matrix (16-byte aligned rows)
     size_t o = 0;
@@ -1056,6 +1209,11 @@ Plan make_plan(int B, int I, int d, int k)
     p.off_flags = o, o += align256((size_t)(B + 1) * sizeof(int));
     p.off_done = o, o += align256((size_t)p.flag_cap * sizeof(int));   // contiguous with the flags: one memset covers both
     p.off_totals = o, o += align256((size_t)B * sizeof(int));          // ... and k_rescore's list lengths
+    p.off_surv = p.off_surv_n = o;                                     // wide rows: k_refine's surviving candidates
+    if (d > 128 && prefilter_supports(d)) {
+        o += align256((size_t)B * kRefineCap * sizeof(int));
+        p.off_surv_n = o, o += align256((size_t)B * sizeof(int));
+    }
     p.total = o;
     return p;
 }
@@ -1209,13 +1367,26 @@ int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const fl
         // Measured (rocprofv3): d = 128, 60 k items, 2048 users 68.6 -> 62.2 us with 1024-item splits.  d = 64: calls with
         // plenty of workgroups take splits of 256-item multiples (one aligned 16-byte store of mask words per lane and stage:
         // 16 384 users 208 -> 181 us); a 2048-user call keeps its 32 splits (28 would cost it 35.5 -> 39 us).
+        if (d > 128) {
+            // wide rows: the filter logs its candidates (k_select's segment layout: the plan's splits), k_refine keeps those that
+            // can still reach the top k, the fp32 chains run on what is left
+            int *surv = reinterpret_cast<int *>(ws + p.off_surv), *surv_n = reinterpret_cast<int *>(ws + p.off_surv_n);
+            if ((rc = launch_prefilter_wide(U, user_ids, B, ipack, I, d, tau_ptr, tau_stride, ubound, fa.logs, fa.counts, p.S,
+                                            p.items_per_split, p.cap2, s)) != TGCN_OK)
+                return rc;
+            RefineArgs ra{fa.logs, fa.counts, mask_rowptr, mask_items, ubound, static_cast<const unsigned char *>(ipack), pack_row_bytes(d),
+                          surv, surv_n, kRefineCap, B, p.S, p.cap2, k};
+            hipLaunchKernelGGL(k_refine, dim3((B + 3) / 4), dim3(256), 0, s, ra);
+            if ((rc = check_launch("k_refine")) != TGCN_OK)
+                return rc;
+            // (the flat lists of the kept pairs go where the filter's logs were: k_refine is done with them)
+            if ((rc = launch_rescore_list(U, user_ids, B, It, d, tau_ptr, tau_stride, surv, surv_n, kRefineCap, fa.logs, totals,
+                                          p.S * 2 * p.cap2, s)) != TGCN_OK)
+                return rc;
+        } else {
         const bool wide = B > 4096;
         int ips_pre = p.items_per_split;
-        if (d > 128) {       // wide rows: ~1024 workgroups of 128 users, each long enough to amortise its 128 x d user tile
-            const int tiles = (B + 127) / 128;
-            const int S_w = max(1, min(1024 / tiles, I / 512));
-            ips_pre = (((I + S_w - 1) / S_w + kStage - 1) / kStage) * kStage;
-        } else if (d > 64 && I <= (1 << 18))
+        if (d > 64 && I <= (1 << 18))
             ips_pre = 1024;      // (768 / 1280 / 2048 with the packed operand: 54 / 53 / 56 us against 46)
         else if (wide)
             ips_pre = ((p.items_per_split + 255) / 256) * 256;
@@ -1223,6 +1394,7 @@ int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const fl
                                    ips_pre, wide, s)) != TGCN_OK)
             return rc;
         rc = launch_rescore(U, user_ids, B, It, d, tau_ptr, tau_stride, mask, p.Wh, (I + kStage - 1) / kStage, fa.logs, totals, p.S * 2 * p.cap2, s);
+        }
     } else if (d <= 128) {
         const dim3 grid((B + kUsersPerWG - 1) / kUsersPerWG, p.S);
         if (d == 64 && B <= 4096)

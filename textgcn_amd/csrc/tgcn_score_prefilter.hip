@@ -11,8 +11,10 @@
 // The bound.  With a = bf16(x), b = bf16(y) (round-to-nearest-even, v_cvt_pk_bf16_f32) and the residuals r_x = x - a, r_y = y - b
 // (exact in fp32):   x.y - a.b = x.r_y + r_x.b,   so   |x.y - a.b| <= |x|_2 |r_y|_2 + |r_x|_2 (|y|_2 + |r_y|_2)    (Cauchy-Schwarz)
 // with the ACTUAL residual norms of the two rows (worst case 2^-8 of the row norm, ~0.4 of that on ordinary data).  The matrix
-// pipe's fp32 accumulation of the d <= 128 exact bf16 products and the fp32 chain's own rounding add at most 2^-11 |x|_2 |y|_2
-// between them (budgeted ~30x above d 2^-23 + d 2^-24).  So
+// pipe's fp32 accumulation of the d exact bf16 products and the fp32 chain's own rounding add at most 2^-11 |x|_2 |y|_2
+// between them: (d - 1) roundings of at most 2^-23 of the running |sum| (truncation assumed for the pipe) plus d roundings of 2^-24
+// in the chain, each sum bounded by |x|_2 |y|_2 -- d 2^-23 + d 2^-24 = 2^-12.4 at the widest row this path takes (d = 1024), ~30x
+// below the budget at d <= 128.  So
 //   score(u, i) > tau_u   ==>   approx(u, i) + n_u r_i + r_u (n_i + r_i) + 2^-11 n_u n_i > tau_u,
 // n = norm of the row (elements floored at 2^-50), r = norm of its residual (floored at 2^-58), each with a 2^-12 margin.  The
 // added terms are computed BY the matrix pipe: one more 16-wide k-step whose only non-zero operands are
@@ -475,9 +477,17 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
 // (32 users per wave, 4 KS registers per lane: one wave per SIMD with the 512-register budget), the items pass through LDS in
 // stages of 64 rows x 256 elements (the K chunks of a 64-item unit follow each other, the accumulators persist across them), and
 // the bound's k-step and the tests follow the unit's last chunk -- 32 tests against 2 KS + 2 MFMAs, so nothing is deferred here.
+struct PreWideArgs {
+    PreArgs p;                      // (mask / Wh unused here)
+    float2 *__restrict__ logs;      // [B][2 S][cap2] lane-private segments of (approx + bound, item), segment = split * 2 + row half
+    int *__restrict__ counts;       // [B][2 S] entries appended (may exceed cap2: the user then takes the exact fallback)
+    int S, cap2;
+};
+
 template <int KS>
-__global__ __launch_bounds__(256) void k_score_prefilter_wide(const PreArgs a)
+__global__ __launch_bounds__(256) void k_score_prefilter_wide(const PreWideArgs wa)
 {
+    const PreArgs &a = wa.p;
     constexpr int T = 256, UT = 128;
     constexpr int RBG = 32 * KS + 16;          // pack row
     constexpr int CK = 16;                     // k-steps per LDS stage
@@ -543,7 +553,12 @@ __global__ __launch_bounds__(256) void k_score_prefilter_wide(const PreArgs a)
     const bf16x8 bfx = __builtin_bit_cast(bf16x8, h == 0 ? make_uint4(bf16_up_bits(ub.x) | (bf16_up_bits(ub.y) << 16),
                                                                        bf16_up_bits(ub.x * kAccumBudget), 0u, 0u)
                                                          : make_uint4(0u, 0u, 0u, 0u));
-    unsigned *__restrict__ mrow = a.mask + ((size_t)user * 2 + h) * a.Wh;
+    // the lane's own segment of the user's candidate log: unlike the narrow kernels this one LOGS the raised approximate score
+    // of every pair that passes (~0.5 per lane and unit against 2 KS + 2 MFMAs): k_refine turns them into a second, far tighter
+    // threshold before any fp32 chain runs
+    const size_t seg = ((size_t)min(user, a.B - 1) * (2 * wa.S) + (size_t)blockIdx.y * 2 + h);
+    float2 *__restrict__ lg = wa.logs + seg * wa.cap2;
+    int n_log = 0;
     store_stage(0, nxt, nfac, 0);
     __syncthreads();
     asm volatile("" ::"v"(tau), "v"(bfx));
@@ -594,16 +609,20 @@ __global__ __launch_bounds__(256) void k_score_prefilter_wide(const PreArgs a)
             buf ^= 1;
         }
         fbuf ^= 1;
-        const int lim = i_end - t0;
-        unsigned bits = 0;
+        const int lim = user_ok ? i_end - t0 : 0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            bits = (bits << 1) | (((r & 3) + 8 * (r >> 2) + 4 * h < lim && !(c0[r] <= tau)) ? 1u : 0u);
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            bits = (bits << 1) | ((32 + (r & 3) + 8 * (r >> 2) + 4 * h < lim && !(c1[r] <= tau)) ? 1u : 0u);
-        mrow[t0 >> 6] = user_ok ? bits : 0u;
+        for (int r = 0; r < 32; ++r) {
+            const int row = 32 * (r >> 4) + (r & 3) + 8 * ((r & 15) >> 2) + 4 * h;
+            const float v = r < 16 ? c0[r & 15] : c1[r & 15];
+            if (row < lim && !(v <= tau)) {
+                if (n_log < wa.cap2)
+                    lg[n_log] = make_float2(v, __int_as_float(t0 + row));
+                ++n_log;
+            }
+        }
     }
+    if (user_ok)
+        wa.counts[seg] = n_log;
 }
 
 // ---- the threshold sample on the bf16 pipe ----------------------------------------------------------------------------------
@@ -721,6 +740,9 @@ struct RescoreArgs {
     int tau_stride;
     const unsigned *__restrict__ mask;
     int Wh, n_units;                 // words per row half (a multiple of 4), of which the first n_units = ceil(I / 64) are written
+    const int *__restrict__ surv;    // FROM_LIST: [B][surv_cap] candidate ids of k_refine, surv_n[b] of them (instead of the mask)
+    const int *__restrict__ surv_n;
+    int surv_cap;
     float2 *__restrict__ lists;     // [B][list_cap]
     int *__restrict__ totals;       // [B]
     int B, d, list_cap;
@@ -733,7 +755,7 @@ constexpr int kKB = 32;             // floats of a row per LDS tile
 constexpr int kTileRow = kKB + 1;   // padded: lane = row reads are conflict-free
 constexpr int kChunkWords = 32;     // mask words per lane per chunk
 
-template <bool ALIGNED4>     // rows are multiples of 16 bytes (d % 4 == 0): one float4 per (row, piece), else four scalars
+template <bool ALIGNED4, bool FROM_LIST>     // rows are multiples of 16 bytes (d % 4 == 0): one float4 per (row, piece), else four scalars
 __global__ __launch_bounds__(256) void k_rescore(const RescoreArgs a)
 {
     __shared__ int ids_all[4][kUserCap];
@@ -757,7 +779,17 @@ __global__ __launch_bounds__(256) void k_rescore(const RescoreArgs a)
     const int n_words = 2 * a.Wh;
     // (1) extract: lane l of a chunk owns words l * 32 .. l * 32 + 31 (contiguous: 128-byte reads per lane)
     int n = 0;
-    for (int c0 = 0; c0 < n_words; c0 += kWave * kChunkWords) {
+    if constexpr (FROM_LIST) {
+        n = a.surv_n[b];
+        if (n > kUserCap) {
+            if (lane == 0)
+                a.totals[b] = kOverflow;
+            return;
+        }
+        for (int j = lane; j < n; j += kWave)
+            ids[j] = a.surv[(size_t)b * a.surv_cap + j];
+    }
+    for (int c0 = 0; !FROM_LIST && c0 < n_words; c0 += kWave * kChunkWords) {
         unsigned word[kChunkWords];
         const int j0 = c0 + lane * kChunkWords;
         if (j0 + kChunkWords <= n_words && ((size_t)mrow & 15) == 0 && (n_words & 3) == 0) {
@@ -947,21 +979,6 @@ int launch_prefilter(const float *U, const int64_t *user_ids, int B, const void 
 {
     PreArgs a{U, user_ids, static_cast<const unsigned char *>(ipack), item_pack_bytes(I, d), tau, tau_stride, ubound, mask, Wh, B, I, d,
               items_per_split};
-    if (d > 128) {       // wide rows: 128 users per workgroup, the users' fragments in registers
-        const dim3 grid((B + 127) / 128, S), block(256);
-        const int ks = pack_ksteps(d);
-        if (ks <= 16)
-            hipLaunchKernelGGL((k_score_prefilter_wide<16>), grid, block, 0, s, a);
-        else if (ks <= 32)
-            hipLaunchKernelGGL((k_score_prefilter_wide<32>), grid, block, 0, s, a);
-        else if (ks == 56)
-            hipLaunchKernelGGL((k_score_prefilter_wide<56>), grid, block, 0, s, a);
-        else if (ks == 60)
-            hipLaunchKernelGGL((k_score_prefilter_wide<60>), grid, block, 0, s, a);
-        else
-            hipLaunchKernelGGL((k_score_prefilter_wide<64>), grid, block, 0, s, a);
-        return check_launch("k_score_prefilter_wide");
-    }
     constexpr int UT = kPreWaves * 32;
     const dim3 grid((B + UT - 1) / UT, S), block(kPreWaves * 64);
     wide = wide && items_per_split % 256 == 0;         // (a stage's words as one aligned store: the splits must be stage multiples)
@@ -984,15 +1001,49 @@ int launch_prefilter(const float *U, const int64_t *user_ids, int B, const void 
     return check_launch("k_score_prefilter");
 }
 
+int pack_row_bytes(int d) { return 32 * pack_ksteps(d) + 16; }
+
+int launch_prefilter_wide(const float *U, const int64_t *user_ids, int B, const void *ipack, int I, int d, const float *tau, int tau_stride,
+                          const float *ubound, void *logs, int *counts, int S, int items_per_split, int cap2, hipStream_t s)
+{
+    PreWideArgs a{PreArgs{U, user_ids, static_cast<const unsigned char *>(ipack), item_pack_bytes(I, d), tau, tau_stride, ubound, nullptr, 0, B,
+                          I, d, items_per_split},
+                  static_cast<float2 *>(logs), counts, S, cap2};
+    const dim3 grid((B + 127) / 128, S), block(256);      // 128 users per workgroup, the users' fragments in registers
+    const int ks = pack_ksteps(d);
+    if (ks <= 16)
+        hipLaunchKernelGGL((k_score_prefilter_wide<16>), grid, block, 0, s, a);
+    else if (ks <= 32)
+        hipLaunchKernelGGL((k_score_prefilter_wide<32>), grid, block, 0, s, a);
+    else if (ks == 56)
+        hipLaunchKernelGGL((k_score_prefilter_wide<56>), grid, block, 0, s, a);
+    else if (ks == 60)
+        hipLaunchKernelGGL((k_score_prefilter_wide<60>), grid, block, 0, s, a);
+    else
+        hipLaunchKernelGGL((k_score_prefilter_wide<64>), grid, block, 0, s, a);
+    return check_launch("k_score_prefilter_wide");
+}
+
 int launch_rescore(const float *U, const int64_t *user_ids, int B, const float *It, int d, const float *tau, int tau_stride,
                    const unsigned *mask, int Wh, int n_units, void *lists, int *totals, int list_cap, hipStream_t s)
 {
-    RescoreArgs a{U, user_ids, It, tau, tau_stride, mask, Wh, n_units, static_cast<float2 *>(lists), totals, B, d, list_cap};
+    RescoreArgs a{U, user_ids, It, tau, tau_stride, mask, Wh, n_units, nullptr, nullptr, 0, static_cast<float2 *>(lists), totals, B, d,
+                  list_cap};
     if ((d & 3) == 0)
-        hipLaunchKernelGGL(k_rescore<true>, dim3((B + 3) / 4), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((k_rescore<true, false>), dim3((B + 3) / 4), dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL(k_rescore<false>, dim3((B + 3) / 4), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((k_rescore<false, false>), dim3((B + 3) / 4), dim3(256), 0, s, a);
     return check_launch("k_rescore");
+}
+
+// the same from k_refine's id lists (wide rows; d % 8 == 0 there)
+int launch_rescore_list(const float *U, const int64_t *user_ids, int B, const float *It, int d, const float *tau, int tau_stride,
+                        const int *surv, const int *surv_n, int surv_cap, void *lists, int *totals, int list_cap, hipStream_t s)
+{
+    RescoreArgs a{U, user_ids, It, tau, tau_stride, nullptr, 0, 0, surv, surv_n, surv_cap, static_cast<float2 *>(lists), totals, B, d,
+                  list_cap};
+    hipLaunchKernelGGL((k_rescore<true, true>), dim3((B + 3) / 4), dim3(256), 0, s, a);
+    return check_launch("k_rescore(list)");
 }
 
 }  // namespace tgcn
