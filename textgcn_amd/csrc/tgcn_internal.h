@@ -122,6 +122,8 @@ int launch_prefilter(const float *U, const int64_t *user_ids, int B, const void 
 int pack_row_bytes(int d);                 // bytes of a packed item row; its 16-byte factor chunk is the last one
 int launch_prefilter_wide(const float *U, const int64_t *user_ids, int B, const void *ipack, int I, int d, const float *tau, int tau_stride,
                           const float *ubound, void *logs, int *counts, int S, int items_per_split, int cap2, hipStream_t stream);
+int launch_sample_wide(const float *U, const int64_t *user_ids, int B, const void *ipack, int I, int m, int d, int stride, float *S,
+                       int64_t ld, hipStream_t stream);
 int launch_rescore_list(const float *U, const int64_t *user_ids, int B, const float *It, int d, const float *tau, int tau_stride,
                         const int *surv, const int *surv_n, int surv_cap, void *lists, int *totals, int list_cap, hipStream_t stream);
 int launch_rescore(const float *U, const int64_t *user_ids, int B, const float *It, int d, const float *tau, int tau_stride,

@@ -1325,8 +1325,9 @@ int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const fl
     int *done = reinterpret_cast<int *>(ws + p.off_done);
     int *totals = prefilter ? reinterpret_cast<int *>(ws + p.off_totals) : nullptr;
     // (the sample is only ranked -- tau is a bar, never a result: up to d = 128 it comes from the bf16 pipe in both entry points)
-    if ((rc = d <= 128 ? launch_sample_bf16(U, user_ids, B, It, p.m, d, kSampleStride, Ss, p.m_ld, s)
-                        : launch_score_dense(U, user_ids, B, It, p.m, d, kSampleStride, Ss, p.m_ld, s)) != TGCN_OK)
+    if ((rc = d <= 128    ? launch_sample_bf16(U, user_ids, B, It, p.m, d, kSampleStride, Ss, p.m_ld, s)
+              : prefilter ? launch_sample_wide(U, user_ids, B, ipack, I, p.m, d, kSampleStride, Ss, p.m_ld, s)      // (from the pack)
+                          : launch_score_dense(U, user_ids, B, It, p.m, d, kSampleStride, Ss, p.m_ld, s)) != TGCN_OK)
         return rc;
     const float *tau_ptr;
     int tau_stride;

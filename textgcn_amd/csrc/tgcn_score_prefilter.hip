@@ -482,9 +482,14 @@ struct PreWideArgs {
     float2 *__restrict__ logs;      // [B][2 S][cap2] lane-private segments of (approx + bound, item), segment = split * 2 + row half
     int *__restrict__ counts;       // [B][2 S] entries appended (may exceed cap2: the user then takes the exact fallback)
     int S, cap2;
+    // SAMPLE form: "item" t is row t * row_stride of the pack, the plain approximate scores go to sample[user * sample_ld + t]
+    // (the threshold sample k_tau ranks: as an fp32 GEMM over the strided rows it cost a fifth of the whole filter)
+    int row_stride;
+    float *__restrict__ sample;
+    int64_t sample_ld;
 };
 
-template <int KS>
+template <int KS, bool SAMPLE>
 __global__ __launch_bounds__(256) void k_score_prefilter_wide(const PreWideArgs wa)
 {
     const PreArgs &a = wa.p;
@@ -514,10 +519,10 @@ __global__ __launch_bounds__(256) void k_score_prefilter_wide(const PreWideArgs 
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int pc = i * T + threadIdx.x;
-            const size_t off = (size_t)(t0 + pc / 32) * RBG + (size_t)ch * (32 * CK) + (size_t)(pc % 32) * 16;
+            const size_t off = (size_t)(t0 + pc / 32) * wa.row_stride * RBG + (size_t)ch * (32 * CK) + (size_t)(pc % 32) * 16;
             v[i] = *reinterpret_cast<const u32x4 *>(a.ipack + min(off, a.pack_bytes - 16));
         }
-        const size_t foff = (size_t)(t0 + min((int)threadIdx.x, kStage - 1)) * RBG + 32 * KS;
+        const size_t foff = (size_t)(t0 + min((int)threadIdx.x, kStage - 1)) * wa.row_stride * RBG + 32 * KS;
         fac = *reinterpret_cast<const u32x4 *>(a.ipack + min(foff, a.pack_bytes - 16));
     };
     auto store_stage = [&](int buf, const u32x4 (&v)[NP], const u32x4 &fac, int fac_buf /* < 0: not a unit's first chunk */) {
@@ -548,15 +553,15 @@ __global__ __launch_bounds__(256) void k_score_prefilter_wide(const PreWideArgs 
                 __builtin_amdgcn_sched_barrier(0);     // (eight steps' loads in flight, not all of them: they would not fit)
         }
     }
-    const float tau = user_ok ? a.tau[(size_t)user * a.tau_stride] : INFINITY;
-    const float2 ub = user_ok ? *reinterpret_cast<const float2 *>(a.ubound + 2 * (size_t)user) : make_float2(0.0f, 0.0f);
+    const float tau = user_ok && !SAMPLE ? a.tau[(size_t)user * a.tau_stride] : INFINITY;
+    const float2 ub = user_ok && !SAMPLE ? *reinterpret_cast<const float2 *>(a.ubound + 2 * (size_t)user) : make_float2(0.0f, 0.0f);
     const bf16x8 bfx = __builtin_bit_cast(bf16x8, h == 0 ? make_uint4(bf16_up_bits(ub.x) | (bf16_up_bits(ub.y) << 16),
                                                                        bf16_up_bits(ub.x * kAccumBudget), 0u, 0u)
                                                          : make_uint4(0u, 0u, 0u, 0u));
     // the lane's own segment of the user's candidate log: unlike the narrow kernels this one LOGS the raised approximate score
     // of every pair that passes (~0.5 per lane and unit against 2 KS + 2 MFMAs): k_refine turns them into a second, far tighter
     // threshold before any fp32 chain runs
-    const size_t seg = ((size_t)min(user, a.B - 1) * (2 * wa.S) + (size_t)blockIdx.y * 2 + h);
+    const size_t seg = SAMPLE ? 0 : ((size_t)min(user, a.B - 1) * (2 * wa.S) + (size_t)blockIdx.y * 2 + h);
     float2 *__restrict__ lg = wa.logs + seg * wa.cap2;
     int n_log = 0;
     store_stage(0, nxt, nfac, 0);
@@ -598,7 +603,7 @@ __global__ __launch_bounds__(256) void k_score_prefilter_wide(const PreWideArgs 
                     c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1[s], bfr[ch * CK + s], c1, 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-            if (ch == NCH - 1) {     // the bound's k-step (both halves read the row's factor chunk) and the tests
+            if (ch == NCH - 1 && !SAMPLE) {     // the bound's k-step (both halves read the row's factor chunk) and the tests
                 const bf16x8 g0 = __builtin_bit_cast(bf16x8, sfac[fbuf][r32]);
                 const bf16x8 g1 = __builtin_bit_cast(bf16x8, sfac[fbuf][32 + r32]);
                 c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, bfx, c0, 0, 0, 0);
@@ -609,6 +614,26 @@ __global__ __launch_bounds__(256) void k_score_prefilter_wide(const PreWideArgs 
             buf ^= 1;
         }
         fbuf ^= 1;
+        if constexpr (SAMPLE) {
+            if (user_ok) {
+                float *__restrict__ srow = wa.sample + (size_t)user * wa.sample_ld;
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {          // registers 4 g' .. 4 g' + 3 of a tile are four consecutive items
+                    const int item = t0 + 32 * (g >> 2) + 8 * (g & 3) + 4 * h;
+                    const f32x16 &c = g < 4 ? c0 : c1;
+                    const int q = 4 * (g & 3);
+                    if (item + 3 < i_end) {
+                        *reinterpret_cast<float4 *>(srow + item) = make_float4(c[q], c[q + 1], c[q + 2], c[q + 3]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (item + e < i_end)
+                                srow[item + e] = c[q + e];
+                    }
+                }
+            }
+            continue;
+        }
         const int lim = user_ok ? i_end - t0 : 0;
 #pragma unroll
         for (int r = 0; r < 32; ++r) {
@@ -621,7 +646,7 @@ __global__ __launch_bounds__(256) void k_score_prefilter_wide(const PreWideArgs 
             }
         }
     }
-    if (user_ok)
+    if (user_ok && !SAMPLE)
         wa.counts[seg] = n_log;
 }
 
@@ -1008,20 +1033,45 @@ int launch_prefilter_wide(const float *U, const int64_t *user_ids, int B, const 
 {
     PreWideArgs a{PreArgs{U, user_ids, static_cast<const unsigned char *>(ipack), item_pack_bytes(I, d), tau, tau_stride, ubound, nullptr, 0, B,
                           I, d, items_per_split},
-                  static_cast<float2 *>(logs), counts, S, cap2};
+                  static_cast<float2 *>(logs), counts, S, cap2, 1, nullptr, 0};
     const dim3 grid((B + 127) / 128, S), block(256);      // 128 users per workgroup, the users' fragments in registers
     const int ks = pack_ksteps(d);
     if (ks <= 16)
-        hipLaunchKernelGGL((k_score_prefilter_wide<16>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((k_score_prefilter_wide<16, false>), grid, block, 0, s, a);
     else if (ks <= 32)
-        hipLaunchKernelGGL((k_score_prefilter_wide<32>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((k_score_prefilter_wide<32, false>), grid, block, 0, s, a);
     else if (ks == 56)
-        hipLaunchKernelGGL((k_score_prefilter_wide<56>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((k_score_prefilter_wide<56, false>), grid, block, 0, s, a);
     else if (ks == 60)
-        hipLaunchKernelGGL((k_score_prefilter_wide<60>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((k_score_prefilter_wide<60, false>), grid, block, 0, s, a);
     else
-        hipLaunchKernelGGL((k_score_prefilter_wide<64>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((k_score_prefilter_wide<64, false>), grid, block, 0, s, a);
     return check_launch("k_score_prefilter_wide");
+}
+
+// the threshold sample of wide rows from the same kernel: S[b][j] ~ <U[b], It[j * stride]> for j < m, bf16 operands from the pack
+int launch_sample_wide(const float *U, const int64_t *user_ids, int B, const void *ipack, int I, int m, int d, int stride, float *S,
+                       int64_t ld, hipStream_t s)
+{
+    const int tiles = (B + 127) / 128, units = (m + kStage - 1) / kStage;
+    const int splits = max(1, min(units, 512 / tiles));
+    const int ips = ((units + splits - 1) / splits) * kStage;
+    PreWideArgs a{PreArgs{U, user_ids, static_cast<const unsigned char *>(ipack), item_pack_bytes(I, d), nullptr, 0, nullptr, nullptr, 0, B,
+                          m, d, ips},
+                  nullptr, nullptr, 1, 1, stride, S, ld};
+    const dim3 grid(tiles, (m + ips - 1) / ips), block(256);
+    const int ks = pack_ksteps(d);
+    if (ks <= 16)
+        hipLaunchKernelGGL((k_score_prefilter_wide<16, true>), grid, block, 0, s, a);
+    else if (ks <= 32)
+        hipLaunchKernelGGL((k_score_prefilter_wide<32, true>), grid, block, 0, s, a);
+    else if (ks == 56)
+        hipLaunchKernelGGL((k_score_prefilter_wide<56, true>), grid, block, 0, s, a);
+    else if (ks == 60)
+        hipLaunchKernelGGL((k_score_prefilter_wide<60, true>), grid, block, 0, s, a);
+    else
+        hipLaunchKernelGGL((k_score_prefilter_wide<64, true>), grid, block, 0, s, a);
+    return check_launch("k_score_prefilter_wide(sample)");
 }
 
 int launch_rescore(const float *U, const int64_t *user_ids, int B, const float *It, int d, const float *tau, int tau_stride,
