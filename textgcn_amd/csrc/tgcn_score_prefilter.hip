@@ -495,16 +495,21 @@ __global__ __launch_bounds__(256) void k_score_prefilter_wide(const PreWideArgs 
     const PreArgs &a = wa.p;
     constexpr int T = 256, UT = 128;
     constexpr int RBG = 32 * KS + 16;          // pack row
-    constexpr int CK = 16;                     // k-steps per LDS stage
+    constexpr int CK = KS >= 32 ? 16 : 8;      // k-steps per LDS stage (an even number of stages per unit: the register sets
+                                               // below alternate by stage parity)
     constexpr int NCH = (KS + CK - 1) / CK;
     constexpr int RBL = 32 * CK + 16;          // LDS row: 512 bytes of the chunk + 16 (conflict-free ds_read_b128 down a column slice)
-    constexpr int NP = kStage * 32 * CK / 16 / T;      // 16-byte pieces of a stage per thread (8)
+    constexpr int PPR = 2 * CK;                        // 16-byte pieces of a row's chunk
+    constexpr int NP = kStage * PPR / T;               // ... of a stage per thread
     __shared__ __attribute__((aligned(16))) unsigned char smem[2][kStage * RBL];
     __shared__ __attribute__((aligned(16))) uint4 sfac[2][kStage];          // the rows' factor chunks (bound step), per unit
     const int lane = lane_id();
     const int w = threadIdx.x >> 6;
     const int r32 = lane & 31;
     const int h = lane >> 5;
+    // (A linear grid with all user tiles of a split on ONE XCD -- they stream the same 3.7 MB slice of the pack -- was measured:
+    // 1573 us against 1508-1562 for this plain grid at 8192 users, K = 960: the launch is not bound by where the slices come from.
+    // Fragment reads four k-steps ahead instead of two: 1680 against 1671.)
     const int u0 = blockIdx.x * UT;
     const int i_beg = blockIdx.y * a.items_per_split;
     const int i_end = min(a.I, i_beg + a.items_per_split);
@@ -519,7 +524,7 @@ __global__ __launch_bounds__(256) void k_score_prefilter_wide(const PreWideArgs 
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int pc = i * T + threadIdx.x;
-            const size_t off = (size_t)(t0 + pc / 32) * wa.row_stride * RBG + (size_t)ch * (32 * CK) + (size_t)(pc % 32) * 16;
+            const size_t off = (size_t)(t0 + pc / PPR) * wa.row_stride * RBG + (size_t)ch * (32 * CK) + (size_t)(pc % PPR) * 16;
             v[i] = *reinterpret_cast<const u32x4 *>(a.ipack + min(off, a.pack_bytes - 16));
         }
         const size_t foff = (size_t)(t0 + min((int)threadIdx.x, kStage - 1)) * wa.row_stride * RBG + 32 * KS;
@@ -529,13 +534,18 @@ __global__ __launch_bounds__(256) void k_score_prefilter_wide(const PreWideArgs 
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int pc = i * T + threadIdx.x;
-            *reinterpret_cast<u32x4 *>(smem[buf] + (pc / 32) * RBL + (pc % 32) * 16) = v[i];
+            *reinterpret_cast<u32x4 *>(smem[buf] + (pc / PPR) * RBL + (pc % PPR) * 16) = v[i];
         }
         if (fac_buf >= 0 && threadIdx.x < kStage)
             *reinterpret_cast<u32x4 *>(&sfac[fac_buf][threadIdx.x]) = fac;
     };
-    u32x4 nxt[NP], nfac;
-    load_stage(nxt, nfac, i_beg, 0);
+    // stage s + 2 is requested while stage s is multiplied: one stage is ~1000 cycles of MFMA for the SIMD's only wave, less than a
+    // memory round trip -- with the request one stage ahead every stage ended waiting for its successor (1.67 -> 1.53 ms per
+    // 8192-user call at K = 960).  Two register sets: stage parity picks the set (NCH is even).
+    static_assert(NCH % 2 == 0, "stage parity");
+    u32x4 setA[NP], setB[NP], facA, facB;
+    load_stage(setA, facA, i_beg, 0);
+    load_stage(setB, facB, i_beg, 1);
 
     // the users' fragments: k-step s of lane (r32, h) = elements 16 s + 8 h .. + 7 of user r32's row, straight from global memory
     bf16x8 bfr[KS];
@@ -564,7 +574,7 @@ __global__ __launch_bounds__(256) void k_score_prefilter_wide(const PreWideArgs 
     const size_t seg = SAMPLE ? 0 : ((size_t)min(user, a.B - 1) * (2 * wa.S) + (size_t)blockIdx.y * 2 + h);
     float2 *__restrict__ lg = wa.logs + seg * wa.cap2;
     int n_log = 0;
-    store_stage(0, nxt, nfac, 0);
+    store_stage(0, setA, facA, 0);
     __syncthreads();
     asm volatile("" ::"v"(tau), "v"(bfx));
     int buf = 0, fbuf = 0;          // unit n reads its factor chunks from sfac[n & 1]
@@ -575,11 +585,15 @@ __global__ __launch_bounds__(256) void k_score_prefilter_wide(const PreWideArgs 
             c0[r] = 0.0f, c1[r] = 0.0f;
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
-            // request the next stage: the unit's next chunk, or the first chunk of the next unit (past the split: a copy nobody reads)
-            if (ch + 1 < NCH)
-                load_stage(nxt, nfac, t0, ch + 1);
-            else
-                load_stage(nxt, nfac, t0 + kStage, 0);
+            // request the stage after the next: a later chunk of this unit or one of the next unit's (past the split: copies nobody
+            // reads).  Even stages travel in set A, odd ones in set B; the set requested now is the one stored one stage ago.
+            {
+                const int t2 = ch + 2 < NCH ? t0 : t0 + kStage, c2 = ch + 2 < NCH ? ch + 2 : ch + 2 - NCH;
+                if (ch % 2 == 0)
+                    load_stage(setA, facA, t2, c2);
+                else
+                    load_stage(setB, facB, t2, c2);
+            }
             const unsigned char *pi = smem[buf] + r32 * RBL + 16 * h;
             // fragments two k-steps ahead of their MFMAs, and no further (scheduling barriers): left to itself the compiler hoists
             // the whole chunk's LDS reads and spills the users' fragments
@@ -609,7 +623,10 @@ __global__ __launch_bounds__(256) void k_score_prefilter_wide(const PreWideArgs 
                 c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, bfx, c0, 0, 0, 0);
                 c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1, bfx, c1, 0, 0, 0);
             }
-            store_stage(buf ^ 1, nxt, nfac, ch + 1 < NCH ? -1 : (fbuf ^ 1));
+            if (ch % 2 == 0)     // the next stage (odd) was requested one stage ago
+                store_stage(buf ^ 1, setB, facB, ch + 1 < NCH ? -1 : (fbuf ^ 1));
+            else
+                store_stage(buf ^ 1, setA, facA, ch + 1 < NCH ? -1 : (fbuf ^ 1));
             __syncthreads();
             buf ^= 1;
         }
