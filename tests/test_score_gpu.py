@@ -459,6 +459,18 @@ def test_prefilter_wide_rows_identical(cuda):
             it[17] = -50.0
         assert (scoring.item_pack(torch.from_numpy(it[:4]).to(cuda)) is None) == (d % 8 != 0 or d > 1024)
         _fused_vs_dense(cuda, u, it, k, mask=_rand_mask(rng, b, i, 0, 60), round4=bool(trial % 2))
+    # k_refine's corners at K = 960: train lists longer than its LDS cache that hold the users' best items (the second threshold
+    # must be formed from what is left), and a catalogue of near-copies (hundreds of candidates inside the error band of the k-th)
+    b, i, d, k = 96, 9000, 960, 64
+    u = (rng.standard_normal((b, d)) * 0.1).astype(np.float32)
+    it = (rng.standard_normal((i, d)) * 0.1).astype(np.float32)
+    best = np.argsort(-(u @ it.T), axis=1)[:, :700]                       # every user's 700 best items are train items
+    rows = [np.unique(np.concatenate([best[r], rng.integers(0, i, 300)])).astype(np.int32) for r in range(b)]
+    rp = np.zeros(b + 1, dtype=np.int64)
+    np.cumsum([len(r) for r in rows], out=rp[1:])
+    _fused_vs_dense(cuda, u, it, k, mask=(rp, np.concatenate(rows)), round4=False)
+    it2 = np.repeat(it[:30], 300, axis=0) * (1.0 + 2.0 ** -12 * rng.integers(0, 3, size=(9000, 1))).astype(np.float32)
+    _fused_vs_dense(cuda, u, it2.astype(np.float32), k, mask=_rand_mask(rng, b, i, 0, 60), round4=False)
 
 
 @pytest.mark.parametrize('b,i,d', [(2048, 50000, 64), (2048, 60000, 128)])
