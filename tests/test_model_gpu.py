@@ -254,6 +254,48 @@ def test_predict_streams_do_not_change_results(cuda, tmp_path):
     assert torch.equal(i3, ri) and torch.equal(v3, rv)
 
 
+@pytest.mark.parametrize('d', [64, 128])
+def test_ltr_predict_same_with_and_without_the_bf16_candidates(cuda, tmp_path, d):
+    """LTRLinear.predict_tensors on a 9000-item catalogue (above the small-catalogue cut, so the fused entry points run): the folded
+    operands are 896 / 960 wide -- k_score_prefilter_wide, k_refine and the list rescoring -- and the lists and scores must be the
+    fp32 filter's, bit for bit, and the scores the pairwise feature path's within the fp32 bar."""
+    import pandas as pd
+    import types
+    from textgcn_amd import synth
+    from textgcn_amd.graph import NormGraph, train_mask_csr
+    from textgcn_amd.ltr import LTRLinear
+    n_u, n_i, t = 700, 9000, 384
+    u, i = synth.interactions(n_u, n_i, 20000, seed=4)
+    g = NormGraph.from_pairs(u, i, n_u, n_i)
+    rp, items = train_mask_csr(u, i, n_u)
+    gen = torch.Generator().manual_seed(d)
+    ds = types.SimpleNamespace(n_users=n_u, n_items=n_i, graph=g, norm_matrix=None, mask_rowptr=rp, mask_items=items,
+                               true_test_lil=[[0]], train_user_dict=None, test_df=pd.DataFrame({'user_id': [0], 'asin': [0]}),
+                               user_mapping=pd.DataFrame({'remap_id': [0], 'org_id': ['u']}),
+                               item_mapping=pd.DataFrame({'remap_id': [0], 'org_id': ['i']}),
+                               items_as_desc=torch.randn((n_i, t), generator=gen), items_as_avg_reviews=torch.randn((n_i, t), generator=gen),
+                               users_as_avg_reviews=torch.randn((n_u, t), generator=gen), users_as_avg_desc=torch.randn((n_u, t), generator=gen),
+                               all_items=range(n_i))
+    p = _params(k=[20, 40], emb_size=d, batch_size=256, save_path=str(tmp_path), exact=False, load_base=None, freeze=True, ltr_layers=[])
+    m = LTRLinear(p, ds)
+    with torch.no_grad():
+        m.layers[0].weight.copy_(torch.tensor([[0.9, 0.05, -0.03, 0.02, 0.04]]))
+        m.layers[0].bias.fill_(0.1)
+    m.ltr_predict_chunk = 256
+    users = np.arange(n_u)
+    assert m.score_prefilter and int(m._k()) == d + 2 * t + 64
+    v1, i1 = m.predict_tensors(users)
+    m.score_prefilter = False
+    v0, i0 = m.predict_tensors(users)
+    assert torch.equal(i1, i0) and torch.equal(v1, v0)
+    with torch.no_grad():
+        ue, ie = m.representation
+        rows = torch.arange(0, n_u, 7, device=cuda)
+        top = i1[rows, 0]
+        pair = m.score_pairwise(ue[rows], ie[top], rows, top).reshape(-1)
+    assert torch.allclose(pair, v1[rows, 0], atol=2e-4, rtol=1e-4)
+
+
 def test_model_takes_segmented_kernels_where_they_pay(cuda):
     """A graph whose user table (10 MB) misses an XCD's L2 while an eighth fits: the model's default path segments
     the item rows (propagate.segment_blocks_auto) in inference, in dropout-free training and -- through the gathered
