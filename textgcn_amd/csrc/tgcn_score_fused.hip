@@ -1372,11 +1372,15 @@ int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const fl
             // wide rows: the filter logs its candidates (k_select's segment layout: the plan's splits), k_refine keeps those that
             // can still reach the top k, the fp32 chains run on what is left
             int *surv = reinterpret_cast<int *>(ws + p.off_surv), *surv_n = reinterpret_cast<int *>(ws + p.off_surv_n);
-            if ((rc = launch_prefilter_wide(U, user_ids, B, ipack, I, d, tau_ptr, tau_stride, ubound, fa.logs, fa.counts, p.S,
-                                            p.items_per_split, p.cap2, s)) != TGCN_OK)
+            // calls with many user tiles take half the plan's splits: a workgroup's prologue (its 128 x d user tile, ~16 us) is
+            // then paid half as often
+            const bool few = (B + 127) / 128 >= 32 && p.S >= 16 && p.S % 2 == 0;
+            const int S_w = few ? p.S / 2 : p.S, ips_w = few ? 2 * p.items_per_split : p.items_per_split;
+            if ((rc = launch_prefilter_wide(U, user_ids, B, ipack, I, d, tau_ptr, tau_stride, ubound, fa.logs, fa.counts, S_w, ips_w,
+                                            p.cap2, s)) != TGCN_OK)
                 return rc;
             RefineArgs ra{fa.logs, fa.counts, mask_rowptr, mask_items, ubound, static_cast<const unsigned char *>(ipack), pack_row_bytes(d),
-                          surv, surv_n, kRefineCap, B, p.S, p.cap2, k};
+                          surv, surv_n, kRefineCap, B, S_w, p.cap2, k};
             hipLaunchKernelGGL(k_refine, dim3((B + 3) / 4), dim3(256), 0, s, ra);
             if ((rc = check_launch("k_refine")) != TGCN_OK)
                 return rc;
