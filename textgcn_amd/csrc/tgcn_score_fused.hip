@@ -1374,7 +1374,7 @@ int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const fl
             int *surv = reinterpret_cast<int *>(ws + p.off_surv), *surv_n = reinterpret_cast<int *>(ws + p.off_surv_n);
             // calls with many user tiles take half the plan's splits: a workgroup's prologue (its 128 x d user tile, ~16 us) is
             // then paid half as often
-            const bool few = (B + 127) / 128 >= 32 && p.S >= 16 && p.S % 2 == 0;
+            const bool few = (B + 127) / 128 >= 16 && p.S >= 16 && p.S % 2 == 0;
             const int S_w = few ? p.S / 2 : p.S, ips_w = few ? 2 * p.items_per_split : p.items_per_split;
             if ((rc = launch_prefilter_wide(U, user_ids, B, ipack, I, d, tau_ptr, tau_stride, ubound, fa.logs, fa.counts, S_w, ips_w,
                                             p.cap2, s)) != TGCN_OK)
