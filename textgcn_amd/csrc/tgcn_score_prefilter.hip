@@ -22,6 +22,12 @@
 // against tau_u.  The bound is per PAIR: one item row of enormous norm becomes a candidate for everybody but does not loosen
 // anybody else's test.  Non-finite data: a non-finite factor becomes +inf, the accumulator +inf or NaN, and the test is
 // !(acc <= tau) -- the pair is kept and decided by its fp32 score.
+//
+// In this file: k_item_pack (the item operand, once per table), k_sample_bf16 / the SAMPLE form of k_score_prefilter_wide (the
+// threshold sample k_tau ranks), k_score_prefilter (d <= 128: pass bits), k_score_prefilter_wide (128 < d <= 1024: the users'
+// fragments in registers, the passing pairs LOGGED with their raised scores -- k_refine in tgcn_score_fused.hip turns those into a
+// second threshold, the k-th largest lower bound, and only what can still reach the top k is rescored), k_rescore (the fp32
+// chains, from the pass bits or from k_refine's id lists).
 #include <type_traits>
 
 #include "tgcn_internal.h"
