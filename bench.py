@@ -221,11 +221,13 @@ def batch_masks(users, mrp, mit, dev, ids_origin=0):
             torch.from_numpy(np.ascontiguousarray(items)).to(dev))
 
 
+SCORE_STREAMS = {False: 3, True: 4}     # set by --streams-fp32 / --streams-prefilter (sweeps); no environment variable is read
+
+
 def n_score_streams(prefilter):
     """calls in flight: 3 for the fp32 filter, 4 (LightGCN.predict_streams) for the bf16-candidate path -- sweeps of 2 / 3 / 4 / 6 on
     the final kernels, profiles/r02_experiments.md"""
-    env = os.environ.get('TGCN_BENCH_STREAMS_PREFILTER' if prefilter else 'TGCN_BENCH_STREAMS_FP32')     # sweeps only
-    return int(env) if env else (4 if prefilter else 3)
+    return SCORE_STREAMS[bool(prefilter)]
 
 
 def scoring_region(ue, ie, batches, k_top, dev, barrier, prefilter=False):
@@ -518,6 +520,39 @@ def record_train_step(dev, u, i, graph, n_u, n_i, d, K, steps=10):
             'through': 'textgcn_amd.LightGCN._train_epoch (get_loss -> backward -> optimizer.step, as fit() does)'}
 
 
+def shared_workload(wl, rank, barrier):
+    """N > 1: the synthetic graph and E0 are generated ONCE per node -- rank 0 builds them (30 s and ~12 GB of host memory for
+    config 4; eight concurrent builds would be eight times both) and publishes the arrays as .npy files in a node-local
+    directory (memory-backed /dev/shm when present), the other ranks wait at a barrier and memory-map them: a rank then only
+    touches the pages of its own row blocks.  Returns (NormGraph over the mapped arrays, E0 as a torch tensor over the map,
+    directory -- removed by rank 0 at the end)."""
+    import tempfile
+    from textgcn_amd import synth
+    from textgcn_amd.graph import NormGraph
+    n_u, n_i, nnz, d, _ = synth.CONFIGS[wl]
+    base = '/dev/shm' if os.path.isdir('/dev/shm') and os.access('/dev/shm', os.W_OK) else tempfile.gettempdir()
+    path = os.path.join(base, f"tgcn_bench_{os.environ.get('MASTER_PORT', '0')}_{wl}")
+    if rank == 0:
+        os.makedirs(path, exist_ok=True)
+        u, i = synth.interactions(n_u, n_i, nnz, seed=0)
+        g = NormGraph.from_pairs(u, i, n_u, n_i)
+        del u, i
+        for name, arr in (('rowptr', g.rowptr), ('colidx', g.colidx), ('vals', g.vals),
+                          ('e0', synth.embeddings(g.n, d, seed=0).numpy())):
+            np.save(os.path.join(path, name + '.npy'), arr)
+        del g
+    barrier()
+    m = {name: np.load(os.path.join(path, name + '.npy'), mmap_mode='c') for name in ('rowptr', 'colidx', 'vals', 'e0')}
+    return NormGraph(n_u, n_i, m['rowptr'], m['colidx'], m['vals']), torch.from_numpy(m['e0']), path
+
+
+def device_identity(dev):
+    """what tells two ranks' GPUs apart in the JSON line: PCI address (domain:bus:device) where torch exposes it, + name"""
+    p = torch.cuda.get_device_properties(dev)
+    pci = ':'.join(f'{getattr(p, a):0{w}x}' for a, w in (('pci_domain_id', 4), ('pci_bus_id', 2), ('pci_device_id', 2)) if hasattr(p, a))
+    return f"{pci or 'pci?'} {getattr(p, 'uuid', '')} {p.name}".strip()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -538,12 +573,16 @@ def main():
     ap.add_argument('--shard', default='rows', choices=['rows', 'features'],
                     help="N > 1: 'rows' = 1-D row partition with per-layer RCCL all-gathers (the north-star design, default); "
                          "'features' = every rank holds all rows and d/N columns: no per-layer exchange, one all-gather at the end")
-    ap.add_argument('--no-feature-partition', action='store_true',
-                    help='N > 1: skip the second timing of the forward under the feature (column) partition')
+    ap.add_argument('--feature-partition', action='store_true',
+                    help='N > 1, --shard rows: ALSO time the forward under the feature (column) partition in the same run (a second '
+                         'full-graph propagator per rank; off by default)')
+    ap.add_argument('--streams-fp32', type=int, default=3, help='scoring calls in flight, fp32 filter path (sweeps)')
+    ap.add_argument('--streams-prefilter', type=int, default=4, help='scoring calls in flight, bf16-candidate path (sweeps)')
     ap.add_argument('--force-sharded', action='store_true',
                     help='N = 1 only: run the N > 1 code path (row blocks, chunked RCCL all-gathers on a 1-rank communicator, '
                          'per-rank scoring, all-reduced timing) on the one GPU -- a rehearsal of the multi-GPU run, not a headline')
     args = ap.parse_args()
+    SCORE_STREAMS[False], SCORE_STREAMS[True] = args.streams_fp32, args.streams_prefilter
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -555,8 +594,14 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a ROCm GPU: the HIP path has no CPU fallback')
     # rehearsal switch for the one-GPU box: every rank on cuda:0, gloo staged through the host (tests only; the
-    # driver's multi-GPU runs use RCCL, one GPU per rank)
+    # driver's multi-GPU runs use RCCL, one GPU per rank).  Refused where more than one GPU is visible: there it could
+    # only turn a real multi-GPU run into a silent one-GPU run.
     rehearsal = os.environ.get('TGCN_BENCH_REHEARSAL') == '1'
+    if rehearsal and torch.cuda.device_count() > 1:
+        raise SystemExit('TGCN_BENCH_REHEARSAL=1 (all ranks on cuda:0 over gloo) is for one-GPU boxes; '
+                         f'{torch.cuda.device_count()} GPUs are visible here -- unset it')
+    if world > 1 and not rehearsal and torch.cuda.device_count() < world:
+        raise SystemExit(f'--gpus {world} needs {world} visible GPUs (one per rank), found {torch.cuda.device_count()}')
     dev_index = 0 if rehearsal else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
@@ -564,23 +609,30 @@ def main():
     if sharded:
         import torch.distributed as dist
         if world == 1 and 'RANK' not in os.environ:      # --force-sharded from a plain `python bench.py`
-            dist.init_process_group(backend='nccl', init_method='tcp://127.0.0.1:29531', rank=0, world_size=1, device_id=dev)
+            import tempfile
+            rdv = tempfile.mkdtemp(prefix='tgcn_bench_rdv_')     # a file store: no TCP port to collide on
+            dist.init_process_group(backend='nccl', init_method=f'file://{rdv}/store', rank=0, world_size=1, device_id=dev)
         elif rehearsal:
             dist.init_process_group(backend='gloo')
         else:
             dist.init_process_group(backend='nccl', device_id=dev)
 
     from textgcn_amd import propagate, synth
-    from textgcn_amd.graph import NormGraph, train_mask_csr
+    from textgcn_amd.graph import NormGraph
 
     default_wl = args.workload is None
     wl = args.workload or ('c4' if sharded else 'c2')
     n_u, n_i, nnz, d, K = synth.CONFIGS[wl]
     wl_name = f'{wl}: U={n_u} I={n_i} nnz={nnz} d={d} K={K}'
     t0 = time.time()
-    u, i = synth.interactions(n_u, n_i, nnz, seed=0)
-    graph = NormGraph.from_pairs(u, i, n_u, n_i)
-    e0 = synth.embeddings(graph.n, d, seed=0)
+    if world > 1:
+        graph, e0, share_dir = shared_workload(wl, rank, dist.barrier)
+        u = i = None
+    else:
+        u, i = synth.interactions(n_u, n_i, nnz, seed=0)
+        graph = NormGraph.from_pairs(u, i, n_u, n_i)
+        e0 = synth.embeddings(graph.n, d, seed=0)
+        share_dir = None
     build_s = time.time() - t0
     thr = args.split_threshold or propagate.DEFAULT_SPLIT_THRESHOLD
 
@@ -648,7 +700,7 @@ def main():
     result = {
         'metric': 'propagated edges/sec (3-layer SpMM, d=64)', 'value': value, 'unit': 'edges/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': t / args.steps * 1e3, 'higher_is_better': True,
-        'scaling': 'strong' if sharded else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': wl_name, 'nnz_A': graph.nnz, 'n_nodes': graph.n, 'max_degree': int(graph.degrees().max()),
                    'mode': 'exact (one fmaf chain per row)' if args.exact else f'one-wave-per-row kernel: rows > {thr} entries split in chunks',
                    'parity_of_this_mode': 'bit-identical to the reference CPU forward' if args.exact else
@@ -663,7 +715,7 @@ def main():
                    'graph_build_s': round(build_s, 1)},
         'roofline': roofline,
     }
-    if sharded and args.shard == 'rows' and d % world == 0 and d // world in (8, 16, 32, 64) and not args.no_feature_partition:
+    if sharded and args.shard == 'rows' and d % world == 0 and d // world in (8, 16, 32, 64) and args.feature_partition:
         # the same forward under the feature partition (every rank: all rows, d / world columns, no per-layer exchange, one
         # all-gather at the end), timed the same way in the same run: the record's `value` stays the row partition's
         cp = ColumnShardedPropagator(graph, d, rank, world, dev, split_threshold=thr, force_collective=args.force_sharded)
@@ -680,6 +732,37 @@ def main():
         cp.close()
         del cp, e_cols
         torch.cuda.empty_cache()
+    if sharded:
+        # evidence that N ranks ran on N distinct devices, and where a layer's time went on the slowest rank
+        ident = [None] * world
+        torch.distributed.all_gather_object(ident, f'rank {rank}: cuda:{dev_index} {device_identity(dev)}')
+        result['config']['world_size'] = torch.distributed.get_world_size()
+        result['config']['backend'] = torch.distributed.get_backend()
+        result['config']['devices'] = ident
+        result['config']['distinct_devices'] = len({x.split(': ', 1)[1] for x in ident})
+        if args.shard == 'rows':
+            sp.record_events = True
+            reps = 3
+            tot = None
+            for _ in range(reps):
+                step()
+                lt = sp.layer_times()
+                tot = lt if tot is None else [{'layer': a['layer'], 'compute_ms': a['compute_ms'] + b['compute_ms'],
+                                               'wait_on_gather_ms': a['wait_on_gather_ms'] + b['wait_on_gather_ms']}
+                                              for a, b in zip(tot, lt)]
+            sp.record_events = False
+            mine = [{'layer': a['layer'] if a['layer'] <= K else 'final gather', 'compute_ms': round(a['compute_ms'] / reps, 3),
+                     'wait_on_gather_ms': round(a['wait_on_gather_ms'] / reps, 3)} for a in tot]
+            every = [None] * world
+            torch.distributed.all_gather_object(every, mine)
+            result['layers'] = {
+                'what': 'per layer, HIP events on the launch stream (3 extra forwards after the timed region): ms the stream spent in '
+                        'its SpMM launches (both half-steps) and ms it sat waiting for an all-gathered block',
+                'rank0': mine,
+                'max_over_ranks': [{'layer': m['layer'], 'compute_ms': max(r[j]['compute_ms'] for r in every),
+                                    'wait_on_gather_ms': max(r[j]['wait_on_gather_ms'] for r in every)} for j, m in enumerate(mine)]}
+    if world > 1:
+        result['scaling'] = 'strong'      # fixed total work (config 4) split over the ranks; a 1-GPU run has no scaling to name
     if sharded:
         result['config']['scaling_note'] = 'fixed total work (BASELINE config 4) split over the ranks; N = 1 of the same workload: ' \
                                            'bench.py --gpus 1 reports it as the sub-record c4_1gpu'
@@ -701,7 +784,7 @@ def main():
             ue, itab = sp.forward(eu, ei, K, exact=args.exact)
             ie = sp.items_in_order(itab)
             users_all = np.arange(*sp.user_range())
-        mrp, mit = train_mask_csr(u, i, n_u)
+        mrp, mit = graph.train_mask()      # = train_mask_csr(u, i, n_u): the generator's pairs are distinct
         n_batches = min(args.score_batches, max(1, len(users_all) // bsz))
         batches = [batch_masks(users_all[b * bsz:(b + 1) * bsz], mrp, mit, dev, ids_origin=users_all[0]) for b in range(n_batches)]
         ue = ue.contiguous()
@@ -780,6 +863,10 @@ def main():
         print(json.dumps(result))
     if sharded:
         sp.close()
+        torch.distributed.barrier()
+        if share_dir is not None and rank == 0:
+            import shutil
+            shutil.rmtree(share_dir, ignore_errors=True)
         torch.distributed.destroy_process_group()
 
 

@@ -4,9 +4,10 @@
   --mode cpu : gloo on CPU tensors; the local SpMM is the CPU oracle (injected stand-in) -- exercises the
                partitioning / padding / all-gather / layer-sum logic of textgcn_amd.dist without a GPU.
   --mode gpu : every rank uses cuda:0 (one-GPU box) with the real HIP kernels; gloo staged through the host.
-  --mode nccl: ONE rank on cuda:0 with backend nccl (= RCCL) and the world == 1 short-circuit bypassed, so the production
+  --mode nccl: backend nccl (= RCCL).  ONE rank on cuda:0 with the world == 1 short-circuit bypassed, so the production
                collective code runs -- in-place all_gather_into_tensor(async_op=True) + work.wait() on torch's communicator
-               (--collective torch) or tgcn_allgather_rows on libtgcn's own communicator and side stream (--collective capi).
+               (--collective torch) or tgcn_allgather_rows on libtgcn's own communicator and side stream (--collective capi);
+               with --device-per-rank, --world N ranks on cuda:0..N-1 of a multi-GPU box (the real thing).
 Writes users_full / items_full of rank 0 (after gathering the user blocks) to --out.
 """
 import argparse
@@ -52,6 +53,7 @@ def main():
     ap.add_argument('--sample', type=int, default=0, help='save only this many seeded sample rows of each table (large graphs)')
     ap.add_argument('--graph-seed', type=int, default=1)
     ap.add_argument('--shard', choices=['rows', 'features'], default='rows')
+    ap.add_argument('--device-per-rank', action='store_true', help='--mode nccl on a multi-GPU box: rank r uses cuda:r')
     args = ap.parse_args()
 
     from textgcn_amd import synth
@@ -59,9 +61,10 @@ def main():
     from textgcn_amd.graph import NormGraph
 
     if args.mode == 'nccl':
-        torch.cuda.set_device(0)
+        dev_index = args.rank if args.device_per_rank else 0
+        torch.cuda.set_device(dev_index)
         dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{args.port}', rank=args.rank, world_size=args.world,
-                                device_id=torch.device('cuda', 0))
+                                device_id=torch.device('cuda', dev_index))
     else:
         dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{args.port}', rank=args.rank, world_size=args.world)
     u, i = synth.interactions(args.n_users, args.n_items, args.nnz, seed=args.graph_seed)

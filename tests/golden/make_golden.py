@@ -385,11 +385,9 @@ def g6_builder(work):
     save('g6_builder.npz', **out)
 
 
-# --------------------------------------------------------------------------- G4: LTRLinear on frozen LightGCN
-def g4_ltr(work, data):
-    """ltr_linear on the synth-60x40 data (SURVEY.md F9: needs reviews_text.tsv + cached 384-d tensors).
-    The text tensors are synthetic (exact_embedding), written where the reference's cache lookup finds them
-    (reviews_models.py:37-53, kg_models.py:24-31), so no SBERT model is involved."""
+def ltr_files(data):
+    """What TextGCN.LTRDataset reads beside the two TSVs, written where its cache lookup finds them: reviews_text.tsv and
+    the two cached 384-d tensors (synthetic, exact_embedding).  Returns (the rng after its draws, text width)."""
     import pandas as pd
     train = pd.read_table(os.path.join(data, 'train.tsv'), dtype=str)
     rng = np.random.default_rng(4)
@@ -403,6 +401,15 @@ def g4_ltr(work, data):
     torch.save(torch.from_numpy(exact_embedding(len(rev), t, 41) * 8), os.path.join(emb_dir, 'item_full_reviews_loss_repr_all-MiniLM-L6-v2_0-seed.torch'))
     n_items = train.asin.nunique()
     torch.save(torch.from_numpy(exact_embedding(n_items, t, 42) * 8), os.path.join(emb_dir, 'item_kg_repr_all-MiniLM-L6-v2_0-seed.torch'))
+    return rng, t
+
+
+# --------------------------------------------------------------------------- G4: LTRLinear on frozen LightGCN
+def g4_ltr(work, data):
+    """ltr_linear on the synth-60x40 data (SURVEY.md F9: needs reviews_text.tsv + cached 384-d tensors).
+    The text tensors are synthetic (exact_embedding), written where the reference's cache lookup finds them
+    (reviews_models.py:37-53, kg_models.py:24-31), so no SBERT model is involved."""
+    rng, t = ltr_files(data)
     # base checkpoint with known weights
     args = run_args(['--model', 'lgcn', '--no_train', '-k', '5', '10', '--batch_size', '32'], data, work)
     ds0 = TextGCN.BaseDataset(args)
@@ -551,6 +558,67 @@ def g10_reshuffle(work, data):
     shutil.rmtree(folder, ignore_errors=True)
 
 
+# --------------------------------------------------------------------------- G11: dynamic negative sampling loss
+def g11_adv_loss(work, data):
+    """AdvSamplModel.get_loss (advanced_sampling.py:46-69) on the synth-60x40 data, no dropout: per row a user and 20 distinct
+    candidate items; the reference ranks them, drops the user's positives, keeps max(k) = 5 hard negatives, pairs them with up
+    to 5 random positives (random.sample -- captured here, it cannot be reproduced elsewhere) and takes BaseModel's loss over
+    the triples.  Stored: the batch, the captured positives, the negatives in the reference's order, the triples, loss + dE0."""
+    import random
+    from collections import defaultdict
+    import TextGCN.advanced_sampling as adv
+    args = run_args(['--model', 'adv_sampling', '--no_train', '-k', '3', '5', '--dropout', '0.0'], data, work)
+    ds = TextGCN.AdvSamplDataset(args)
+    model = TextGCN.AdvSamplModel(args, ds)
+    set_weights(model, exact_embedding(ds.n_users, 64, 11), exact_embedding(ds.n_items, 64, 12))
+    rng = np.random.default_rng(11)
+    b, m = 24, 20
+    users = rng.integers(0, ds.n_users, b)
+    cand = np.stack([rng.choice(ds.n_items, size=m, replace=False) for _ in users])
+    batch = torch.from_numpy(np.concatenate([users[:, None], cand], axis=1).astype(np.int64))
+    positives, survivors, triples = [], [], []
+    real_sample, real_sub, real_loss = random.sample, adv.subtract_tensor_as_set, TextGCN.BaseModel.get_loss
+
+    def rec_sample(pop, k):
+        out = real_sample(pop, k)
+        positives.append(list(out))
+        return out
+
+    def rec_sub(t1, t2):
+        out = real_sub(t1, t2)
+        survivors.append(out.clone())
+        return out
+
+    def rec_loss(self, d):
+        triples.append(d.clone())
+        return real_loss(self, d)
+    model._loss_values = defaultdict(float)
+    model.train()
+    model.training = True
+    model.zero_grad()
+    random.seed(1111)
+    random.sample, adv.subtract_tensor_as_set, TextGCN.BaseModel.get_loss = rec_sample, rec_sub, rec_loss
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)        # the 560-row index backward adds duplicates in thread order: one thread = one order, so
+    try:                            # that the fixture regenerates byte for byte (the test's bar is normwise 1e-4 anyway)
+        loss = model.get_loss(batch)
+        loss.backward()
+    finally:
+        random.sample, adv.subtract_tensor_as_set, TextGCN.BaseModel.get_loss = real_sample, real_sub, real_loss
+        torch.set_num_threads(threads)
+    kmax = max(args.k)
+    pos = np.full((b, ds.pos_samples), -1, dtype=np.int64)
+    neg = np.full((b, kmax), -1, dtype=np.int64)
+    for r in range(b):
+        pos[r, :len(positives[r])] = positives[r]
+        keep = survivors[r][:kmax].numpy()
+        neg[r, :len(keep)] = keep
+    save('g11_adv_loss.npz', batch=batch.numpy(), positives=pos, negatives=neg, triples=triples[0].numpy(),
+         loss=np.float64(loss.detach().item()), bpr=np.float64(float(model._loss_values['bpr'])), reg=np.float64(float(model._loss_values['reg'])),
+         grad_user=model.embedding_user.weight.grad.numpy().copy(), grad_item=model.embedding_item.weight.grad.numpy().copy(),
+         k=np.asarray(args.k), pos_samples=np.int64(ds.pos_samples), reg_lambda=np.float64(args.reg_lambda))
+
+
 def main():
     work = tempfile.mkdtemp(prefix='tgcn_golden_')
     try:
@@ -567,6 +635,8 @@ def main():
             g9_metrics(work)
         if ONLY in (None, 'g10'):
             g10_reshuffle(work, data60)
+        if ONLY in (None, 'g11'):
+            g11_adv_loss(work, data60)
         if ONLY is None:
             g5_medium(work)
             g6_builder(work)

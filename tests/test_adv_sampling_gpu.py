@@ -72,3 +72,43 @@ def test_adv_loss_and_step(cuda):
         mine = set(items[rp[x]:rp[x + 1]])
         got = [v for v in pos[r] if v >= 0]
         assert len(got) == min(5, len(mine)) == len(set(got)) and set(got) <= mine
+
+
+def test_adv_get_loss_matches_reference(golden, cuda):
+    """G11: AdvSamplModel.get_loss (advanced_sampling.py:46-69) run by the reference on the synth-60x40 data.  The hard
+    negatives must be the reference's, in its order; with the reference's captured random positives injected, loss, its two
+    parts and dE0 must match (normwise 1e-4, the north star's fp32 bar)."""
+    from collections import defaultdict
+    from conftest import normwise
+    from textgcn_amd.adv_sampling import AdvSamplModel
+    from textgcn_amd.graph import NormGraph
+    g2, g = golden('g2_synth60'), golden('g11_adv_loss')
+    n_u, n_i = int(g2['n_users']), int(g2['n_items'])
+    train = pd.DataFrame({'user_id': g2['train_u'], 'asin': g2['train_i']})
+    test = pd.DataFrame({'user_id': g2['test_u'], 'asin': g2['test_i']})
+    ds = types.SimpleNamespace(n_users=n_u, n_items=n_i, graph=NormGraph.from_pairs(g2['train_u'], g2['train_i'], n_u, n_i), norm_matrix=None,
+                               true_test_lil=test.groupby('user_id')['asin'].aggregate(list).values.tolist(),
+                               train_user_dict=train.groupby('user_id')['asin'].aggregate(list), test_df=test,
+                               user_mapping=pd.DataFrame({'remap_id': range(n_u), 'org_id': range(n_u)}),
+                               item_mapping=pd.DataFrame({'remap_id': range(n_i), 'org_id': range(n_i)}),
+                               pos_samples=int(g['pos_samples']), seed=0)
+    for exact in (True, False):
+        p = types.SimpleNamespace(k=[int(x) for x in g['k']], emb_size=64, n_layers=3, device='cuda:0', load=None, quiet=True, dropout=0.0,
+                                  exact=exact, reg_lambda=float(g['reg_lambda']))
+        m = AdvSamplModel(p, ds)
+        with torch.no_grad():
+            m.embedding_user.weight.copy_(torch.from_numpy(g2['a_layer0'][:n_u]))
+            m.embedding_item.weight.copy_(torch.from_numpy(g2['a_layer0'][n_u:]))
+        batch = torch.from_numpy(g['batch'])
+        neg = m.hard_negatives(batch[:, 0].contiguous().to(cuda), batch[:, 1:].contiguous().to(cuda)).cpu().numpy()
+        assert np.array_equal(neg, g['negatives'])
+        m.sample_positives = lambda users_np: g['positives']          # the reference's random.sample draws (not reproducible)
+        m._loss_values = defaultdict(float)
+        m.training = True
+        loss = m.get_loss(batch)
+        loss.backward()
+        assert abs(float(loss) - float(g['loss'])) <= 1e-5 * abs(float(g['loss'])) + 1e-8
+        assert abs(float(m._loss_values['bpr']) - float(g['bpr'])) <= 1e-5 * abs(float(g['bpr'])) + 1e-8
+        assert abs(float(m._loss_values['reg']) - float(g['reg'])) <= 1e-5 * abs(float(g['reg']))
+        assert normwise(m.embedding_user.weight.grad.cpu().numpy(), g['grad_user']) <= 1e-4
+        assert normwise(m.embedding_item.weight.grad.cpu().numpy(), g['grad_item']) <= 1e-4

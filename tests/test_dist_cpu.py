@@ -84,3 +84,31 @@ def test_nnz_balanced_partition_evens_out_entries():
     rows_equal = np.diff(g.rowptr[3000 + np.minimum(np.arange(5) * 250, 1000)])
     assert per.max() / per.mean() < 1.1 <= rows_equal.max() / rows_equal.mean() + 0.1
     assert per.max() <= rows_equal.max()
+
+
+def test_forward_results_are_views_until_the_next_forward_and_copy_detaches_them(oracle):
+    """ShardedPropagator.forward hands back views of its reusable buffers (documented lifetime: until the next
+    forward on the object); copy=True gives private tensors that survive it."""
+    import torch
+    from dist_worker import oracle_spmm
+    from textgcn_amd import synth
+    from textgcn_amd.dist import ShardedPropagator
+    from textgcn_amd.graph import NormGraph
+    u, i = synth.interactions(203, 97, 2500, seed=1)
+    g = NormGraph.from_pairs(u, i, 203, 97)
+    sp = ShardedPropagator(g, 0, 1, 'cpu', local_spmm=oracle_spmm, split_threshold=None, chunks=2)
+    e_a = synth.embeddings(g.n, 64, seed=2)
+    e_b = synth.embeddings(g.n, 64, seed=3)
+    for layers in (0, 3):
+        ua, ia = sp.forward(*sp.local_e0(e_a), layers, copy=True)
+        keep_u, keep_i = ua.clone(), ia.clone()
+        va, vi = sp.forward(*sp.local_e0(e_a), layers)
+        assert torch.equal(va, keep_u) and torch.equal(vi, keep_i)
+        ub, ib = sp.forward(*sp.local_e0(e_b), layers)            # overwrites the buffers the views point into
+        assert torch.equal(ua, keep_u) and torch.equal(ia, keep_i)          # the copies are untouched
+        assert ub.data_ptr() == va.data_ptr() and torch.equal(va, ub)       # the view now shows the NEW forward (documented)
+        assert not torch.equal(ub, keep_u)
+        if layers:
+            want, _ = oracle.propagate(*g.to_coo(), e_a.numpy(), layers)
+            got_i = sp.items_in_order(keep_i).numpy()
+            assert np.array_equal(bits(keep_u[:203].numpy()), bits(want[:203])) and np.array_equal(bits(got_i), bits(want[203:]))

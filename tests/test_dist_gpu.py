@@ -35,6 +35,67 @@ def test_rccl_collective_path_runs_on_one_rank(cuda, tmp_path, collective, chunk
     assert np.array_equal(bits(got['items']), bits(ref[n_u:]))
 
 
+def _n_gpus():
+    import torch
+    return torch.cuda.device_count()      # does not initialise the GPU (the ranks are fresh child processes)
+
+
+@pytest.mark.parametrize('collective,chunks', [('torch', 1), ('torch', 4), ('capi', 1), ('capi', 3)])
+@pytest.mark.parametrize('world', [2, 4])
+def test_rccl_multi_gpu_forward_is_bit_identical(tmp_path, world, collective, chunks):
+    """The first thing to run on a multi-GPU box: `world` ranks, ONE GPU EACH, backend nccl (= RCCL over xGMI) -- the in-place
+    asynchronous all_gather_into_tensor into the chunk-major layer table with real peers, the CapiComm id broadcast and
+    tgcn_allgather_rows on its side stream -- must reproduce the one-GPU forward bit for bit.  Skipped where fewer GPUs are
+    visible (this pool's one-GPU boxes); the ranks are fresh child processes started before anything here touches a GPU."""
+    if _n_gpus() < world:
+        pytest.skip(f'needs {world} GPUs, {_n_gpus()} visible')
+    import torch
+    out = str(tmp_path / 'r0.npz')
+    n_u, n_i, nnz = 2030, 970, 40000
+    run_ranks(world, 'nccl', out, extra=('--n-users', str(n_u), '--n-items', str(n_i), '--nnz', str(nnz), '--collective', collective,
+                                         '--chunks', str(chunks), '--device-per-rank'))
+    got = np.load(out)
+    ref = _single_gpu_reference(torch.device('cuda:0'), n_u, n_i, nnz)
+    assert np.array_equal(bits(got['users']), bits(ref[:n_u]))
+    assert np.array_equal(bits(got['items']), bits(ref[n_u:]))
+
+
+def test_rccl_multi_gpu_feature_partition(tmp_path):
+    """the feature partition's one collective (all-gather + column interleave) over two real RCCL ranks"""
+    if _n_gpus() < 2:
+        pytest.skip(f'needs 2 GPUs, {_n_gpus()} visible')
+    import torch
+    out = str(tmp_path / 'r0.npz')
+    n_u, n_i, nnz = 2030, 970, 40000
+    run_ranks(2, 'nccl', out, extra=('--n-users', str(n_u), '--n-items', str(n_i), '--nnz', str(nnz), '--shard', 'features',
+                                     '--device-per-rank'))
+    got = np.load(out)
+    ref = _single_gpu_reference(torch.device('cuda:0'), n_u, n_i, nnz)
+    assert np.array_equal(bits(got['users']), bits(ref[:n_u])) and np.array_equal(bits(got['items']), bits(ref[n_u:]))
+
+
+def test_bench_two_gpus_rccl(tmp_path):
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one GPU per rank, RCCL) on the small workload: one JSON
+    line whose config shows two ranks on two distinct devices and a per-layer compute / wait split."""
+    if _n_gpus() < 2:
+        pytest.skip(f'needs 2 GPUs, {_n_gpus()} visible')
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    from test_dist_cpu import free_port
+    env = {k: v for k, v in os.environ.items() if k != 'TGCN_BENCH_REHEARSAL'}
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+           '--workload', 'small', '--score-batches', '1', '--no-cpu-baseline']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert r['n_gpus'] == 2 and r['scaling'] == 'strong' and r['config']['world_size'] == 2 and r['config']['distinct_devices'] == 2
+    assert r['config']['backend'] == 'nccl' and len(r['layers']['max_over_ranks']) == 4
+
+
 @pytest.mark.parametrize('world,balance,chunks', [(2, 'nnz', 1), (3, 'nnz', 2), (3, 'rows', 1)])
 def test_sharded_hip_forward_equals_single_gpu(cuda, tmp_path, world, balance, chunks):
     from textgcn_amd import synth
@@ -74,6 +135,9 @@ def test_bench_two_rank_rehearsal(cuda, tmp_path):
     assert len(lines) == 1
     r = json.loads(lines[0])
     assert r['n_gpus'] == 2 and r['value'] > 0 and r['scaling'] == 'strong' and 'roofline' in r and r['scoring']['value'] > 0
+    # two ranks, ONE device (the rehearsal): the line says so
+    assert r['config']['world_size'] == 2 and r['config']['backend'] == 'gloo' and r['config']['distinct_devices'] == 1
+    assert len(r['layers']['rank0']) == 4
 
 
 def test_bench_sharded_path_on_one_rank_rccl(cuda):
@@ -91,8 +155,14 @@ def test_bench_sharded_path_on_one_rank_rccl(cuda):
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     r = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
-    assert r['n_gpus'] == 1 and r['scaling'] == 'strong' and 'row-sharded x1' in r['config']['sharding'] and '3 row chunk' in r['config']['sharding']
+    assert r['n_gpus'] == 1 and 'scaling' not in r and 'row-sharded x1' in r['config']['sharding'] and '3 row chunk' in r['config']['sharding']
     assert r['value'] > 0 and r['scoring']['value'] > 0 and r['roofline']['frac'] > 0
+    # the evidence fields of a multi-GPU line: what RCCL saw, on which devices, and where each layer's time went
+    c = r['config']
+    assert c['world_size'] == 1 and c['backend'] == 'nccl' and len(c['devices']) == 1 and c['distinct_devices'] == 1
+    lay = r['layers']['rank0']
+    assert [x['layer'] for x in lay] == [1, 2, 3, 'final gather'] and all(x['compute_ms'] > 0 for x in lay[:3])
+    assert all(x['wait_on_gather_ms'] >= 0 for x in lay)
 
 
 @pytest.mark.parametrize('d,world', [(64, 2), (64, 4), (64, 8), (128, 4), (256, 8)])

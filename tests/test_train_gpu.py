@@ -142,3 +142,65 @@ def test_c2_training_step_uses_one_regather_per_values(cuda):
     first = ev.seg_vals
     prop.forward(e0, 3, vals=ev)
     assert ev.seg_vals is first
+
+
+@pytest.mark.parametrize('dtype', [torch.int32, torch.int16])
+@pytest.mark.parametrize('where', ['cpu', 'cuda'])
+def test_get_loss_accepts_any_integer_batch_dtype(golden, cuda, dtype, where):
+    """the reference's `users_emb[users]` (base_model.py:189-193) indexes with any integer dtype; the native step reads
+    raw int64 ids, so get_loss converts -- an int32 / int16 batch gives the int64 batch's loss and gradient bit for bit."""
+    g2, g8 = golden('g2_synth60'), golden('g8_loss')
+    batch = torch.from_numpy(g8['drop2_batch'])
+    res = []
+    for b in (batch, batch.to(dtype).to(where)):
+        m = _model(g2, dropout=0.0)
+        assert m._native_loss()
+        m.training = True
+        loss = m.get_loss(b)
+        loss.backward()
+        res.append((float(loss), m.embedding_user.weight.grad.clone(), m.embedding_item.weight.grad.clone()))
+    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+
+
+def test_get_loss_rejects_ids_outside_the_tables(golden, cuda):
+    """a host batch is checked before anything is launched; a device batch is clamped (no kernel sees the bad address) and
+    the step raises at its next flag read -- IndexError either way, as torch's own indexing in the reference"""
+    g2, g8 = golden('g2_synth60'), golden('g8_loss')
+    m = _model(g2, dropout=0.0)
+    m.training = True
+    bad = torch.from_numpy(g8['drop2_batch']).clone()
+    bad[3, 1] = m.n_items            # one past the item table
+    with pytest.raises(IndexError):
+        m.get_loss(bad)
+    neg = torch.from_numpy(g8['drop2_batch']).clone()
+    neg[0, 0] = -1
+    with pytest.raises(IndexError):
+        m.get_loss(neg)
+    with pytest.raises(TypeError):
+        m.get_loss(bad.float())
+    with pytest.raises(ValueError):
+        m.get_loss(bad[:, :2])
+    m.optimizer = torch.optim.Adam(m.parameters(), lr=1e-3)
+    with pytest.raises(IndexError):
+        m._train_epoch([bad.to(cuda)], 1)
+    torch.cuda.synchronize()
+    assert torch.isfinite(m.embedding_user.weight).all() and torch.isfinite(m.embedding_item.weight).all()
+
+
+@pytest.mark.parametrize('deferred', [False, True])
+def test_nan_loss_stops_fit_before_the_weights_take_it(golden, cuda, deferred):
+    """base_model.py:123 asserts on the loss BEFORE backward(): with the default order a NaN loss leaves weights and Adam moments
+    untouched; the opt-in deferred check raises the same AssertionError after the step"""
+    g2, g8 = golden('g2_synth60'), golden('g8_loss')
+    m = _model(g2, dropout=0.0)
+    m.deferred_nan_check = deferred
+    m.optimizer = torch.optim.Adam(m.parameters(), lr=1e-3, fused=True)
+    with torch.no_grad():
+        m.embedding_user.weight[int(g8['drop2_batch'][0, 0]), 0] = float('nan')
+    before = m.embedding_item.weight.detach().clone()
+    with pytest.raises(AssertionError, match='loss is NA'):
+        m._train_epoch([torch.from_numpy(g8['drop2_batch'])], 1)
+    torch.cuda.synchronize()
+    if not deferred:
+        assert torch.equal(m.embedding_item.weight.detach(), before)
+        assert all(len(st) == 0 for st in m.optimizer.state.values())

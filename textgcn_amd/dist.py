@@ -24,7 +24,6 @@ side stream.  Any other backend (gloo) is the CPU / one-GPU rehearsal used by th
 asynchronously by gloo itself, device tensors are staged through host memory.
 """
 import ctypes
-import os
 
 import numpy as np
 import torch
@@ -100,11 +99,11 @@ class _Done:
 class _EventWork:
     """completion of a collective enqueued on a side stream: wait() orders the CURRENT stream after it"""
 
-    def __init__(self, event):
-        self.event = event
+    def __init__(self, event, device):
+        self.event, self.device = event, device
 
     def wait(self):
-        torch.cuda.current_stream().wait_event(self.event)
+        torch.cuda.current_stream(self.device).wait_event(self.event)
 
 
 class CapiComm:
@@ -141,7 +140,7 @@ class CapiComm:
         _capi.check(rc, 'tgcn_allgather_rows')
         ev = torch.cuda.Event()
         ev.record(self.stream)
-        return _EventWork(ev)
+        return _EventWork(ev, self.device)
 
     def close(self):
         if self._comm:
@@ -156,6 +155,19 @@ class ShardedPropagator:
     forward(e0_users_local, e0_items_local) -> (users_local [bu, d], items_table [I_pad, d]): the rank keeps its own
     users (they are scored where they live) and the gathered item table of the layer mean, in table order
     (`items_in_order` puts it back in item-id order).
+
+    LIFETIME of the two results: both are views of this object's reusable buffers (`users_local` of the output block,
+    `items_table` of the ping-pong layer table the last layer was written to) and are valid until the NEXT forward() on this
+    object, which overwrites them from its first launch on.  A consumer that keeps a result across another forward -- scoring
+    overlapped with the next step, a result held through a timing loop -- passes copy=True (or clones): the gathered table is
+    then copied out once (I_pad x d x 4 bytes) and the buffers are free again.
+
+    collective: 'torch' (default; 'auto' means the same) = torch.distributed's communicator, 'capi' = libtgcn's own
+    (tgcn_comm_init_rank / tgcn_allgather_rows).  The choice is an argument only: no environment variable changes it.
+
+    record_events = True makes forward() bracket every half-step's wait-for-gather and its SpMM launches with HIP events on the
+    launch stream; `layer_times()` then returns, per layer, the milliseconds that stream spent computing and the milliseconds it
+    sat waiting for an all-gathered block (bench.py prints them so that a multi-GPU number can be attributed).
     """
 
     def __init__(self, graph: NormGraph, rank, world, device, group=None, split_threshold=DEFAULT_SPLIT_THRESHOLD,
@@ -182,7 +194,7 @@ class ShardedPropagator:
         self._capi_comm = None
         if self.uses_collective and self.backend == 'nccl':
             if collective == 'auto':
-                collective = os.environ.get('TGCN_COLLECTIVE', 'torch')
+                collective = 'torch'
             if collective == 'capi':
                 self._capi_comm = CapiComm(self.rank, self.world, self.device, group)
             elif collective != 'torch':
@@ -194,6 +206,8 @@ class ShardedPropagator:
         self.nnz_local = sum(c.nnz for c in self.csr_u) + sum(c.nnz for c in self.csr_i)
         self._buf = {}
         self._item_order = None
+        self.record_events = False
+        self._events = None
 
     # ------------------------------------------------------------------ construction
     def _chunk_csrs(self, graph, lay, row_origin, remap, split_threshold):
@@ -259,13 +273,39 @@ class ShardedPropagator:
         for w in works:
             w.wait()
 
+    def _mark(self, layer, kind):
+        """record_events: a timed HIP event on the launch stream, tagged (layer, 'wait_begin' | 'wait_end' | 'compute_end')"""
+        if self._events is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(self.device))
+            self._events.append((layer, kind, ev))
+
+    def layer_times(self):
+        """After a forward() with record_events = True (and a device synchronisation): [{layer, compute_ms, wait_on_gather_ms}]
+        per layer (+ layer K + 1 = the final wait for the last item gather), summed over the two half-steps of the layer."""
+        if not self._events:
+            return []
+        torch.cuda.synchronize(self.device)
+        out = {}
+        prev = None
+        for layer, kind, ev in self._events:
+            rec = out.setdefault(layer, {'layer': layer, 'compute_ms': 0.0, 'wait_on_gather_ms': 0.0})
+            if kind == 'wait_end':
+                rec['wait_on_gather_ms'] += prev.elapsed_time(ev)
+            elif kind == 'compute_end':
+                rec['compute_ms'] += prev.elapsed_time(ev)
+            prev = ev
+        return [out[k] for k in sorted(out)]
+
     def _chunks(self, table_part, lay):
         """[(gather target slab, this rank's view of it)] per chunk of one node kind's part of a layer table"""
         return [(table_part[lay.chunk_slab(c)], table_part[lay.my_slab(self.rank, c)]) for c in range(lay.chunks)]
 
     # ------------------------------------------------------------------ forward
-    def forward(self, e0_u, e0_i, n_layers, single=False, exact=False):
-        """e0_u [bu, d], e0_i [bi, d]: this rank's (padded) rows of E0."""
+    def forward(self, e0_u, e0_i, n_layers, single=False, exact=False, copy=False):
+        """e0_u [bu, d], e0_i [bi, d]: this rank's (padded) rows of E0.  The results are views of reusable buffers, dead after
+        the next forward() (class docstring); copy=True returns private copies."""
+        self._events = [] if (self.record_events and self.device.type == 'cuda') else None
         d = e0_u.shape[1]
         b = self.buffers(d)
         x, y = b['x']
@@ -282,7 +322,7 @@ class ShardedPropagator:
         self._wait(pending)
         if n_layers == 0:
             b['out_u'].copy_(e0_u)
-            return b['out_u'], x[self.u_pad:]
+            return (b['out_u'].clone(), x[self.u_pad:].clone()) if copy else (b['out_u'], x[self.u_pad:])
         acc_u, acc_i = b['acc_u'], b['acc_i']
         # Pending gathers of the table being READ (x): users feed the item half-step, items feed the user half-step.
         wait_users, wait_items = [], []
@@ -293,7 +333,9 @@ class ShardedPropagator:
             yi_chunks = self._chunks(y[self.u_pad:], li)
 
             def user_half():   # reads the item rows of x
+                self._mark(k, 'wait_begin')
                 self._wait(wait_items)
+                self._mark(k, 'wait_end')
                 works = []
                 for c in range(C):
                     full, mine = yu_chunks[c]
@@ -305,10 +347,13 @@ class ShardedPropagator:
                                    acc_out=b['out_u'][r] if last else acc_u[r], acc_div=div, exact=exact)
                     if not last:   # users stay where they live after the last layer
                         works.append(self._all_gather(full, mine))
+                self._mark(k, 'compute_end')
                 return works
 
             def item_half():   # reads the user rows of x
+                self._mark(k, 'wait_begin')
                 self._wait(wait_users)
+                self._mark(k, 'wait_end')
                 works = []
                 for c in range(C):
                     full, mine = yi_chunks[c]
@@ -320,6 +365,7 @@ class ShardedPropagator:
                         self._spmm(self.csr_i[c], x, y=None if last else mine, acc_in=e0_i[r] if k == 1 else acc_i[r],
                                    acc_out=mine if last else acc_i[r], acc_div=div, exact=exact)
                     works.append(self._all_gather(full, mine))
+                self._mark(k, 'compute_end')
                 return works
 
             # Alternate the order so that EVERY all-gather overlaps a half-step: the block gathered last in layer
@@ -332,9 +378,13 @@ class ShardedPropagator:
                 nu = user_half()
             wait_users, wait_items = nu, ni
             x, y = y, x
+        self._mark(n_layers + 1, 'wait_begin')
         self._wait(wait_users)
         self._wait(wait_items)
+        self._mark(n_layers + 1, 'wait_end')
         # after the swap, x holds the last layer: its item part is the gathered item table (a view, no copy)
+        if copy:
+            return b['out_u'].clone(), x[self.u_pad:].clone()
         return b['out_u'], x[self.u_pad:]
 
     # ------------------------------------------------------------------ consumers

@@ -131,6 +131,12 @@ class NormGraph:
             return np.maximum.accumulate(b)
         return cut(0, self.n_users), cut(self.n_users, self.n)
 
+    def train_mask(self):
+        """(rowptr int64 [U+1], items int32): every user's train items, ascending and distinct -- the user rows of A with the
+        column offset taken off.  Equal to train_mask_csr(train_u, train_i, U) up to repeated pairs (a mask is idempotent)."""
+        e = int(self.rowptr[self.n_users])
+        return np.asarray(self.rowptr[:self.n_users + 1], dtype=np.int64), (np.asarray(self.colidx[:e]) - np.int32(self.n_users)).astype(np.int32)
+
     def row_block(self, r0, r1):
         """CSR of rows [r0, r1): (rowptr int64 rebased to 0, colidx, vals) -- views, no copy of the big arrays."""
         a, b = int(self.rowptr[r0]), int(self.rowptr[r1])

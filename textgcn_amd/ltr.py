@@ -116,8 +116,10 @@ class LTRLinear(LightGCN):
     def _k(self):
         return _capi.lib().tgcn_ltr_folded_width(self.emb_size, self.text_dim)
 
-    def _fold_users(self, users_emb, emb_ids, text_ids):
-        w, b = self.effective_weights()
+    def _fold_users(self, users_emb, emb_ids, text_ids, wb=None):
+        """[n, K] user operand of the folded GEMM.  wb = effective_weights(): a device-to-host read (a stream sync), so a
+        caller that folds chunk after chunk reads it ONCE and passes it in (predict_tensors)."""
+        w, b = wb if wb is not None else self.effective_weights()
         n = emb_ids.numel() if emb_ids is not None else users_emb.shape[0]
         out = torch.empty((n, self._k()), dtype=torch.float32, device=self.device)
         w5 = (ctypes.c_float * 5)(*[float(x) for x in w[:5]])   # the five dot-product features; subclasses add columns
@@ -173,6 +175,7 @@ class LTRLinear(LightGCN):
         users_emb, items_emb = self.representation
         users_emb, items_emb = users_emb.contiguous(), items_emb.contiguous()
         ia = self._pack_items(items_emb)
+        wb = self.effective_weights()      # the one device-to-host read of the call, before the first chunk is issued
         # the folded operands are 896 / 960 wide: the bf16 candidate pass takes them too (same lists as the fp32 path, bit for bit)
         prefilter = bool(self.score_prefilter) and len(users_np) > 0
         pack = scoring.item_pack(ia) if prefilter else None
@@ -180,15 +183,12 @@ class LTRLinear(LightGCN):
         main = torch.cuda.current_stream(self.device)
         streams = self._predict_streams()       # chunks round-robin on a few streams, as in LightGCN.predict_tensors
         step = max(self.batch_size, self.ltr_predict_chunk)   # no [B, I] matrix to bound: larger calls, fewer launches
-        for n, j in enumerate(range(0, len(users_np), step)):
-            batch = users_np[j:j + step]
-            ids = torch.from_numpy(batch).to(self.device)
-            rp, it = self._batch_mask(batch)
+        for n, (ids, rp, it) in enumerate(self._chunk_masks(users_np, step)):
             slot = n % len(streams)
             side = streams[slot]
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                ua = self._fold_users(users_emb, ids, ids)
+                ua = self._fold_users(users_emb, ids, ids, wb)
                 v, i = scoring.score_topk(ua, ia, kmax, mask_rowptr=rp, mask_items=it, round4=True, slot=slot, prefilter=prefilter,
                                           item_pack=pack)
             for t in (ids, rp, it, ua, v, i):
@@ -234,9 +234,10 @@ class LTRLinearWPop(LTRLinear):
         wide[:, :t.shape[1]] = t
         return wide
 
-    def _fold_users(self, users_emb, emb_ids, text_ids):
-        out = self._widen(super()._fold_users(users_emb, emb_ids, text_ids))
-        w, _ = self.effective_weights()
+    def _fold_users(self, users_emb, emb_ids, text_ids, wb=None):
+        wb = wb if wb is not None else self.effective_weights()
+        out = self._widen(super()._fold_users(users_emb, emb_ids, text_ids, wb))
+        w, _ = wb
         c, _ = self._pop_columns()
         pop = self.popularity_users[:, 0] if text_ids is None else self.popularity_users[text_ids, 0]
         out[:, c] = float(w[5]) * pop

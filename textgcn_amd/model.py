@@ -131,6 +131,9 @@ class LightGCN(nn.Module):
     score_prefilter = True  # predict: candidates from the bf16 matrix pass, scores from the fp32 chains (identical lists and
                             # scores, ~2x the throughput for d <= 128); False: the fp32 MFMA filter finds the candidates
     exact = False   # True: no long-row split -> every row is one fmaf chain (bit-identical to the CPU reference)
+    fused_adam = True
+    deferred_nan_check = False   # False: fit() reads the loss's NaN flag before backward(), as base_model.py:123 does; True: one
+                                 # step later (no pipeline bubble; the weights have then taken two steps with the NaN)
 
     def __init__(self, params, dataset):
         super().__init__()
@@ -345,14 +348,38 @@ class LightGCN(nn.Module):
         """data: [batch, 2 + n_neg] rows (user, positive, negatives...) -> BPR + L2 terms."""
         if not hasattr(self, '_loss_values'):
             self._loss_values = defaultdict(float)
-        cols = data.to(self.device).t()
+        data = torch.as_tensor(data)
+        if data.dim() != 2 or data.shape[1] < 3:
+            raise ValueError(f'get_loss expects [batch, 2 + n_neg] rows (user, positive, negatives...), got {tuple(data.shape)}')
+        if data.dtype.is_floating_point or data.dtype.is_complex or data.dtype == torch.bool:
+            raise TypeError(f'batch ids must be an integer tensor, got {data.dtype}')
         if self._native_loss():
-            bpr, reg = _BprStep.apply(self.embedding_user.weight, self.embedding_item.weight, self, cols.contiguous())
+            bpr, reg = _BprStep.apply(self.embedding_user.weight, self.embedding_item.weight, self, self._checked_ids(data))
             self._loss_values['bpr'] += bpr.detach()
             self._loss_values['reg'] += reg.detach()
             return bpr + reg
+        cols = data.to(self.device).t()
         users, pos, negs = cols[0], cols[1], list(cols[2:])
         return self.bpr_loss(users, pos, negs) + self.reg_loss(users, pos, negs)
+
+    def _checked_ids(self, data):
+        """[2 + n_neg, batch] contiguous int64 ids on the model's device, every id inside its table: the contract of
+        tgcn_bpr_pairs_f32 / tgcn_reg_rows_f32 (include/tgcn.h), which read raw 8-byte ids and add gradient rows at the
+        addresses they name.  The reference's `users_emb[users]` (base_model.py:189-193) takes any integer dtype and raises
+        IndexError on an id outside the table; so does this: a host batch (what a DataLoader yields) is checked before it is
+        copied, without touching the GPU; a device batch is checked by two reductions whose flag is read together with the
+        step's NaN flag, and its ids are clamped meanwhile so that no kernel ever sees an address outside the tables."""
+        lim = torch.tensor([self.n_users] + [self.n_items] * (data.shape[1] - 1), dtype=torch.int64)
+        if data.device.type == 'cpu':
+            d64 = data.to(torch.int64)
+            if data.numel() and bool(((d64 < 0) | (d64 >= lim)).any()):
+                raise IndexError('get_loss: a user or item id of the batch is outside its embedding table')
+            return d64.to(self.device).t().contiguous()
+        d64 = data.to(self.device, torch.int64)
+        lim = lim.to(self.device)
+        bad = ((d64 < 0) | (d64 >= lim)).any()
+        self._bad_ids = bad if getattr(self, '_bad_ids', None) is None else (self._bad_ids | bad)
+        return torch.minimum(d64.clamp_min(0), lim - 1).t().contiguous()
 
     def _native_loss(self):
         """The fused step applies to the plain LightGCN loss: a subclass or instance that replaces a scoring / loss member
@@ -387,27 +414,43 @@ class LightGCN(nn.Module):
         self.train()
         self.training = True
         self._loss_values = defaultdict(float)
-        pending = None                     # the previous step's NaN flag (a device scalar)
+        pending = None                     # deferred mode: the previous step's flags (device scalars)
+        self._bad_ids = None
+
+        def stop_if(flags):
+            nan, bad = flags
+            if bad is not None and bool(bad):
+                raise IndexError(f'get_loss: a user or item id of a batch was outside its embedding table (epoch {epoch})')
+            if bool(nan):
+                raise AssertionError(f'loss is NA at epoch {epoch}')
         for data in batches:
             self.optimizer.zero_grad()
             loss = self.get_loss(data)
-            is_nan = loss.isnan()
+            flags = (loss.isnan(), self._bad_ids)
+            self._bad_ids = None
+            if not self.deferred_nan_check:
+                stop_if(flags)             # base_model.py:123: before backward(), so a NaN never reaches the weights or Adam's moments
             loss.backward()
             self.optimizer.step()
-            # base_model.py:123 checks the loss before backward(); here the flag of step t - 1 is read once step t is enqueued,
-            # so the only host sync of a step never leaves the GPU without queued work (~0.1 ms of a 1.5 ms step on config 2).
-            # A NaN still stops the run with the same AssertionError, one step later.
-            if pending is not None and bool(pending):
-                raise AssertionError(f'loss is NA at epoch {epoch}')
-            pending = is_nan
-        if pending is not None and bool(pending):
-            raise AssertionError(f'loss is NA at epoch {epoch}')
+            if self.deferred_nan_check:
+                # opt-in: the flag of step t - 1 is read once step t is enqueued, so the step's only host sync never leaves the
+                # GPU without queued work (~0.1 ms of a 1.5 ms step on config 2).  A NaN stops the run with the same
+                # AssertionError one step later -- AFTER two optimizer steps have seen it: only for runs that discard the
+                # model on that error.
+                if pending is not None:
+                    stop_if(pending)
+                pending = flags
+        if pending is not None:
+            stop_if(pending)
 
     def fit(self, batches):
         """Adam over all parameters; every `evaluate_every` epochs: log losses, evaluate, checkpoint, early stop.
         A run that is never stopped early writes a final checkpoint (the reference's for/else)."""
-        # same update rule as the reference's torch.optim.Adam (base_model.py:110); `fused` = one launch per step on the GPU
-        self.optimizer = torch.optim.Adam(self.parameters(), lr=self.lr, fused=self.device.type == 'cuda')
+        # same update rule as the reference's torch.optim.Adam (base_model.py:110).  `fused` = one launch per step on the GPU
+        # instead of the default implementation's per-tensor foreach ops: same formulas, but the fused kernel evaluates
+        # them in a different operation order, so the weights differ from a foreach/for-loop Adam in the last bits (they
+        # are not pinned by a golden; G8 pins loss and gradient).  `fused_adam = False` restores torch's default.
+        self.optimizer = torch.optim.Adam(self.parameters(), lr=self.lr, fused=self.device.type == 'cuda' and self.fused_adam)
         stopped = False
         for epoch in range(1, self.epochs + 1):
             self._train_epoch(batches, epoch)
@@ -440,26 +483,42 @@ class LightGCN(nn.Module):
             self.logger.info(f'{m:11}' + ' '.join([f'{j:.4f}' for j in results[m]]))
         return results
 
-    def _batch_mask(self, batch_users, ids=None):
-        """device CSR (rowptr int32 [B+1], items int32) of the train items of `batch_users`, cut out of the device mask CSR:
-        a contiguous id range is a view of it (no copy); any other list is one device gather.  The host only does O(B)
-        numpy arithmetic on the row pointers -- no per-user loop."""
+    def _chunk_masks(self, users, step):
+        """[(ids int64 [b], mask rowptr int32 [b + 1], mask items int32)] on the device for the consecutive `step`-user chunks of
+        `users`, cut out of the device mask CSR.  The whole call costs ONE host-to-device copy (the ids): the row pointers are
+        a device cumsum of counts read from the device CSR, a contiguous id range takes its items as a view, any other list by
+        one device gather; the host only does O(len(users)) numpy arithmetic on its copy of the row pointers (for the sizes)
+        and never waits for the GPU."""
         rp = self._mask_rowptr_host
-        cnt = rp[batch_users + 1] - rp[batch_users]
-        rowptr = np.zeros(len(batch_users) + 1, dtype=np.int32)
-        np.cumsum(cnt, out=rowptr[1:])
-        rowptr_dev = torch.from_numpy(rowptr).to(self.device)
-        _, items_dev = self._mask()
-        total = int(rowptr[-1])
-        if total == 0:
-            return rowptr_dev, items_dev[:1] if items_dev.numel() else torch.zeros(1, dtype=torch.int32, device=self.device)
-        if len(batch_users) and np.all(np.diff(batch_users) == 1):
-            return rowptr_dev, items_dev[int(rp[batch_users[0]]):int(rp[batch_users[-1] + 1])]
-        if ids is None:
-            ids = torch.from_numpy(batch_users).to(self.device)
-        starts = torch.from_numpy(rp[batch_users]).to(self.device)
-        shift = torch.repeat_interleave(starts - rowptr_dev[:-1].to(torch.int64), torch.from_numpy(cnt).to(self.device), output_size=total)
-        return rowptr_dev, items_dev[shift + torch.arange(total, device=self.device)]
+        rp_dev, items_dev = self._mask()
+        ids_all = torch.from_numpy(np.ascontiguousarray(users)).to(self.device)
+        start_all = rp_dev[ids_all]
+        cnt_all = rp_dev[ids_all + 1] - start_all
+        cnt_host = rp[users + 1] - rp[users]
+        out = []
+        for j in range(0, len(users), step):
+            batch = users[j:j + step]
+            ids, cnt = ids_all[j:j + step], cnt_all[j:j + step]
+            rowptr = torch.zeros(len(batch) + 1, dtype=torch.int32, device=self.device)
+            torch.cumsum(cnt, 0, out=rowptr[1:])
+            total = int(cnt_host[j:j + step].sum())
+            if total == 0:
+                items = items_dev[:1] if items_dev.numel() else torch.zeros(1, dtype=torch.int32, device=self.device)
+            elif np.all(np.diff(batch) == 1):
+                items = items_dev[int(rp[batch[0]]):int(rp[batch[-1] + 1])]
+            else:
+                shift = torch.repeat_interleave(start_all[j:j + step] - rowptr[:-1].to(torch.int64), cnt, output_size=total)
+                items = items_dev[shift + torch.arange(total, device=self.device)]
+            out.append((ids, rowptr, items))
+        return out
+
+    def _batch_mask(self, batch_users, ids=None):
+        """(mask rowptr, mask items) of one batch (see _chunk_masks)"""
+        batch_users = np.asarray(batch_users, dtype=np.int64)
+        if len(batch_users) == 0:
+            return torch.zeros(1, dtype=torch.int32, device=self.device), torch.zeros(1, dtype=torch.int32, device=self.device)
+        _, rowptr, items = self._chunk_masks(batch_users, len(batch_users))[0]
+        return rowptr, items
 
     @torch.no_grad()
     def predict(self, users, save: bool = False, with_scores: bool = False):
@@ -495,10 +554,7 @@ class LightGCN(nn.Module):
         # the item-side factor of its error bound is computed once for the whole predict call
         prefilter = bool(getattr(self, 'score_prefilter', True)) and not custom
         item_pack = scoring.item_pack(items_emb) if prefilter and len(users) else None
-        for n, j in enumerate(range(0, len(users), step)):
-            batch = users[j:j + step]
-            ids = torch.from_numpy(batch).to(self.device)
-            rp, it = self._batch_mask(batch, ids)
+        for n, (ids, rp, it) in enumerate(self._chunk_masks(users, step)):
             slot = n % len(streams)
             side = streams[slot]
             side.wait_stream(main)          # inputs (and the representation) are produced on the main stream
