@@ -66,8 +66,10 @@ def spmm_sources_sha16():
 
 
 def load_traffic(workload):
-    """(HBM bytes per layer launch, source note) from the rocprofv3 PMC pass under profiles/ -- a recorded figure, not
-    measured in this run; dropped (None) when the SpMM sources differ from the ones the pass was taken on."""
+    """(fabric-side bytes per layer launch, source note) from the rocprofv3 PMC pass under profiles/ -- a recorded figure, not
+    measured in this run; dropped (None) when the SpMM sources differ from the ones the pass was taken on.  The counters sit on
+    the L2's memory side: Infinity-Cache hits are INSIDE the figure (profiles/r03_gather_calibration.json), so it is L2-miss
+    traffic, an upper bound of the HBM bytes."""
     p = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
     try:
         ent = json.load(open(p)).get(workload)
@@ -75,11 +77,46 @@ def load_traffic(workload):
         ent = None
     if not ent:
         return None, 'no PMC pass recorded for this workload (profiles/hbm_traffic.json)'
-    src = (f"profiles/hbm_traffic.json[{workload}]: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of round {ent.get('round')}, "
-           f"kernels {ent.get('kernels') or ent.get('kernel')}, FETCH_SIZE x2 + WRITE_SIZE; recorded, not measured in this run")
+    f = ent.get('factors') or {}
+    how = (f"TCC_EA0_RDREQ_DRAM_32B_sum x 32 B x {f.get('RDREQ_DRAM_32B_x32', 1):.3f}" if ent.get('read_bytes_from_RDREQ_DRAM_32B')
+           else f"FETCH_SIZE x {f.get('FETCH_SIZE', 2):.3f}") + f" + WRITE_SIZE x {f.get('WRITE_SIZE', 1):.3f}"
+    src = (f"profiles/hbm_traffic.json[{workload}]: rocprofv3 --pmc passes of round {ent.get('round')}, kernels "
+           f"{ent.get('kernels') or ent.get('kernel')}, {how} (factors measured on known-traffic gathers: {f.get('source', 'n/a')}); "
+           f"L2-miss bytes incl. Infinity-Cache hits; recorded, not measured in this run")
     if ent.get('sources_sha16') != spmm_sources_sha16():
         return None, src + ' -- STALE: the SpMM sources changed since that pass, figure withheld'
-    return ent.get('hbm_bytes_per_layer'), src
+    return ent.get('fabric_bytes_per_layer', ent.get('hbm_bytes_per_layer')), src
+
+
+INFINITY_CACHE_BYTES = 256 << 20      # MI355X_MICROARCH.md: 256 MiB die-level L3
+
+
+def hbm_bytes_model(deg, nnz, n_rows, d, fabric_bytes):
+    """HBM bytes of one layer launch under an IDEAL Infinity Cache -- a model, because rocprofv3 on gfx950 exposes no counter
+    behind that cache (no MALL / UMC block; every TCC_EA counter includes its hits: profiles/r03_gather_calibration.json).
+    Streams touched once per layer (CSR entries, row pointers, the layer-sum read, every store) go to HBM whenever the layer's
+    footprint exceeds the cache; of the gather misses the cache can at best keep the most-referenced rows that fit its 256 MiB
+    (row c is gathered deg(c) times per layer) -- share h of the gathers.  Returns a dict; `bytes` is None when the whole
+    per-layer footprint fits the cache (then HBM sees next to nothing after the first layer, and the launch is bound by the
+    caches, not by HBM)."""
+    row = 4 * d
+    stream_read = nnz * 8 + (n_rows + 1) * 4 + n_rows * row          # CSR + rowptr + acc_in
+    stores = 2 * n_rows * row                                          # Y + acc_out
+    footprint = stream_read + stores + n_rows * row                   # + the gathered table
+    out = {'what': 'ideal-LRU Infinity Cache model (no counter exists behind that cache on gfx950): streamed-once bytes + the gather '
+                   'misses the 256 MiB cache cannot hold', 'layer_footprint_bytes': int(footprint)}
+    if fabric_bytes is None:
+        return out
+    if footprint <= INFINITY_CACHE_BYTES:
+        out.update(bytes=None, note='the layer footprint fits the 256 MiB Infinity Cache: the fabric-side traffic can be served on-die; '
+                                    'HBM is not the binding level for this workload')
+        return out
+    top = np.sort(np.asarray(deg))[::-1][:INFINITY_CACHE_BYTES // row]
+    h = float(top.sum()) / float(nnz)
+    gather_fabric = max(fabric_bytes - stream_read - stores, 0.0)
+    out.update(bytes=int(stream_read + stores + gather_fabric * (1.0 - h)), cacheable_gather_share=round(h, 4),
+               gather_fabric_bytes=int(gather_fabric), streamed_once_bytes=int(stream_read + stores))
+    return out
 
 
 def cpu_threads_note():
@@ -187,17 +224,24 @@ def random_row_rate(n_rows, d, dev, entries=1 << 23):
     return len(cols) * 4.0 * d / (ev0.elapsed_time(ev1) / 1e3 / reps)
 
 
-def spmm_roofline(nnz_local, n_rows_local, n_src, d, K, t_dev, steps, traffic, traffic_src, dev, gather=True):
+def spmm_roofline(nnz_local, n_rows_local, n_src, d, K, t_dev, steps, traffic, traffic_src, dev, gather=True, deg=None):
     layer_bytes = [algorithmic_bytes_per_layer(nnz_local, n_rows_local, n_src, d, k, K, False) for k in range(1, K + 1)]
     mean_layer_s = t_dev / (steps * K)
     achieved = float(np.mean(layer_bytes)) / mean_layer_s / 1e9
     r = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
          'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
-         # recorded memory-side bytes (PMC pass, profiles/) over the live launch time: what the fabric moves
+         'traffic_kind': "L2-miss bytes on the L2's fabric side; Infinity-Cache hits included, so NOT an HBM byte count",
+         # recorded fabric-side bytes (PMC pass, profiles/) over the live launch time: what the fabric moves
          'traffic_GBs': round(traffic / mean_layer_s / 1e9, 1) if traffic else None,
          'kernel': 'one SpMM layer (k_spmm_seg + k_spmm_seg_reduce, or k_spmm_wave + k_spmm_long_reduce)',
          'algorithmic_bytes_per_launch': int(np.mean(layer_bytes)), 'launch_us': round(mean_layer_s * 1e6, 2),
          'gather_model_GBs': round((nnz_local * (8 + 4 * d) + n_rows_local * d * 4) / mean_layer_s / 1e9, 1)}
+    if deg is not None:
+        m = hbm_bytes_model(deg, nnz_local, n_rows_local, d, traffic)
+        if m.get('bytes'):
+            m['GBs'] = round(m['bytes'] / mean_layer_s / 1e9, 1)
+            m['frac_of_hbm_peak'] = round(m['bytes'] / mean_layer_s / 1e9 / HBM_PEAK_GBS, 4)
+        r['hbm_bytes_model'] = m
     if gather:
         rate = random_row_rate(n_src, d, dev)
         t_gather = nnz_local * 4.0 * d / rate
@@ -288,7 +332,7 @@ def record_c4_one_gpu(dev, steps=5, warmup=2, cpu=True):
            'config': {'workload': f'c4: U={n_u} I={n_i} nnz={nnz} d={d} K={K}', 'nnz_A': graph.nnz, 'n_nodes': graph.n,
                       'max_degree': int(graph.degrees().max()), 'sharding': 'none (whole graph on one GPU)',
                       'graph_build_s': round(build_s, 1)},
-           'roofline': spmm_roofline(graph.nnz, graph.n, graph.n, d, K, t_dev, steps, traffic, tsrc, dev)}
+           'roofline': spmm_roofline(graph.nnz, graph.n, graph.n, d, K, t_dev, steps, traffic, tsrc, dev, deg=graph.degrees())}
     if cpu:
         # CPU sample: the layer-1 product of the first user rows holding ~10 M stored entries (the full forward is ~25 s per
         # layer on torch's single-threaded COO kernel); the same rows of the GPU's layer 1 are checked against it
@@ -391,7 +435,7 @@ def records_c3_c5(dev, want_c5=True, cpu=True):
           'steps': reps, 'ms_per_step': t_fwd * 1e3, 'dtype': 'f32', 'data': 'synthetic',
           'config': {'workload': f'c3: U={n_u} I={n_i} nnz={nnz} d={d} K={K}', 'nnz_A': g.nnz, 'graph_build_s': round(build_s, 1),
                      'through': 'textgcn_amd.LightGCN.representation / predict_tensors'},
-          'roofline': spmm_roofline(g.nnz, g.n, g.n, d, K, t_fwd, 1, traffic, tsrc, dev),
+          'roofline': spmm_roofline(g.nnz, g.n, g.n, d, K, t_fwd, 1, traffic, tsrc, dev, deg=g.degrees()),
           'scoring': {'metric': 'scored user-item pairs/sec (full catalogue: every user x every item, mask + top-40 fused)',
                       'value': pairs / t_score, 'unit': 'pairs/s', 'ms_total': t_score * 1e3,
                       'roofline': {'bound': 'mfma', 'achieved': round(2.0 * d * pairs / t_score / 1e12, 2), 'peak': MFMA_F32_PEAK_TF,
@@ -693,7 +737,8 @@ def main():
     else:
         traffic, tsrc = None, 'no PMC pass for this mode'
     d_local = sp.dl if (sharded and args.shard == 'features') else d
-    roofline = spmm_roofline(nnz_local, n_rows_local, n_src, d_local, K, t_dev, args.steps, traffic, tsrc, dev, gather=not sharded)
+    roofline = spmm_roofline(nnz_local, n_rows_local, n_src, d_local, K, t_dev, args.steps, traffic, tsrc, dev, gather=not sharded,
+                             deg=None if sharded else graph.degrees())
     if sharded:
         roofline['note'] = 'per rank: this rank\'s row blocks, launch time includes waiting for the all-gathered tables'
 

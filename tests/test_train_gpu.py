@@ -148,7 +148,8 @@ def test_c2_training_step_uses_one_regather_per_values(cuda):
 @pytest.mark.parametrize('where', ['cpu', 'cuda'])
 def test_get_loss_accepts_any_integer_batch_dtype(golden, cuda, dtype, where):
     """the reference's `users_emb[users]` (base_model.py:189-193) indexes with any integer dtype; the native step reads
-    raw int64 ids, so get_loss converts -- an int32 / int16 batch gives the int64 batch's loss and gradient bit for bit."""
+    raw int64 ids, so get_loss converts -- an int32 / int16 batch gives the int64 batch's loss and gradient (the gradient rows
+    are added by float atomics, whose order differs from run to run: compared normwise)."""
     g2, g8 = golden('g2_synth60'), golden('g8_loss')
     batch = torch.from_numpy(g8['drop2_batch'])
     res = []
@@ -158,8 +159,8 @@ def test_get_loss_accepts_any_integer_batch_dtype(golden, cuda, dtype, where):
         m.training = True
         loss = m.get_loss(b)
         loss.backward()
-        res.append((float(loss), m.embedding_user.weight.grad.clone(), m.embedding_item.weight.grad.clone()))
-    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+        res.append((float(loss), m.embedding_user.weight.grad.cpu().numpy(), m.embedding_item.weight.grad.cpu().numpy()))
+    assert res[0][0] == res[1][0] and normwise(res[1][1], res[0][1]) <= 1e-6 and normwise(res[1][2], res[0][2]) <= 1e-6
 
 
 def test_get_loss_rejects_ids_outside_the_tables(golden, cuda):

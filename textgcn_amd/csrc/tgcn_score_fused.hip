@@ -714,7 +714,7 @@ __device__ __forceinline__ void select_core(const unsigned (&key)[VPL], const in
 // from there the path is the narrow rows' (scores > tau_u kept, k_select_flat, fallback).  Non-finite R or bound: survives,
 // never counted towards k.  One wave per user; train items are dropped here already.
 struct RefineArgs {
-    const float2 *__restrict__ logs;   // [B][2 S][cap2]
+    const float2 *__restrict__ logs;   // [B][2 S][cap2]  (S = twice the wide filter's splits: 4 segments per split)
     const int *__restrict__ counts;    // [B][2 S]
     const int *__restrict__ mask_rowptr;
     const int *__restrict__ mask_items;
@@ -1158,6 +1158,7 @@ __global__ __launch_bounds__(kBruteWaves * 64) void k_brute_part(const BruteArgs
 
 struct Plan {
     int S, items_per_split, cap2, m, m_ld;  // m = sampled items
+    int S_w, ips_w;                         // wide bf16 filter: its own (at most 16) item splits -- 4 log segments per split and user
     int Wh;                                 // mask words per (user, row half): the 64-item units of the catalogue, padded to 4
     size_t off_mask;
     size_t off_sample, off_tauv, off_taui, off_tau, off_ubound, off_ipack, off_logs, off_counts, off_parts, off_flags, off_done, off_totals, off_surv, off_surv_n, total;
@@ -1202,8 +1203,16 @@ Plan make_plan(int B, int I, int d, int k)
     p.off_mask = o;
     if (prefilter_supports(d))
         o += align256((size_t)((B + 255) / 256) * 256 * 2 * p.Wh * sizeof(unsigned));   // rows of the bf16 filter's padded users
-    p.off_logs = o, o += align256((size_t)B * p.S * 2 * p.cap2 * sizeof(float2));
-    p.off_counts = o, o += align256((size_t)B * p.S * 2 * sizeof(int));
+    // the wide bf16 filter (K split between two waves per SIMD) logs into 4 segments per (user, split) -- (tile, row half) of the
+    // lane that finished the pair -- and k_refine reads one segment per lane: at most 16 splits, merged from the plan's
+    {
+        const int f = (p.S + 15) / 16;
+        p.ips_w = f * p.items_per_split;
+        p.S_w = (I + p.ips_w - 1) / p.ips_w;
+    }
+    const int n_seg = (d > 128 && prefilter_supports(d)) ? max(2 * p.S, 4 * p.S_w) : 2 * p.S;
+    p.off_logs = o, o += align256((size_t)B * n_seg * p.cap2 * sizeof(float2));
+    p.off_counts = o, o += align256((size_t)B * n_seg * sizeof(int));
     p.flag_cap = B;   // every user may need the fallback (e.g. fully tied scores): 16 KB of partial lists each
     p.off_parts = o, o += align256((size_t)p.flag_cap * kBruteSplits * kWave * sizeof(float2));
     p.off_flags = o, o += align256((size_t)(B + 1) * sizeof(int));
@@ -1372,15 +1381,12 @@ int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const fl
             // wide rows: the filter logs its candidates (k_select's segment layout: the plan's splits), k_refine keeps those that
             // can still reach the top k, the fp32 chains run on what is left
             int *surv = reinterpret_cast<int *>(ws + p.off_surv), *surv_n = reinterpret_cast<int *>(ws + p.off_surv_n);
-            // calls with many user tiles take half the plan's splits: a workgroup's prologue (its 128 x d user tile, ~16 us) is
-            // then paid half as often
-            const bool few = (B + 127) / 128 >= 16 && p.S >= 16 && p.S % 2 == 0;
-            const int S_w = few ? p.S / 2 : p.S, ips_w = few ? 2 * p.items_per_split : p.items_per_split;
-            if ((rc = launch_prefilter_wide(U, user_ids, B, ipack, I, d, tau_ptr, tau_stride, ubound, fa.logs, fa.counts, S_w, ips_w,
+            // at most 16 splits (make_plan): 4 lane-private log segments per split and user, 64 segments = one per lane of k_refine
+            if ((rc = launch_prefilter_wide(U, user_ids, B, ipack, I, d, tau_ptr, tau_stride, ubound, fa.logs, fa.counts, p.S_w, p.ips_w,
                                             p.cap2, s)) != TGCN_OK)
                 return rc;
             RefineArgs ra{fa.logs, fa.counts, mask_rowptr, mask_items, ubound, static_cast<const unsigned char *>(ipack), pack_row_bytes(d),
-                          surv, surv_n, kRefineCap, B, S_w, p.cap2, k};
+                          surv, surv_n, kRefineCap, B, 2 * p.S_w, p.cap2, k};
             hipLaunchKernelGGL(k_refine, dim3((B + 3) / 4), dim3(256), 0, s, ra);
             if ((rc = check_launch("k_refine")) != TGCN_OK)
                 return rc;

@@ -479,14 +479,21 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
 }
 
 // ---- the bf16 filter for wide rows (128 < d <= 1024, d % 8 == 0: the folded ltr_linear operands, K = 896 / 960) -----------
-// Same test, same pass bits, same pack (rows of 32 KS + 16 bytes).  The users' fragments stay in registers for the whole launch
-// (32 users per wave, 4 KS registers per lane: one wave per SIMD with the 512-register budget), the items pass through LDS in
-// stages of 64 rows x 256 elements (the K chunks of a 64-item unit follow each other, the accumulators persist across them), and
-// the bound's k-step and the tests follow the unit's last chunk -- 32 tests against 2 KS + 2 MFMAs, so nothing is deferred here.
+// Same test, same pack (rows of 32 KS + 16 bytes).  The users' fragments stay in registers for the whole launch; a row is too wide
+// for one wave to hold 32 users' fragments AND leave the SIMD a second wave (4 KS registers per lane: 240 of 512 at K = 960 --
+// round 2's form, one wave per SIMD, had the matrix pipe 20 % busy: every wait, barrier and log append of the SIMD's only wave was
+// exposed).  So K is SPLIT between two waves: a workgroup is 8 waves, waves w and w + 4 (one SIMD) share 32 users, each holds the
+// fragments of HALF the k-steps (2 KS registers: 120 at K = 960, two waves per SIMD fit the 256-register budget) and accumulates
+// its half of the dot products of the unit's 64 items x 32 users; at the end of a unit each wave hands the partial sums of ONE
+// 32-item tile to its partner through LDS (16 registers each way) and finishes the other tile: adds, the bound's k-step (in wave
+// 0's sums), tests and appends for 32 items.  One wave's waits, LDS traffic and appends now run under its partner's MFMAs.
+// The items pass through LDS in stages of 64 rows x CK k-steps (CK = half the row where LDS allows: two barriers per unit), the
+// row's factor chunk rides in the LDS row's 16-byte pad; a stage is requested one stage ahead (a stage is ~2 x 15 x 2 MFMAs of
+// 32 cycles on a SIMD: more than a memory round trip).
 struct PreWideArgs {
     PreArgs p;                      // (mask / Wh unused here)
-    float2 *__restrict__ logs;      // [B][2 S][cap2] lane-private segments of (approx + bound, item), segment = split * 2 + row half
-    int *__restrict__ counts;       // [B][2 S] entries appended (may exceed cap2: the user then takes the exact fallback)
+    float2 *__restrict__ logs;      // [B][4 S][cap2] lane-private segments of (approx + bound, item), segment = split * 4 + tile * 2 + row half
+    int *__restrict__ counts;       // [B][4 S] entries appended (may exceed cap2: the user then takes the exact fallback)
     int S, cap2;
     // SAMPLE form: "item" t is row t * row_stride of the pack, the plain approximate scores go to sample[user * sample_ld + t]
     // (the threshold sample k_tau ranks: as an fp32 GEMM over the strided rows it cost a fifth of the whole filter)
@@ -495,77 +502,117 @@ struct PreWideArgs {
     int64_t sample_ld;
 };
 
+// k-steps per LDS stage: three stage buffers of 64 rows (one multiplied, two in flight) beside the exchange buffer in 160 KB
+template <int KS>
+struct WideStage {
+    static constexpr int CK = KS <= 16 ? 8 : KS <= 32 ? 16 : KS == 56 ? 14 : KS == 60 ? 20 : 16;
+};
+
+// s_waitcnt vmcnt(N) alone (gfx9 encoding: vmcnt in bits 3:0 and 15:14, expcnt 6:4 and lgkmcnt 11:8 left at their maxima)
+template <int N>
+__device__ __forceinline__ void wait_vmcnt()
+{
+    static_assert(N >= 0 && N < 64, "vmcnt");
+    __builtin_amdgcn_s_waitcnt((N & 0xF) | ((N >> 4) << 14) | (0x7 << 4) | (0xF << 8));
+}
+
+// One LDS-DMA piece: every lane's 16 bytes at `src` land at LDS offset lds_base + 16 lane (global_load_lds_dwordx4; M0 carries the
+// wave-uniform LDS offset, one wait state behind the write of M0).  As inline assembly ON PURPOSE: through
+// __builtin_amdgcn_global_load_lds hipcc's wait-count pass puts s_waitcnt vmcnt(0) in front of the next ds_read of ANY LDS
+// address (it cannot tell the ring's buffers apart), i.e. right behind the request -- no prefetch left.  Hidden from that pass,
+// the requests are ordered by hand (wait_vmcnt<N> + the stage barrier).  An uncounted VMEM operation can only make a
+// compiler-placed vmcnt wait longer, never shorter: returns are in issue order.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"      // "clobber list contains reserved registers: m0" -- it is written here
+__device__ __forceinline__ void lds_dma16(const void *src, unsigned lds_base)
+{
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_base), "v"(src) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+
 template <int KS, bool SAMPLE>
-__global__ __launch_bounds__(256) void k_score_prefilter_wide(const PreWideArgs wa)
+__global__ __launch_bounds__(512) void k_score_prefilter_wide(const PreWideArgs wa)
 {
     const PreArgs &a = wa.p;
-    constexpr int T = 256, UT = 128;
+    constexpr int UT = 128;
     constexpr int RBG = 32 * KS + 16;          // pack row
-    constexpr int CK = KS >= 32 ? 16 : 8;      // k-steps per LDS stage (an even number of stages per unit: the register sets
-                                               // below alternate by stage parity)
-    constexpr int NCH = (KS + CK - 1) / CK;
-    constexpr int RBL = 32 * CK + 16;          // LDS row: 512 bytes of the chunk + 16 (conflict-free ds_read_b128 down a column slice)
-    constexpr int PPR = 2 * CK;                        // 16-byte pieces of a row's chunk
-    constexpr int NP = kStage * PPR / T;               // ... of a stage per thread
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2][kStage * RBL];
-    __shared__ __attribute__((aligned(16))) uint4 sfac[2][kStage];          // the rows' factor chunks (bound step), per unit
+    constexpr int CK = WideStage<KS>::CK;      // k-steps per stage
+    static_assert(KS % CK == 0 && CK % 2 == 0 && KS / CK >= 2, "stages per row");
+    constexpr int NCH = KS / CK;
+    constexpr int HK = CK / 2;                 // ... of which a wave multiplies half
+    constexpr int KH = KS / 2;                 // k-steps whose user fragments a wave holds
+    constexpr int RBL = 32 * CK + 16;          // LDS row: the chunk + 16 bytes (conflict-free ds_read_b128 down a column slice: 8 CK + 4
+                                               // dwords = 4 x odd, so 16 rows that differ mod 16 cover the 64 banks); the pad holds the
+                                               // row's factor chunk
+    constexpr int SBYTES = kStage * RBL;       // a stage = SBYTES contiguous bytes of LDS
+    constexpr int NPIECE = (SBYTES + 1023) / 1024;     // ... moved as 1 KB pieces, one per wave instruction (16 bytes per lane)
+    constexpr int NPW = (NPIECE + 7) / 8;              // pieces per wave and stage (the same count for every wave: waits are counted)
+    constexpr int SBUF = NPIECE * 1024;
+    static_assert(3 * SBUF + 4 * 2 * 16 * kWave * 4 <= 160 * 1024, "LDS");
+    // Stages travel by LDS-DMA (global_load_lds_dwordx4: 16 bytes per lane straight into LDS, no staging registers -- the users'
+    // fragments need them) into a ring of three buffers: stage s + 2 is requested when stage s starts, so a request has two
+    // stages (~2 x 2 x HK x 2 MFMAs of 32 cycles) to land.  With one stage of lead (round-3 first form, through registers) the
+    // waves spent 58 % of their time in s_waitcnt / s_barrier: the pack (116 MB at config 5) comes from the Infinity Cache, a
+    // loaded round trip is longer than a stage.
+    __shared__ __attribute__((aligned(16))) unsigned char smem[3][SBUF];
+    __shared__ __attribute__((aligned(16))) float xbuf[4][2][16 * kWave];   // [user group][sending half][register][lane]
     const int lane = lane_id();
-    const int w = threadIdx.x >> 6;
+    const int w = uniform(threadIdx.x >> 6);
+    const int ug = w & 3, hk = w >> 2;                 // waves ug and ug + 4 land on one SIMD (dispatch order 0 -> 2 -> 1 -> 3)
     const int r32 = lane & 31;
     const int h = lane >> 5;
-    // (A linear grid with all user tiles of a split on ONE XCD -- they stream the same 3.7 MB slice of the pack -- was measured:
-    // 1573 us against 1508-1562 for this plain grid at 8192 users, K = 960: the launch is not bound by where the slices come from.
-    // Fragment reads four k-steps ahead instead of two: 1680 against 1671.)
     const int u0 = blockIdx.x * UT;
     const int i_beg = blockIdx.y * a.items_per_split;
     const int i_end = min(a.I, i_beg + a.items_per_split);
     if (i_beg >= i_end)
         return;
-    const int user = u0 + w * 32 + r32;
+    const int user = u0 + ug * 32 + r32;
     const bool user_ok = user < a.B;
 
-    // stage (unit t0, chunk ch): piece p of thread = row p / 32, 16-byte column p % 32 of the chunk; every load unconditional
-    // (addresses past the pack clamp to its last 16 bytes; columns past the row belong to k-steps that do not exist)
-    auto load_stage = [&](u32x4 (&v)[NP], u32x4 &fac, int t0, int ch) {
+    // stage (unit t0, chunk ch) -> ring buffer `buf`: LDS byte o of the stage is byte o % RBL of row o / RBL; its source is the
+    // chunk's bytes of the pack row, or (the pad) the row's factor chunk.  Every request unconditional: rows past the table clamp
+    // to its last row, a piece past the stage's last one repeats it (the same bytes to the same place).  What does not depend on
+    // the stage is computed once per lane and piece (row, column part): a request is an add, a min, a 64-bit multiply-add.
+    int prow[NPW], pcol[NPW];       // row inside the stage; byte inside the pack row for chunk 0 (the pad: the factor chunk, bit 30 set)
 #pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const int pc = i * T + threadIdx.x;
-            const size_t off = (size_t)(t0 + pc / PPR) * wa.row_stride * RBG + (size_t)ch * (32 * CK) + (size_t)(pc % PPR) * 16;
-            v[i] = *reinterpret_cast<const u32x4 *>(a.ipack + min(off, a.pack_bytes - 16));
-        }
-        const size_t foff = (size_t)(t0 + min((int)threadIdx.x, kStage - 1)) * wa.row_stride * RBG + 32 * KS;
-        fac = *reinterpret_cast<const u32x4 *>(a.ipack + min(foff, a.pack_bytes - 16));
-    };
-    auto store_stage = [&](int buf, const u32x4 (&v)[NP], const u32x4 &fac, int fac_buf /* < 0: not a unit's first chunk */) {
+    for (int i = 0; i < NPW; ++i) {
+        const int pc = min(w + 8 * i, NPIECE - 1);                 // wave-uniform
+        const int o = min(pc * 1024 + lane * 16, SBYTES - 16);
+        prow[i] = o / RBL;
+        const int q = o - prow[i] * RBL;
+        pcol[i] = q < 32 * CK ? q : (32 * KS) | (1 << 30);
+    }
+    const int last_row = (int)(a.pack_bytes / RBG) - 1;            // rows of the pack
+    const unsigned row_pitch = (unsigned)wa.row_stride * RBG;
+    const int last_t = last_row / wa.row_stride;
+    auto request = [&](int buf, int t0, int ch) {
 #pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            const int pc = i * T + threadIdx.x;
-            *reinterpret_cast<u32x4 *>(smem[buf] + (pc / PPR) * RBL + (pc % PPR) * 16) = v[i];
+        for (int i = 0; i < NPW; ++i) {
+            const int pc = min(w + 8 * i, NPIECE - 1);
+            const unsigned col = (pcol[i] >> 30) ? (unsigned)(pcol[i] & 0xFFFFFF) : (unsigned)(pcol[i] + ch * (32 * CK));
+            const size_t off = (size_t)(unsigned)min(t0 + prow[i], last_t) * row_pitch + col;
+            lds_dma16(a.ipack + off, uniform((int)(unsigned)(uintptr_t)(smem[buf] + pc * 1024)));
         }
-        if (fac_buf >= 0 && threadIdx.x < kStage)
-            *reinterpret_cast<u32x4 *>(&sfac[fac_buf][threadIdx.x]) = fac;
     };
-    // stage s + 2 is requested while stage s is multiplied: one stage is ~1000 cycles of MFMA for the SIMD's only wave, less than a
-    // memory round trip -- with the request one stage ahead every stage ended waiting for its successor (1.67 -> 1.53 ms per
-    // 8192-user call at K = 960).  Two register sets: stage parity picks the set (NCH is even).
-    static_assert(NCH % 2 == 0, "stage parity");
-    u32x4 setA[NP], setB[NP], facA, facB;
-    load_stage(setA, facA, i_beg, 0);
-    load_stage(setB, facB, i_beg, 1);
+    // stage n of the launch (n = unit * NCH + chunk) lives in buffer n % 3
+    request(0, i_beg, 0);
+    request(1, NCH > 1 ? i_beg : i_beg + kStage, NCH > 1 ? 1 : 0);
 
-    // the users' fragments: k-step s of lane (r32, h) = elements 16 s + 8 h .. + 7 of user r32's row, straight from global memory
-    bf16x8 bfr[KS];
+    // the users' fragments: k-step (ch, s) of this wave is k-step ch CK + hk HK + s of the row; lane (r32, h) holds elements
+    // 16 kg + 8 h .. + 7 of user r32's row, straight from global memory
+    bf16x8 bfr[KH];
     {
         const float *__restrict__ urow = a.U + (size_t)(a.user_ids ? a.user_ids[min(user, a.B - 1)] : (int64_t)min(user, a.B - 1)) * a.d;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const int k0 = 16 * s + 8 * h;
+        for (int j = 0; j < KH; ++j) {
+            const int kg = (j / HK) * CK + hk * HK + (j % HK);
+            const int k0 = 16 * kg + 8 * h;
             const float4 x = *reinterpret_cast<const float4 *>(urow + min(k0, a.d - 8));
             const float4 y = *reinterpret_cast<const float4 *>(urow + min(k0, a.d - 8) + 4);
             const bool in = k0 < a.d && user_ok;
-            bfr[s] = __builtin_bit_cast(bf16x8, make_uint4(in ? pack_bf16(x.x, x.y) : 0u, in ? pack_bf16(x.z, x.w) : 0u,
+            bfr[j] = __builtin_bit_cast(bf16x8, make_uint4(in ? pack_bf16(x.x, x.y) : 0u, in ? pack_bf16(x.z, x.w) : 0u,
                                                           in ? pack_bf16(y.x, y.y) : 0u, in ? pack_bf16(y.z, y.w) : 0u));
-            if (s % 8 == 7)
+            if (j % 8 == 7)
                 __builtin_amdgcn_sched_barrier(0);     // (eight steps' loads in flight, not all of them: they would not fit)
         }
     }
@@ -574,16 +621,18 @@ __global__ __launch_bounds__(256) void k_score_prefilter_wide(const PreWideArgs 
     const bf16x8 bfx = __builtin_bit_cast(bf16x8, h == 0 ? make_uint4(bf16_up_bits(ub.x) | (bf16_up_bits(ub.y) << 16),
                                                                        bf16_up_bits(ub.x * kAccumBudget), 0u, 0u)
                                                          : make_uint4(0u, 0u, 0u, 0u));
-    // the lane's own segment of the user's candidate log: unlike the narrow kernels this one LOGS the raised approximate score
-    // of every pair that passes (~0.5 per lane and unit against 2 KS + 2 MFMAs): k_refine turns them into a second, far tighter
-    // threshold before any fp32 chain runs
-    const size_t seg = SAMPLE ? 0 : ((size_t)min(user, a.B - 1) * (2 * wa.S) + (size_t)blockIdx.y * 2 + h);
+    // the lane's own segment of the user's candidate log: every pair that passes is LOGGED with its raised approximate score
+    // (~0.5 per lane and unit against 2 KS + 2 MFMAs per wave pair): k_refine turns them into a second, far tighter threshold
+    // before any fp32 chain runs.  This wave finishes tile hk of every unit: segment (split, tile hk, row half h).
+    const size_t seg = SAMPLE ? 0 : ((size_t)min(user, a.B - 1) * (4 * wa.S) + (size_t)blockIdx.y * 4 + hk * 2 + h);
     float2 *__restrict__ lg = wa.logs + seg * wa.cap2;
     int n_log = 0;
-    store_stage(0, setA, facA, 0);
-    __syncthreads();
     asm volatile("" ::"v"(tau), "v"(bfx));
-    int buf = 0, fbuf = 0;          // unit n reads its factor chunks from sfac[n & 1]
+    wait_vmcnt<0>();                // everything above has arrived, the first two stages included
+    __syncthreads();
+    int buf = 0;                    // ring position of the stage being multiplied
+    float *__restrict__ xout = &xbuf[ug][hk][0] + lane * 4;           // [register quad][lane][4]
+    const float *__restrict__ xin = &xbuf[ug][hk ^ 1][0] + lane * 4;
     for (int t0 = i_beg; t0 < i_end; t0 += kStage) {
         f32x16 c0, c1;
 #pragma unroll
@@ -591,84 +640,99 @@ __global__ __launch_bounds__(256) void k_score_prefilter_wide(const PreWideArgs 
             c0[r] = 0.0f, c1[r] = 0.0f;
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
-            // request the stage after the next: a later chunk of this unit or one of the next unit's (past the split: copies nobody
-            // reads).  Even stages travel in set A, odd ones in set B; the set requested now is the one stored one stage ago.
+            // request the stage after the next into the buffer the previous stage was read from (every wave is past that stage's
+            // barrier); past the split: copies nobody reads
             {
-                const int t2 = ch + 2 < NCH ? t0 : t0 + kStage, c2 = ch + 2 < NCH ? ch + 2 : ch + 2 - NCH;
-                if (ch % 2 == 0)
-                    load_stage(setA, facA, t2, c2);
-                else
-                    load_stage(setB, facB, t2, c2);
+                const int c2 = (ch + 2) % NCH, t2 = t0 + ((ch + 2) / NCH) * kStage;
+                request(buf == 0 ? 2 : buf - 1, t2, c2);
             }
-            const unsigned char *pi = smem[buf] + r32 * RBL + 16 * h;
+            const unsigned char *pi = smem[buf] + r32 * RBL + hk * (HK * 32) + 16 * h;
             // fragments two k-steps ahead of their MFMAs, and no further (scheduling barriers): left to itself the compiler hoists
             // the whole chunk's LDS reads and spills the users' fragments
-            const int NS = KS - ch * CK < CK ? KS - ch * CK : CK;      // k-steps of this chunk (a constant once unrolled)
-            bf16x8 f0[CK], f1[CK];
+            bf16x8 f0[HK], f1[HK];
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
-                if (s < NS) {
-                    f0[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pi + 32 * s));
-                    f1[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pi + 32 * RBL + 32 * s));
-                }
+            for (int s = 0; s < 2 && s < HK; ++s) {
+                f0[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pi + 32 * s));
+                f1[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pi + 32 * RBL + 32 * s));
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int s = 0; s < CK; ++s)
-                if (s < NS) {
-                    if (s + 2 < NS) {
-                        f0[s + 2] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pi + 32 * (s + 2)));
-                        f1[s + 2] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pi + 32 * RBL + 32 * (s + 2)));
-                    }
-                    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0[s], bfr[ch * CK + s], c0, 0, 0, 0);
-                    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1[s], bfr[ch * CK + s], c1, 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
+            for (int s = 0; s < HK; ++s) {
+                if (s + 2 < HK) {
+                    f0[s + 2] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pi + 32 * (s + 2)));
+                    f1[s + 2] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pi + 32 * RBL + 32 * (s + 2)));
                 }
-            if (ch == NCH - 1 && !SAMPLE) {     // the bound's k-step (both halves read the row's factor chunk) and the tests
-                const bf16x8 g0 = __builtin_bit_cast(bf16x8, sfac[fbuf][r32]);
-                const bf16x8 g1 = __builtin_bit_cast(bf16x8, sfac[fbuf][32 + r32]);
-                c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, bfx, c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1, bfx, c1, 0, 0, 0);
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0[s], bfr[ch * HK + s], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1[s], bfr[ch * HK + s], c1, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            if (ch % 2 == 0)     // the next stage (odd) was requested one stage ago
-                store_stage(buf ^ 1, setB, facB, ch + 1 < NCH ? -1 : (fbuf ^ 1));
-            else
-                store_stage(buf ^ 1, setA, facA, ch + 1 < NCH ? -1 : (fbuf ^ 1));
+            if (ch == NCH - 1) {
+                if (!SAMPLE && hk == 0) {      // the bound's k-step, once per pair (both row halves read the row's factor chunk in the pad)
+                    const unsigned char *pf = smem[buf] + r32 * RBL + 32 * CK;
+                    const bf16x8 g0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pf));
+                    const bf16x8 g1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pf + 32 * RBL));
+                    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, bfx, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1, bfx, c1, 0, 0, 0);
+                }
+                // hand the partner the partial sums of the tile IT finishes (wave 0: tile 1, wave 1: tile 0)
+                if (hk == 0) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<float4 *>(xout + g * 4 * kWave) = make_float4(c1[4 * g], c1[4 * g + 1], c1[4 * g + 2], c1[4 * g + 3]);
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<float4 *>(xout + g * 4 * kWave) = make_float4(c0[4 * g], c0[4 * g + 1], c0[4 * g + 2], c0[4 * g + 3]);
+                }
+            }
+            // the NEXT stage's pieces of this wave have landed when all but the NPW requests just issued are done (requests,
+            // loads and the log stores retire in order); the barrier then covers the other waves' pieces and their reads of `buf`
+            wait_vmcnt<NPW>();
             __syncthreads();
-            buf ^= 1;
+            buf = buf == 2 ? 0 : buf + 1;
         }
-        fbuf ^= 1;
+        // this wave's tile: own half + the partner's (the next write of xbuf lies behind the next unit's first barrier)
+        float fin[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 p = *reinterpret_cast<const float4 *>(xin + g * 4 * kWave);
+            fin[4 * g + 0] = (hk == 0 ? c0[4 * g + 0] : c1[4 * g + 0]) + p.x;
+            fin[4 * g + 1] = (hk == 0 ? c0[4 * g + 1] : c1[4 * g + 1]) + p.y;
+            fin[4 * g + 2] = (hk == 0 ? c0[4 * g + 2] : c1[4 * g + 2]) + p.z;
+            fin[4 * g + 3] = (hk == 0 ? c0[4 * g + 3] : c1[4 * g + 3]) + p.w;
+        }
+        const int tb = t0 + 32 * hk;          // first item of the tile
         if constexpr (SAMPLE) {
             if (user_ok) {
                 float *__restrict__ srow = wa.sample + (size_t)user * wa.sample_ld;
 #pragma unroll
-                for (int g = 0; g < 8; ++g) {          // registers 4 g' .. 4 g' + 3 of a tile are four consecutive items
-                    const int item = t0 + 32 * (g >> 2) + 8 * (g & 3) + 4 * h;
-                    const f32x16 &c = g < 4 ? c0 : c1;
-                    const int q = 4 * (g & 3);
+                for (int g = 0; g < 4; ++g) {          // registers 4 g .. 4 g + 3 of a tile are four consecutive items
+                    const int item = tb + 8 * g + 4 * h;
                     if (item + 3 < i_end) {
-                        *reinterpret_cast<float4 *>(srow + item) = make_float4(c[q], c[q + 1], c[q + 2], c[q + 3]);
+                        *reinterpret_cast<float4 *>(srow + item) = make_float4(fin[4 * g], fin[4 * g + 1], fin[4 * g + 2], fin[4 * g + 3]);
                     } else {
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
                             if (item + e < i_end)
-                                srow[item + e] = c[q + e];
+                                srow[item + e] = fin[4 * g + e];
                     }
                 }
             }
             continue;
         }
-        const int lim = user_ok ? i_end - t0 : 0;
+        const int lim = user_ok ? i_end - tb : 0;
 #pragma unroll
-        for (int r = 0; r < 32; ++r) {
-            const int row = 32 * (r >> 4) + (r & 3) + 8 * ((r & 15) >> 2) + 4 * h;
-            const float v = r < 16 ? c0[r & 15] : c1[r & 15];
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float v = fin[r];
             if (row < lim && !(v <= tau)) {
                 if (n_log < wa.cap2)
-                    lg[n_log] = make_float2(v, __int_as_float(t0 + row));
+                    lg[n_log] = make_float2(v, __int_as_float(tb + row));
                 ++n_log;
             }
         }
     }
+    wait_vmcnt<0>();          // requests still in flight write into this workgroup's LDS: they must land before it is released
     if (user_ok && !SAMPLE)
         wa.counts[seg] = n_log;
 }
@@ -1057,7 +1121,7 @@ int launch_prefilter_wide(const float *U, const int64_t *user_ids, int B, const 
     PreWideArgs a{PreArgs{U, user_ids, static_cast<const unsigned char *>(ipack), item_pack_bytes(I, d), tau, tau_stride, ubound, nullptr, 0, B,
                           I, d, items_per_split},
                   static_cast<float2 *>(logs), counts, S, cap2, 1, nullptr, 0};
-    const dim3 grid((B + 127) / 128, S), block(256);      // 128 users per workgroup, the users' fragments in registers
+    const dim3 grid((B + 127) / 128, S), block(512);      // 128 users per workgroup, K split between the two waves of a SIMD
     const int ks = pack_ksteps(d);
     if (ks <= 16)
         hipLaunchKernelGGL((k_score_prefilter_wide<16, false>), grid, block, 0, s, a);
@@ -1082,7 +1146,7 @@ int launch_sample_wide(const float *U, const int64_t *user_ids, int B, const voi
     PreWideArgs a{PreArgs{U, user_ids, static_cast<const unsigned char *>(ipack), item_pack_bytes(I, d), nullptr, 0, nullptr, nullptr, 0, B,
                           m, d, ips},
                   nullptr, nullptr, 1, 1, stride, S, ld};
-    const dim3 grid(tiles, (m + ips - 1) / ips), block(256);
+    const dim3 grid(tiles, (m + ips - 1) / ips), block(512);
     const int ks = pack_ksteps(d);
     if (ks <= 16)
         hipLaunchKernelGGL((k_score_prefilter_wide<16, true>), grid, block, 0, s, a);

@@ -168,8 +168,9 @@ def split_plan_arrays(rowptr, threshold):
 def segment_plan_arrays(rowptr, colidx, vals, phases, tile_entries=256, n_classes=8, min_row_len=0):
     """Host arrays of a tgcn_segment_plan_t (XCD-affine column blocking, include/tgcn.h).
 
-    phases: list of (row_begin, row_end, col_lo, col_hi, n_blocks) -- row ranges whose entries fall in one column
-    range, cut into n_blocks column blocks (a multiple of n_classes).  The entries of a phase are copied into
+    phases: list of (row_begin, row_end, col_lo, col_hi, n_blocks[, n_classes]) -- row ranges whose entries fall in one column
+    range, cut into n_blocks column blocks (a multiple of the phase's n_classes: 8 = one class per XCD, 4 = two XCDs share a
+    class -- for a table of which a QUARTER fits an L2: half the pieces per row).  The entries of a phase are copied into
     n_classes streams: stream x holds the entries of blocks x, x + n_classes, ... ordered by (block, row, column).
     A row's run inside one block is a segment; streams are cut into tiles of `tile_entries` entries (one wavefront
     each) and a segment crossing a cut becomes two pieces.  The last entry of every piece has its bit set in
@@ -190,7 +191,12 @@ def segment_plan_arrays(rowptr, colidx, vals, phases, tile_entries=256, n_classe
     tiles_col, tiles_val, tiles_meta, tiles_src = [], [], [], []      # per phase, already in launch order
     flag_orig, flag_slot = [], []                      # piece ends: original entry offset, slot id
     slot_base = 0
-    for (r0, r1, c0, c1, nb) in phases:
+    default_classes = n_classes
+    for ph in phases:
+        r0, r1, c0, c1, nb = ph[:5]
+        n_classes = int(ph[5]) if len(ph) > 5 else default_classes
+        if n_classes not in (1, 2, 4, 8):
+            raise ValueError('n_classes must divide 8 (workgroups are dealt round-robin over the 8 XCDs)')
         nb = int(nb)
         if nb <= 0 or nb % n_classes:
             raise ValueError('n_blocks must be a positive multiple of n_classes')
@@ -223,6 +229,8 @@ def segment_plan_arrays(rowptr, colidx, vals, phases, tile_entries=256, n_classe
         last |= (pos_in_cls % T) == T - 1                                         # tile cuts
         tiles_per_cls = -(-cls_len // T)
         n_t = int(-(-tiles_per_cls.max() // 4) * 4)                               # tiles per class, padded to workgroups
+        while (n_t // 4 * n_classes) % 8:                                         # a phase is a whole number of 8-workgroup rounds, so
+            n_t += 4                                                              # that the next phase's classes start on XCD class 0
         tile_in_cls = pos_in_cls // T
         # launch order: workgroup w = (tile_in_cls // 4) * n_classes + class, tile = w * 4 + tile_in_cls % 4
         tile_id = ((tile_in_cls // 4) * n_classes + o_cls) * 4 + tile_in_cls % 4

@@ -124,7 +124,7 @@ class DeviceCSR:
         block_specs[i]; 0 keeps that row range on the one-wave-per-row path.  ('auto' picks these per width.)"""
         if not self._block_specs or len(blocks_per_spec) != len(self._block_specs):
             raise ValueError('one block count per block_spec is required')
-        self._segment_mode = [int(b) for b in blocks_per_spec]
+        self._segment_mode = [tuple(int(x) for x in b) if isinstance(b, (tuple, list)) else int(b) for b in blocks_per_spec]
         self.segment_tile = int(tile_entries)
         self.segment_min_row_len = int(min_row_len)
         self._segment_plans = {}
@@ -148,7 +148,9 @@ class DeviceCSR:
                 blocks = list(self._segment_mode)
             entry = None
             if any(blocks):
-                phases = [(r0, r1, c0, c1, nb) for (r0, r1, c0, c1), nb in zip(self._block_specs, blocks) if nb]
+                # a block count may be (n_blocks, n_classes): see segment_plan_arrays
+                phases = [(r0, r1, c0, c1) + (tuple(nb) if isinstance(nb, (tuple, list)) else (nb,))
+                          for (r0, r1, c0, c1), nb in zip(self._block_specs, blocks) if nb]
                 h = segment_plan_arrays(rowptr, colidx, self.vals.cpu().numpy(), phases, self.segment_tile,
                                         min_row_len=self.segment_min_row_len)
                 dv = {k: torch.from_numpy(v).to(self.device) for k, v in h.items() if isinstance(v, np.ndarray)}

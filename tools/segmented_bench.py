@@ -2,7 +2,8 @@
 """Timing of the XCD-affine segmented SpMM (tgcn_spmm_segmented_f32) against the plain kernel on a BASELINE config.
 
     python tools/segmented_bench.py --workload c2 --configs 0,8 8,8 0,16 --tile 256
-Each --configs entry is users_blocks,items_blocks (column blocks for user rows / item rows; 0 = rows stay direct)."""
+Each --configs entry is users_blocks,items_blocks (column blocks for user rows / item rows; 0 = rows stay direct); a block
+count may carry its class count as blocks:classes (4:4 = four blocks, two XCDs per block)."""
 import argparse
 import json
 import os
@@ -48,7 +49,7 @@ def main():
     ref = out.clone()
     print(json.dumps({'variant': 'plain', 'ms_per_forward': round(base, 4)}), flush=True)
     for cfg in args.configs:
-        bu, bi = (int(t) for t in cfg.split(','))
+        bu, bi = (tuple(int(x) for x in t.split(':')) if ':' in t else int(t) for t in cfg.split(','))
         for ml, mr in [(x, y) for x in args.tile for y in args.min_row_len]:
             prop.csr.configure_segments([bu, bi], tile_entries=ml, min_row_len=mr)
             for un in args.unroll:
