@@ -42,6 +42,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3   # fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+MFMA_BF16_PEAK_TF = 2500.0 # dense bf16 matrix peak (v_mfma_f32_32x32x16_bf16; MI355X_MICROARCH.md: ~2.5 PF dense)
 SPMM_SOURCES = ('textgcn_amd/csrc/tgcn_spmm.hip', 'textgcn_amd/propagate.py', 'textgcn_amd/graph.py')
 
 
@@ -274,6 +275,42 @@ def n_score_streams(prefilter):
     return SCORE_STREAMS[bool(prefilter)]
 
 
+def pack_ksteps(d):
+    """16-wide k-steps of a packed item row (tgcn_score_prefilter.hip pack_ksteps)"""
+    return 4 if d <= 64 else 8 if d <= 128 else 16 if d <= 256 else 32 if d <= 512 else 64 if d <= 832 else 56 if d <= 896 else 60 if d <= 960 else 64
+
+
+def candidate_path_roofline(b, n_items, d, k_top, t_call, dev, slot=0):
+    """Roofline of ONE call of the default scoring path (tgcn_score_topk_prefilter_f32: bf16 candidate pass + fp32 chains for the
+    candidates).  The call has three floors, none of which the others can hide below: the bf16 matrix pipe (2 K' B I flop, K' =
+    the packed row width + the bound's k-step), the candidates' fp32 row gathers at the chip's random-row rate (pairs counted by
+    tgcn_score_topk_stats on the last call of `slot`, rate measured live for a table of the item table's size), and the streams
+    every call must move once (the item pack; the narrow path's pass-bit words, written and read).  bound = the largest of the
+    three; frac = bound time / measured time of the call."""
+    from textgcn_amd import scoring
+    st = scoring.call_stats(dev, b, n_items, d, k_top, True, slot=slot)
+    ks = pack_ksteps(d)
+    flop = 2.0 * 16 * (ks + 1) * b * n_items
+    t_mfma = flop / (MFMA_BF16_PEAK_TF * 1e12)
+    # random-row rate for rows of 4 d bytes from a table of this many bytes (wide rows: the probe kernel's widest row, same bytes)
+    probe_d = d if d in (64, 128, 256) else 256
+    rate = random_row_rate(max(64, n_items * d // probe_d), probe_d, dev, entries=1 << 21)
+    gather_bytes = st['rescored_pairs'] * 4.0 * d
+    t_gather = gather_bytes / rate
+    wh = ((n_items + 63) // 64 + 3) & ~3
+    stream_bytes = n_items * (32 * ks + 16) + (0 if d > 128 else 2 * ((b + 255) // 256 * 256) * 2 * wh * 4)
+    t_stream = stream_bytes / (HBM_PEAK_GBS * 1e9)
+    floors = {'mfma_bf16': t_mfma, 'candidate_row_gathers': t_gather, 'pack_and_mask_streams': t_stream}
+    which = max(floors, key=floors.get)
+    return {'bound': which, 'what': 'max of three floors of one call: bf16 MFMA time of 2 K\' B I, candidates\' fp32 row gathers / live '
+                                    'random-row rate, pack + pass-bit streams / HBM peak', 'frac': round(floors[which] / t_call, 4),
+            'floors_us': {k: round(v * 1e6, 2) for k, v in floors.items()}, 'call_us': round(t_call * 1e6, 2),
+            'mfma_frac_of_bf16_peak': round(t_mfma / t_call, 4), 'bf16_flop': flop, 'peak_TF': MFMA_BF16_PEAK_TF,
+            'users': b, 'rescored_pairs_per_user': round(st['rescored_pairs'] / b, 1), 'kept_pairs_per_user': round(st['kept_pairs'] / b, 1),
+            'logged_pairs_per_user': round(st['logged_pairs'] / b, 1), 'fallback_users': st['fallback_users'],
+            'random_row_rate_GBs': round(rate / 1e9, 1), 'gather_bytes': int(gather_bytes), 'stream_bytes': int(stream_bytes)}
+
+
 def scoring_region(ue, ie, batches, k_top, dev, barrier, prefilter=False):
     """Consecutive calls are independent: issued round-robin on a few HIP streams with their own scratch buffers, as
     LightGCN.predict does, so one call's small selection kernels run under the next call's GEMM.  Returns seconds.
@@ -468,7 +505,10 @@ def records_c3_c5(dev, want_c5=True, cpu=True):
         'what': 'LightGCN.score_prefilter = True (the class default): tgcn_score_topk_prefilter_f32',
         'value': pairs / (t_all_p - t_fwd), 'unit': 'pairs/s', 'ms_total': (t_all_p - t_fwd) * 1e3,
         'identical_to_fp32_path': bool(torch.equal(pv, ref_v) and torch.equal(pi, ref_i)),
-        'evaluate_wall_s_all_users': round(time.time() - t1, 4)}
+        'evaluate_wall_s_all_users': round(time.time() - t1, 4),
+        # per call of predict_chunk users (slot 0's last call is a full chunk); the calls overlap on the model's streams, so
+        # the time of one call is the region's time / number of calls
+        'roofline': candidate_path_roofline(min(m.predict_chunk, n_u), n_i, d, max(m.k), (t_all_p - t_fwd) / -(-n_u // m.predict_chunk), dev)}
     del ref_v, ref_i, pv, pi
     ue, ie = fwd()
     if cpu:
@@ -512,7 +552,9 @@ def records_c3_c5(dev, want_c5=True, cpu=True):
           'bf16_candidates': {'what': 'LTRLinear.score_prefilter = True (the class default): the folded K = 960 operands through '
                                       'tgcn_score_topk_prefilter_f32 (k_score_prefilter_wide + fp32 chains)',
                               'value': pairs / t_ltr_pre, 'unit': 'pairs/s', 'ms_total': t_ltr_pre * 1e3,
-                              'identical_to_fp32_path': same5}}
+                              'identical_to_fp32_path': same5,
+                              'roofline': candidate_path_roofline(min(ltr.ltr_predict_chunk, n_u), n_i, int(ltr._k()), max(ltr.k),
+                                                                  t_ltr_pre / -(-n_u // ltr.ltr_predict_chunk), dev)}}
     if cpu:
         from oracle import torch_port
         nb = 256
@@ -862,7 +904,8 @@ def main():
                 'what': 'tgcn_score_topk_prefilter_f32: bf16 MFMA pass with a proven error bound keeps a superset of the candidates, '
                         'k-ordered fp32 chains rescore them; top-k lists and scores identical to the fp32 path',
                 'value': pairs / tp, 'unit': 'pairs/s', 'ms_per_batch': tp / n_batches * 1e3, 'streams': n_score_streams(True),
-                'identical_to_fp32_path': bool(same), 'speedup': round(ts / tp, 3)}
+                'identical_to_fp32_path': bool(same), 'speedup': round(ts / tp, 3),
+                'roofline': candidate_path_roofline(int(batches[0][0].numel()), n_i, d, k_top, tp / n_batches, dev)}
         # the model class scores 16384 users per call (LightGCN.predict_chunk); same kernels, fewer launches
         big = min(16384, len(users_all))
         if not sharded and big > bsz:
@@ -875,7 +918,9 @@ def main():
                                                 'mfma_frac': round(2.0 * d * pb / tb / 1e12 / MFMA_F32_PEAK_TF, 4)}
             if d <= 128:
                 tbp, _ = scoring_region(ue, ie, bb, k_top, dev, barrier, prefilter=True)
-                result['scoring']['large_batch']['bf16_candidates'] = {'value': pb / tbp, 'unit': 'pairs/s', 'ms_per_call': tbp / n_big * 1e3}
+                result['scoring']['large_batch']['bf16_candidates'] = {
+                    'value': pb / tbp, 'unit': 'pairs/s', 'ms_per_call': tbp / n_big * 1e3,
+                    'roofline': candidate_path_roofline(big, n_i, d, k_top, tbp / n_big, dev)}
 
     # ---------------- CPU baseline beside it + verification of the timed outputs (rank 0, N = 1 only; outside the timed regions)
     if not sharded and not args.no_cpu_baseline:

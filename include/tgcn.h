@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TGCN_ABI_VERSION 7
+#define TGCN_ABI_VERSION 8
 
 #define TGCN_OK 0
 #define TGCN_ERR_ARG (-1)         /* bad argument (null pointer, size, unsupported d/k ...) */
@@ -185,6 +185,13 @@ int tgcn_item_norms_f32(const float *It, int32_t I, int32_t d, float *out, tgcn_
  * synchronises the stream.  The results never depend on it; a high count means the call paid for k_brute_part. */
 int tgcn_score_topk_fallback_count(const void *workspace, int32_t B, int32_t I, int32_t d, int32_t k, int32_t *out_host,
                                    tgcn_stream_t stream);
+/* Diagnostic (ABI v8): what the LAST call that used `workspace` (same B, I, d, k; `prefilter` = which entry point it was) did,
+ * summed over its users -- out_host[0] users sent to the exact fallback, [1] pairs kept (fp32 score > tau_u), [2] pairs rescored by
+ * an fp32 chain (the bf16 pass's candidates; wide rows: what k_refine let through), [3] pairs logged by the filter (fp32 filters
+ * and the wide bf16 filter).  bench.py prices the rescoring's row gathers with [2].  Runs a small kernel, copies four int64 to
+ * the HOST pointer and synchronises the stream; the results never depend on it. */
+int tgcn_score_topk_stats(void *workspace, int32_t B, int32_t I, int32_t d, int32_t k, int32_t prefilter, int64_t *out_host,
+                          tgcn_stream_t stream);
 
 /* K11-K13: LTR text-feature head (config 5) folded into one GEMM of width K = tgcn_ltr_folded_width(d, t).
  *   replaces get_user_vectors / get_item_vectors / get_features_batchwise + nn.Linear(5, 1)

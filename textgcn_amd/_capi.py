@@ -8,7 +8,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_ui
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, '_lib', 'libtgcn.so')
 
-TGCN_ABI_VERSION = 7
+TGCN_ABI_VERSION = 8
 TGCN_COMM_ID_BYTES = 128
 SPMM_AUTO, SPMM_WAVE_PER_ROW = 0, 1
 
@@ -45,6 +45,7 @@ _SIGNATURES = {
     'tgcn_score_topk_prefilter_f32': (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_int32,
                                                      c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     'tgcn_score_topk_fallback_count': (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, POINTER(c_int32), c_void_p]),
+    'tgcn_score_topk_stats': (ctypes.c_int, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, POINTER(c_int64), c_void_p]),
     'tgcn_item_pack_bytes': (ctypes.c_int64, [c_int32, c_int32]),
     'tgcn_item_pack_bf16': (ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
     'tgcn_item_norms_f32': (ctypes.c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p]),

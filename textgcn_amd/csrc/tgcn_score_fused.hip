@@ -478,7 +478,8 @@ struct SelectArgs {
     int64_t *__restrict__ out_idx;
     int *__restrict__ flagged;  // [1 + B]: count, then the flagged user rows (count zeroed by the caller each call)
     int B, S, cap2, k, do_round;
-    const int *__restrict__ totals;   // k_select_flat (k_rescore's output): user b's entries are logs[b * S * 2 * cap2 + 0 .. totals[b])
+    const int *__restrict__ totals;   // k_select_flat (k_rescore's output): user b's entries are logs[b * list_cap + 0 .. totals[b])
+    int list_cap;                     // ... entries of log area per user
 };
 
 constexpr int kMaskCache = 512;  // train items per user cached in LDS for the membership test
@@ -974,7 +975,7 @@ __global__ __launch_bounds__(256) void k_select_flat(const SelectArgs a)
     }
     const bool cached = (me - mb) <= kMaskCache;
     const int m_first = (cached && lane < me - mb) ? a.mask_items[mb + lane] : 0;
-    const int list_cap = a.S * 2 * a.cap2;
+    const int list_cap = a.list_cap;
     const int n = a.totals[b];
     bool ok = n <= min(kSelCap, list_cap) && n > 0;
     float out_v = -INFINITY;
@@ -1158,10 +1159,11 @@ __global__ __launch_bounds__(kBruteWaves * 64) void k_brute_part(const BruteArgs
 
 struct Plan {
     int S, items_per_split, cap2, m, m_ld;  // m = sampled items
-    int S_w, ips_w;                         // wide bf16 filter: its own (at most 16) item splits -- 4 log segments per split and user
+    int S_w, ips_w, cap2_w;                 // wide bf16 filter: its own (at most 16) item splits -- 4 log segments of cap2_w per split and user
     int Wh;                                 // mask words per (user, row half): the 64-item units of the catalogue, padded to 4
     size_t off_mask;
-    size_t off_sample, off_tauv, off_taui, off_tau, off_ubound, off_ipack, off_logs, off_counts, off_parts, off_flags, off_done, off_totals, off_surv, off_surv_n, total;
+    size_t off_sample, off_tauv, off_taui, off_tau, off_ubound, off_ipack, off_logs, off_counts, off_parts, off_flags, off_done, off_totals, off_surv, off_surv_n, off_stats, total;
+    int n_seg;                              // log segments per user (2 S; the wide bf16 filter: 4 S_w)
     int flag_cap;
     bool small;
 };
@@ -1204,15 +1206,23 @@ Plan make_plan(int B, int I, int d, int k)
     if (prefilter_supports(d))
         o += align256((size_t)((B + 255) / 256) * 256 * 2 * p.Wh * sizeof(unsigned));   // rows of the bf16 filter's padded users
     // the wide bf16 filter (K split between two waves per SIMD) logs into 4 segments per (user, split) -- (tile, row half) of the
-    // lane that finished the pair -- and k_refine reads one segment per lane: at most 16 splits, merged from the plan's
+    // lane that finished the pair -- and k_refine reads one segment per lane: at most 16 splits.  As few splits as fill the chip
+    // ONCE (one 512-thread workgroup per CU: 256 workgroups): a workgroup's prologue -- its users' fragments, ~35 us by the cycle
+    // stamps -- is then paid once per call, not once per generation of workgroups (8192 users: 64 tiles x 4 splits).
     {
-        const int f = (p.S + 15) / 16;
-        p.ips_w = f * p.items_per_split;
+        const int tiles = (B + 127) / 128;
+        const int units = (I + kStage - 1) / kStage;
+        int sw = max(1, min(16, 256 / max(tiles, 1)));
+        sw = max(1, min(sw, units / 8));                       // at least 8 units per split
+        p.ips_w = ((units + sw - 1) / sw) * kStage;
         p.S_w = (I + p.ips_w - 1) / p.ips_w;
+        p.cap2_w = max(p.cap2, (64 * 64) / (4 * p.S_w));       // 4096 log entries per user in all (~550 are used at K = 960)
     }
-    const int n_seg = (d > 128 && prefilter_supports(d)) ? max(2 * p.S, 4 * p.S_w) : 2 * p.S;
-    p.off_logs = o, o += align256((size_t)B * n_seg * p.cap2 * sizeof(float2));
-    p.off_counts = o, o += align256((size_t)B * n_seg * sizeof(int));
+    p.n_seg = 2 * p.S;
+    if (d > 128 && prefilter_supports(d))      // the log area in units of cap2: both layouts fit
+        p.n_seg = max(p.n_seg, (4 * p.S_w * p.cap2_w + p.cap2 - 1) / p.cap2);
+    p.off_logs = o, o += align256((size_t)B * p.n_seg * p.cap2 * sizeof(float2));
+    p.off_counts = o, o += align256((size_t)B * p.n_seg * sizeof(int));
     p.flag_cap = B;   // every user may need the fallback (e.g. fully tied scores): 16 KB of partial lists each
     p.off_parts = o, o += align256((size_t)p.flag_cap * kBruteSplits * kWave * sizeof(float2));
     p.off_flags = o, o += align256((size_t)(B + 1) * sizeof(int));
@@ -1223,8 +1233,54 @@ Plan make_plan(int B, int I, int d, int k)
         o += align256((size_t)B * kRefineCap * sizeof(int));
         p.off_surv_n = o, o += align256((size_t)B * sizeof(int));
     }
+    p.off_stats = o, o += 256;                                         // tgcn_score_topk_stats' four counters
     p.total = o;
     return p;
+}
+
+// tgcn_score_topk_stats: sums over the users of the last call.  One wave per 64 users; wave-reduced adds into four counters.
+struct StatsArgs {
+    const int *__restrict__ flagged;   // [0] = users sent to the exact fallback
+    const int *__restrict__ totals;    // [B] pairs kept by k_rescore (score > tau), or NULL
+    const unsigned *__restrict__ mask; // narrow bf16 filter: pass bits [B padded][2][Wh], or NULL
+    int Wh, n_units;
+    const int *__restrict__ surv_n;    // wide bf16 filter: candidates k_refine kept [B], or NULL
+    const int *__restrict__ counts;    // logged candidates [B][n_seg] (fp32 filters and the wide bf16 filter), or NULL
+    int n_seg, cap2, B;
+    unsigned long long *__restrict__ out;   // [4]: fallback users, kept pairs, candidates rescored in fp32, logged pairs
+};
+
+__global__ __launch_bounds__(256) void k_stats(const StatsArgs a)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    unsigned long long kept = 0, cand = 0, logged = 0;
+    if (b < a.B) {
+        if (a.totals)
+            kept = (unsigned long long)min(a.totals[b], 1 << 20);
+        if (a.mask) {
+            const unsigned *__restrict__ row = a.mask + (size_t)b * 2 * a.Wh;
+            for (int hh = 0; hh < 2; ++hh)
+                for (int j = 0; j < a.n_units; ++j)
+                    cand += __popc(row[hh * a.Wh + j]);
+        }
+        if (a.surv_n)
+            cand = (unsigned long long)min(a.surv_n[b], 1 << 20);
+        if (a.counts)
+            for (int j = 0; j < a.n_seg; ++j)
+                logged += (unsigned long long)min(a.counts[(size_t)b * a.n_seg + j], a.cap2);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        kept += __shfl_xor(kept, o);
+        cand += __shfl_xor(cand, o);
+        logged += __shfl_xor(logged, o);
+    }
+    if (lane_id() == 0) {
+        atomicAdd(a.out + 1, kept);
+        atomicAdd(a.out + 2, cand);
+        atomicAdd(a.out + 3, logged);
+        if (b == 0)
+            a.out[0] = (unsigned long long)a.flagged[0];
+    }
 }
 
 // > 64 KB of dynamic LDS needs hipFuncAttributeMaxDynamicSharedMemorySize on the kernel, per device (the attribute lives
@@ -1383,16 +1439,16 @@ int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const fl
             int *surv = reinterpret_cast<int *>(ws + p.off_surv), *surv_n = reinterpret_cast<int *>(ws + p.off_surv_n);
             // at most 16 splits (make_plan): 4 lane-private log segments per split and user, 64 segments = one per lane of k_refine
             if ((rc = launch_prefilter_wide(U, user_ids, B, ipack, I, d, tau_ptr, tau_stride, ubound, fa.logs, fa.counts, p.S_w, p.ips_w,
-                                            p.cap2, s)) != TGCN_OK)
+                                            p.cap2_w, s)) != TGCN_OK)
                 return rc;
             RefineArgs ra{fa.logs, fa.counts, mask_rowptr, mask_items, ubound, static_cast<const unsigned char *>(ipack), pack_row_bytes(d),
-                          surv, surv_n, kRefineCap, B, 2 * p.S_w, p.cap2, k};
+                          surv, surv_n, kRefineCap, B, 2 * p.S_w, p.cap2_w, k};
             hipLaunchKernelGGL(k_refine, dim3((B + 3) / 4), dim3(256), 0, s, ra);
             if ((rc = check_launch("k_refine")) != TGCN_OK)
                 return rc;
             // (the flat lists of the kept pairs go where the filter's logs were: k_refine is done with them)
             if ((rc = launch_rescore_list(U, user_ids, B, It, d, tau_ptr, tau_stride, surv, surv_n, kRefineCap, fa.logs, totals,
-                                          p.S * 2 * p.cap2, s)) != TGCN_OK)
+                                          p.n_seg * p.cap2, s)) != TGCN_OK)
                 return rc;
         } else {
         const bool wide = B > 4096;
@@ -1429,7 +1485,8 @@ int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const fl
         return rc;
 
     // 3. exact selection from the logs; 4. exact rescoring of flagged users
-    SelectArgs sa{fa.logs, fa.counts, mask_rowptr, mask_items, out_val, out_idx, flagged, B, p.S, p.cap2, k, round4, totals};
+    SelectArgs sa{fa.logs, fa.counts, mask_rowptr, mask_items, out_val, out_idx, flagged, B, p.S, p.cap2, k, round4, totals,
+                  (prefilter && d > 128 ? p.n_seg : 2 * p.S) * p.cap2};
     if (sa.totals)
         hipLaunchKernelGGL(k_select_flat, dim3((B + 3) / 4), dim3(256), 0, s, sa);
     else
@@ -1479,6 +1536,40 @@ extern "C" int tgcn_score_topk_fallback_count(const void *workspace, int32_t B, 
     if (hipMemcpyAsync(out_host, static_cast<const char *>(workspace) + p.off_flags, sizeof(int32_t), hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipStreamSynchronize(s) != hipSuccess)
         return check_launch("tgcn_score_topk_fallback_count");
+    return TGCN_OK;
+}
+
+extern "C" int tgcn_score_topk_stats(void *workspace, int32_t B, int32_t I, int32_t d, int32_t k, int32_t prefilter, int64_t *out_host,
+                                     tgcn_stream_t stream)
+{
+    TGCN_REQUIRE(workspace && out_host, "NULL pointer");
+    TGCN_REQUIRE(B > 0 && I > 0 && d > 0, "empty call");
+    const Plan p = make_plan(B, I, d, k);
+    out_host[0] = out_host[1] = out_host[2] = out_host[3] = 0;
+    if (p.small)
+        return TGCN_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    char *ws = static_cast<char *>(workspace);
+    const bool pre = prefilter && prefilter_supports(d);
+    const bool wide = pre && d > 128;
+    StatsArgs a{};
+    a.flagged = reinterpret_cast<const int *>(ws + p.off_flags);
+    a.totals = pre ? reinterpret_cast<const int *>(ws + p.off_totals) : nullptr;
+    a.mask = pre && !wide ? reinterpret_cast<const unsigned *>(ws + p.off_mask) : nullptr;
+    a.Wh = p.Wh, a.n_units = (I + kStage - 1) / kStage;
+    a.surv_n = wide ? reinterpret_cast<const int *>(ws + p.off_surv_n) : nullptr;
+    // (the narrow bf16 path rewrites the log area with k_rescore's flat lists: its counts are not logs)
+    a.counts = (!pre || wide) ? reinterpret_cast<const int *>(ws + p.off_counts) : nullptr;
+    a.n_seg = wide ? 4 * p.S_w : 2 * p.S, a.cap2 = wide ? p.cap2_w : p.cap2, a.B = B;
+    a.out = reinterpret_cast<unsigned long long *>(ws + p.off_stats);
+    if (hipMemsetAsync(a.out, 0, 32, s) != hipSuccess)
+        return check_launch("hipMemsetAsync(stats)");
+    hipLaunchKernelGGL(k_stats, dim3((B + 255) / 256), dim3(256), 0, s, a);
+    int rc = check_launch("k_stats");
+    if (rc != TGCN_OK)
+        return rc;
+    if (hipMemcpyAsync(out_host, a.out, 32, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+        return check_launch("tgcn_score_topk_stats");
     return TGCN_OK;
 }
 

@@ -500,7 +500,42 @@ struct PreWideArgs {
     int row_stride;
     float *__restrict__ sample;
     int64_t sample_ld;
+    int n_tiles;                    // user tiles of 128; the grid is linear: 32 x 8 x ceil(n_tiles / 32 x splits / 8) workgroups
 };
+
+// workgroups of the wide filter's linear grid: groups of 32 (one XCD's CUs) = 32 user tiles of one split, dealt 8 groups per round
+inline unsigned wide_grid(int n_tiles, int splits)
+{
+    const int groups = ((n_tiles + 31) / 32) * splits;
+    return (unsigned)(((groups + 7) / 8) * 8 * 32);
+}
+
+// development switches (tools/wide_ablate.py builds private copies with one of them off to price the loop's ingredients; the
+// shipped library has all of them on)
+#ifndef TGCN_WIDE_DMA
+#define TGCN_WIDE_DMA 1        // 0: no stage requests inside the loop (the ring keeps its first stages: timing only)
+#endif
+#ifndef TGCN_WIDE_TESTS
+#define TGCN_WIDE_TESTS 1      // 0: no tests / appends / sample stores
+#endif
+#ifndef TGCN_WIDE_MFMA
+#define TGCN_WIDE_MFMA 1       // 0: no MFMAs (fragment reads stay)
+#endif
+#ifndef TGCN_WIDE_PF
+#define TGCN_WIDE_PF 4
+#endif
+#ifndef TGCN_WIDE_LDSREAD
+#define TGCN_WIDE_LDSREAD 1    // 0: the item fragments are read once per stage instead of once per k-step
+#endif
+
+#ifdef TGCN_WIDE_STAMP
+// private diagnostic build (tools/wide_ablate.py stamp): per wave, shader-clock cycles of the loop and of its waits; the shipped
+// library carries none of this
+__device__ unsigned long long g_wstamp[1 << 16][8];
+#define WSTAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define WSTAMP(var)
+#endif
 
 // k-steps per LDS stage: three stage buffers of 64 rows (one multiplied, two in flight) beside the exchange buffer in 160 KB
 template <int KS>
@@ -556,15 +591,30 @@ __global__ __launch_bounds__(512) void k_score_prefilter_wide(const PreWideArgs 
     // loaded round trip is longer than a stage.
     __shared__ __attribute__((aligned(16))) unsigned char smem[3][SBUF];
     __shared__ __attribute__((aligned(16))) float xbuf[4][2][16 * kWave];   // [user group][sending half][register][lane]
+    WSTAMP(st_kernel);
     const int lane = lane_id();
     const int w = uniform(threadIdx.x >> 6);
     const int ug = w & 3, hk = w >> 2;                 // waves ug and ug + 4 land on one SIMD (dispatch order 0 -> 2 -> 1 -> 3)
     const int r32 = lane & 31;
     const int h = lane >> 5;
-    const int u0 = blockIdx.x * UT;
-    const int i_beg = blockIdx.y * a.items_per_split;
+    // Which (user tile, item split) this workgroup takes.  A workgroup streams its split's slice of the pack (7 MB of config 5's
+    // 116 MB) once; every user tile of the call streams all of it, so at 8192 users the launch pulls 64 x 116 MB = 7.4 GB -- at
+    // ~1 ms per launch that is the Infinity Cache's whole bandwidth.  The grid is therefore linear and dealt so that the 32
+    // workgroups an XCD runs at a time (one per CU: 160 KB of LDS) are 32 user tiles of ONE split: started together, working at
+    // the same pace, they read the same rows within microseconds of each other and all but the first find them in that XCD's L2.
+    // (Workgroups are dealt round-robin over the XCDs: linear id % 8 -- for speed only, no result depends on the placement.)
+    int tile, split;
+    {
+        const int L = blockIdx.x, x = L & 7, j = L >> 3;
+        const int grp = (j >> 5) * 8 + x;              // group of 32 workgroups: XCD x, generation j / 32
+        const int tgroups = (wa.n_tiles + 31) >> 5;
+        split = grp / tgroups;
+        tile = (grp % tgroups) * 32 + (j & 31);
+    }
+    const int u0 = tile * UT;
+    const int i_beg = split * a.items_per_split;
     const int i_end = min(a.I, i_beg + a.items_per_split);
-    if (i_beg >= i_end)
+    if (tile >= wa.n_tiles || i_beg >= i_end)
         return;
     const int user = u0 + ug * 32 + r32;
     const bool user_ok = user < a.B;
@@ -585,14 +635,16 @@ __global__ __launch_bounds__(512) void k_score_prefilter_wide(const PreWideArgs 
     const int last_row = (int)(a.pack_bytes / RBG) - 1;            // rows of the pack
     const unsigned row_pitch = (unsigned)wa.row_stride * RBG;
     const int last_t = last_row / wa.row_stride;
+    auto request_piece = [&](int i, int buf, int t0, int ch) {
+        const int pc = min(w + 8 * i, NPIECE - 1);
+        const unsigned col = (pcol[i] >> 30) ? (unsigned)(pcol[i] & 0xFFFFFF) : (unsigned)(pcol[i] + ch * (32 * CK));
+        const size_t off = (size_t)(unsigned)min(t0 + prow[i], last_t) * row_pitch + col;
+        lds_dma16(a.ipack + off, uniform((int)(unsigned)(uintptr_t)(smem[buf] + pc * 1024)));
+    };
     auto request = [&](int buf, int t0, int ch) {
 #pragma unroll
-        for (int i = 0; i < NPW; ++i) {
-            const int pc = min(w + 8 * i, NPIECE - 1);
-            const unsigned col = (pcol[i] >> 30) ? (unsigned)(pcol[i] & 0xFFFFFF) : (unsigned)(pcol[i] + ch * (32 * CK));
-            const size_t off = (size_t)(unsigned)min(t0 + prow[i], last_t) * row_pitch + col;
-            lds_dma16(a.ipack + off, uniform((int)(unsigned)(uintptr_t)(smem[buf] + pc * 1024)));
-        }
+        for (int i = 0; i < NPW; ++i)
+            request_piece(i, buf, t0, ch);
     };
     // stage n of the launch (n = unit * NCH + chunk) lives in buffer n % 3
     request(0, i_beg, 0);
@@ -624,7 +676,7 @@ __global__ __launch_bounds__(512) void k_score_prefilter_wide(const PreWideArgs 
     // the lane's own segment of the user's candidate log: every pair that passes is LOGGED with its raised approximate score
     // (~0.5 per lane and unit against 2 KS + 2 MFMAs per wave pair): k_refine turns them into a second, far tighter threshold
     // before any fp32 chain runs.  This wave finishes tile hk of every unit: segment (split, tile hk, row half h).
-    const size_t seg = SAMPLE ? 0 : ((size_t)min(user, a.B - 1) * (4 * wa.S) + (size_t)blockIdx.y * 4 + hk * 2 + h);
+    const size_t seg = SAMPLE ? 0 : ((size_t)min(user, a.B - 1) * (4 * wa.S) + (size_t)split * 4 + hk * 2 + h);
     float2 *__restrict__ lg = wa.logs + seg * wa.cap2;
     int n_log = 0;
     asm volatile("" ::"v"(tau), "v"(bfx));
@@ -633,39 +685,109 @@ __global__ __launch_bounds__(512) void k_score_prefilter_wide(const PreWideArgs 
     int buf = 0;                    // ring position of the stage being multiplied
     float *__restrict__ xout = &xbuf[ug][hk][0] + lane * 4;           // [register quad][lane][4]
     const float *__restrict__ xin = &xbuf[ug][hk ^ 1][0] + lane * 4;
+    // A finished tile (16 sums per lane) is consumed UNDER the next unit's first stage: its tests / appends (or the sample's
+    // stores) sit between that stage's MFMAs, as the stage-after-next's requests do -- behind an MFMA they issue while the
+    // matrix pipe works, in front of the stage they would leave it idle for both waves of the SIMD at once.
+    float fin[16];
+    int fin_t = -1;                 // first item of the tile in `fin` (-1: none yet)
+    constexpr int PF = TGCN_WIDE_PF < HK ? TGCN_WIDE_PF : HK;      // k-steps of lead of the LDS fragment reads
+    constexpr int TS = HK > NPW ? HK - NPW : 0;      // k-steps of a unit's first stage that carry the tests (0: after the stage)
+    auto consume = [&](int r0, int r1) {       // registers r0 .. r1 - 1 of the finished tile
+        if constexpr (SAMPLE) {
+            // (registers 4 g .. 4 g + 3 of a tile are four consecutive items: one 16-byte store per group, issued with its last register)
+#pragma unroll
+            for (int r = r0; r < r1; ++r) {
+                if ((r & 3) != 3)
+                    continue;
+                const int g = r >> 2;
+                const int item = fin_t + 8 * g + 4 * h;
+                if (user_ok) {
+                    float *__restrict__ srow = wa.sample + (size_t)user * wa.sample_ld;
+                    if (item + 3 < i_end) {
+                        *reinterpret_cast<float4 *>(srow + item) = make_float4(fin[4 * g], fin[4 * g + 1], fin[4 * g + 2], fin[4 * g + 3]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (item + e < i_end)
+                                srow[item + e] = fin[4 * g + e];
+                    }
+                }
+            }
+        } else {
+            const int lim = user_ok ? i_end - fin_t : 0;
+#pragma unroll
+            for (int r = r0; r < r1; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float v = fin[r];
+                if (row < lim && !(v <= tau)) {
+                    if (n_log < wa.cap2)
+                        lg[n_log] = make_float2(v, __int_as_float(fin_t + row));
+                    ++n_log;
+                }
+            }
+        }
+    };
+#ifdef TGCN_WIDE_STAMP
+    unsigned long long st_wait = 0, st_bar = 0;
+    const unsigned long long st_begin = __builtin_amdgcn_s_memtime(), st_rbegin = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int t0 = i_beg; t0 < i_end; t0 += kStage) {
         f32x16 c0, c1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            c0[r] = 0.0f, c1[r] = 0.0f;
-#pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
-            // request the stage after the next into the buffer the previous stage was read from (every wave is past that stage's
-            // barrier); past the split: copies nobody reads
-            {
-                const int c2 = (ch + 2) % NCH, t2 = t0 + ((ch + 2) / NCH) * kStage;
-                request(buf == 0 ? 2 : buf - 1, t2, c2);
-            }
             const unsigned char *pi = smem[buf] + r32 * RBL + hk * (HK * 32) + 16 * h;
-            // fragments two k-steps ahead of their MFMAs, and no further (scheduling barriers): left to itself the compiler hoists
-            // the whole chunk's LDS reads and spills the users' fragments
+            // the stage after the next goes into the buffer the previous stage was read from (every wave is past that stage's
+            // barrier); past the split: copies nobody reads
+            const int c2 = (ch + 2) % NCH, t2 = t0 + ((ch + 2) / NCH) * kStage, b2 = buf == 0 ? 2 : buf - 1;
+            // fragments PF k-steps ahead of their MFMAs, and no further (scheduling barriers): left to itself the compiler hoists
+            // the whole chunk's LDS reads and spills the users' fragments.  (Stamps at two k-steps: ~2.5 k of a unit's 8.5 k cycles
+            // per wave in s_waitcnt lgkmcnt -- eight waves' reads and the ring's DMA writes queue at the LDS.)
             bf16x8 f0[HK], f1[HK];
 #pragma unroll
-            for (int s = 0; s < 2 && s < HK; ++s) {
+            for (int s = 0; s < PF && s < HK; ++s) {
                 f0[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pi + 32 * s));
                 f1[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pi + 32 * RBL + 32 * s));
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int s = 0; s < HK; ++s) {
-                if (s + 2 < HK) {
-                    f0[s + 2] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pi + 32 * (s + 2)));
-                    f1[s + 2] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pi + 32 * RBL + 32 * (s + 2)));
+                if (s + PF < HK) {
+                    if (TGCN_WIDE_LDSREAD) {
+                        f0[s + PF] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pi + 32 * (s + PF)));
+                        f1[s + PF] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pi + 32 * RBL + 32 * (s + PF)));
+                    } else {
+                        f0[s + PF] = f0[s % PF], f1[s + PF] = f1[s % PF];
+                    }
                 }
-                c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0[s], bfr[ch * HK + s], c0, 0, 0, 0);
-                c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1[s], bfr[ch * HK + s], c1, 0, 0, 0);
+                if (!TGCN_WIDE_MFMA) {
+                    if (ch == 0 && s == 0)
+                        for (int r = 0; r < 16; ++r)
+                            c0[r] = 0.f, c1[r] = 0.f;
+                    c0[s & 15] += __builtin_bit_cast(f32x16, (unsigned __attribute__((ext_vector_type(16)))){0})[0] + __uint_as_float(__builtin_bit_cast(uint4, f0[s]).x ^ __builtin_bit_cast(uint4, bfr[ch * HK + s]).x);
+                    c1[s & 15] += __uint_as_float(__builtin_bit_cast(uint4, f1[s]).x);
+                } else if (ch == 0 && s == 0) {       // a unit's first k-step starts its sums from zero (no register clearing)
+                    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0[s], bfr[ch * HK + s], zero, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1[s], bfr[ch * HK + s], zero, 0, 0, 0);
+                } else {
+                    c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0[s], bfr[ch * HK + s], c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1[s], bfr[ch * HK + s], c1, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // behind the pair: (first stage of a unit) a share of the previous tile's tests in the stage's first k-steps, one
+                // request of stage + 2 in its last ones -- in this order, so that every log store is OLDER than every request of
+                // the stage and the counted wait below never has to cover a request just issued
+                if (ch == 0 && TS > 0 && s < TS && fin_t >= 0)
+                    consume((16 * s) / TS, (16 * (s + 1)) / TS);
+                if (TGCN_WIDE_DMA && s >= HK - min(NPW, HK))
+                    request_piece(s - (HK - min(NPW, HK)), b2, t2, c2);
                 __builtin_amdgcn_sched_barrier(0);
             }
+#pragma unroll
+            for (int i = min(NPW, HK); TGCN_WIDE_DMA && i < NPW; ++i)      // (stages with fewer k-steps per wave than pieces)
+                request_piece(i, b2, t2, c2);
+            if (ch == 0 && TS == 0 && fin_t >= 0)
+                consume(0, 16);
             if (ch == NCH - 1) {
                 if (!SAMPLE && hk == 0) {      // the bound's k-step, once per pair (both row halves read the row's factor chunk in the pad)
                     const unsigned char *pf = smem[buf] + r32 * RBL + 32 * CK;
@@ -686,13 +808,19 @@ __global__ __launch_bounds__(512) void k_score_prefilter_wide(const PreWideArgs 
                 }
             }
             // the NEXT stage's pieces of this wave have landed when all but the NPW requests just issued are done (requests,
-            // loads and the log stores retire in order); the barrier then covers the other waves' pieces and their reads of `buf`
+            // loads and the log stores retire in order; log stores issued since then only make this wait for more); the barrier
+            // then covers the other waves' pieces and their reads of `buf`
+            WSTAMP(ts0);
             wait_vmcnt<NPW>();
+            WSTAMP(ts1);
             __syncthreads();
+            WSTAMP(ts2);
+#ifdef TGCN_WIDE_STAMP
+            st_wait += ts1 - ts0, st_bar += ts2 - ts1;
+#endif
             buf = buf == 2 ? 0 : buf + 1;
         }
         // this wave's tile: own half + the partner's (the next write of xbuf lies behind the next unit's first barrier)
-        float fin[16];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const float4 p = *reinterpret_cast<const float4 *>(xin + g * 4 * kWave);
@@ -701,37 +829,19 @@ __global__ __launch_bounds__(512) void k_score_prefilter_wide(const PreWideArgs 
             fin[4 * g + 2] = (hk == 0 ? c0[4 * g + 2] : c1[4 * g + 2]) + p.z;
             fin[4 * g + 3] = (hk == 0 ? c0[4 * g + 3] : c1[4 * g + 3]) + p.w;
         }
-        const int tb = t0 + 32 * hk;          // first item of the tile
-        if constexpr (SAMPLE) {
-            if (user_ok) {
-                float *__restrict__ srow = wa.sample + (size_t)user * wa.sample_ld;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {          // registers 4 g .. 4 g + 3 of a tile are four consecutive items
-                    const int item = tb + 8 * g + 4 * h;
-                    if (item + 3 < i_end) {
-                        *reinterpret_cast<float4 *>(srow + item) = make_float4(fin[4 * g], fin[4 * g + 1], fin[4 * g + 2], fin[4 * g + 3]);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (item + e < i_end)
-                                srow[item + e] = fin[4 * g + e];
-                    }
-                }
-            }
-            continue;
-        }
-        const int lim = user_ok ? i_end - tb : 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const float v = fin[r];
-            if (row < lim && !(v <= tau)) {
-                if (n_log < wa.cap2)
-                    lg[n_log] = make_float2(v, __int_as_float(tb + row));
-                ++n_log;
-            }
-        }
+        fin_t = t0 + 32 * hk;          // first item of the tile
     }
+    consume(0, 16);                    // the split's last tile
+#ifdef TGCN_WIDE_STAMP
+    if (!SAMPLE && lane == 0) {
+        const unsigned slot = (blockIdx.x * 8 + w) & 0xFFFF;
+        g_wstamp[slot][0] = __builtin_amdgcn_s_memtime() - st_begin;
+        g_wstamp[slot][1] = __builtin_amdgcn_s_memrealtime() - st_rbegin;
+        g_wstamp[slot][2] = st_wait, g_wstamp[slot][3] = st_bar;
+        g_wstamp[slot][4] = st_begin - st_kernel;       // prologue
+        g_wstamp[slot][5] = (i_end - i_beg + kStage - 1) / kStage;
+    }
+#endif
     wait_vmcnt<0>();          // requests still in flight write into this workgroup's LDS: they must land before it is released
     if (user_ok && !SAMPLE)
         wa.counts[seg] = n_log;
@@ -1048,6 +1158,15 @@ __global__ __launch_bounds__(256) void k_rescore(const RescoreArgs a)
 
 }  // namespace
 
+#ifdef TGCN_WIDE_STAMP
+}  // namespace tgcn
+extern "C" int tgcn_wide_stamp_read(void *host, long long bytes)
+{
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(tgcn::g_wstamp), (size_t)bytes) == hipSuccess ? 0 : -2;
+}
+namespace tgcn {
+#endif
+
 bool prefilter_supports(int d) { return d <= 128 || (d <= kMaxPreD && d % 8 == 0); }
 
 int launch_item_norms(const float *It, int I, int d, float *norms, hipStream_t s)
@@ -1120,8 +1239,8 @@ int launch_prefilter_wide(const float *U, const int64_t *user_ids, int B, const 
 {
     PreWideArgs a{PreArgs{U, user_ids, static_cast<const unsigned char *>(ipack), item_pack_bytes(I, d), tau, tau_stride, ubound, nullptr, 0, B,
                           I, d, items_per_split},
-                  static_cast<float2 *>(logs), counts, S, cap2, 1, nullptr, 0};
-    const dim3 grid((B + 127) / 128, S), block(512);      // 128 users per workgroup, K split between the two waves of a SIMD
+                  static_cast<float2 *>(logs), counts, S, cap2, 1, nullptr, 0, (B + 127) / 128};
+    const dim3 grid(wide_grid((B + 127) / 128, S)), block(512);      // 128 users per workgroup, K split between the two waves of a SIMD
     const int ks = pack_ksteps(d);
     if (ks <= 16)
         hipLaunchKernelGGL((k_score_prefilter_wide<16, false>), grid, block, 0, s, a);
@@ -1145,8 +1264,8 @@ int launch_sample_wide(const float *U, const int64_t *user_ids, int B, const voi
     const int ips = ((units + splits - 1) / splits) * kStage;
     PreWideArgs a{PreArgs{U, user_ids, static_cast<const unsigned char *>(ipack), item_pack_bytes(I, d), nullptr, 0, nullptr, nullptr, 0, B,
                           m, d, ips},
-                  nullptr, nullptr, 1, 1, stride, S, ld};
-    const dim3 grid(tiles, (m + ips - 1) / ips), block(512);
+                  nullptr, nullptr, 1, 1, stride, S, ld, tiles};
+    const dim3 grid(wide_grid(tiles, (m + ips - 1) / ips)), block(512);
     const int ks = pack_ksteps(d);
     if (ks <= 16)
         hipLaunchKernelGGL((k_score_prefilter_wide<16, true>), grid, block, 0, s, a);

@@ -113,6 +113,21 @@ def fallback_count(dev, b, n_items, d, k, slot=0):
     return out.value
 
 
+def call_stats(dev, b, n_items, d, k, prefilter, slot=0):
+    """What the last score_topk call on (dev, slot) did, summed over its users (tgcn_score_topk_stats; diagnostic, synchronises):
+    dict(fallback_users, kept_pairs, rescored_pairs, logged_pairs)."""
+    import ctypes
+    dev = _capi.resolve_device(dev)
+    ws = _WORKSPACE.get((dev, slot))
+    if ws is None:
+        raise RuntimeError('no score_topk call has used this slot')
+    out = (ctypes.c_int64 * 4)()
+    rc = _capi.lib().tgcn_score_topk_stats(_capi.ptr(ws), b, n_items, d, int(min(k, MAX_K_PER_PASS)), 1 if prefilter else 0, out,
+                                           _capi.current_stream(dev))
+    _capi.check(rc, 'tgcn_score_topk_stats')
+    return dict(zip(('fallback_users', 'kept_pairs', 'rescored_pairs', 'logged_pairs'), [int(x) for x in out]))
+
+
 def item_pack(items_emb):
     """The item operand of the prefilter's bf16 pass (tgcn_item_pack_bf16): per row its bf16 image and the row's factors of the
     error bound, as a uint8 tensor.  Pack once per item table and hand it to score_topk(prefilter=True, item_pack=...).
