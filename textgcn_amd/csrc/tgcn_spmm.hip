@@ -412,14 +412,9 @@ int launch_seg(const SpmmArgs &a, const SegArgs &g, int unroll, int grid, hipStr
 
 // one wave per segmented row: y = ((p0 + p1) + p2) + ... over the row's pieces in column order, then the epilogue
 template <int VEC>
-__global__ __launch_bounds__(256) void k_spmm_seg_reduce(const SpmmArgs a, const int *__restrict__ rows,
-                                                         const int *__restrict__ row_slot_ptr,
-                                                         const int *__restrict__ row_slots, int n)
+__device__ __forceinline__ void seg_reduce_row(const SpmmArgs &a, const int *__restrict__ rows, const int *__restrict__ row_slot_ptr,
+                                               const int *__restrict__ row_slots, int l, int lane)
 {
-    const int lane = lane_id();
-    const int l = uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (l >= n)
-        return;
     const int row = rows[l];
     const int s0 = row_slot_ptr[l], s1 = row_slot_ptr[l + 1];
     const size_t off = (size_t)row * a.d + lane * VEC;
@@ -463,6 +458,45 @@ __global__ __launch_bounds__(256) void k_spmm_seg_reduce(const SpmmArgs a, const
         }
         store_vec<VEC>(a.acc_out + off, t);
     }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_spmm_seg_reduce(const SpmmArgs a, const int *__restrict__ rows,
+                                                         const int *__restrict__ row_slot_ptr,
+                                                         const int *__restrict__ row_slots, int n)
+{
+    const int lane = lane_id();
+    const int l = uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (l >= n)
+        return;
+    seg_reduce_row<VEC>(a, rows, row_slot_ptr, row_slots, l, lane);
+}
+
+// The second launch of the two-launch form (flags bit 16 of tgcn_spmm_segmented_f32): the segmented rows' piece sums are
+// added up by the first waves WHILE the remaining waves chain the direct rows -- the reduce is a bandwidth-bound stream (its
+// pieces come back from the Infinity Cache), the direct rows are latency-bound gathers: side by side they share the launch.
+template <int VEC>
+__global__ __launch_bounds__(256) void k_spmm_reduce_direct(const SpmmArgs a, const int *__restrict__ rows,
+                                                            const int *__restrict__ row_slot_ptr,
+                                                            const int *__restrict__ row_slots, int n_red,
+                                                            const int *__restrict__ direct_rows, int n_direct)
+{
+    const int lane = lane_id();
+    const int wave = uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (wave < n_red) {
+        seg_reduce_row<VEC>(a, rows, row_slot_ptr, row_slots, wave, lane);
+        return;
+    }
+    const int w = wave - n_red;
+    if (w >= n_direct)
+        return;
+    const int row = direct_rows[w];
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k)
+        acc[k] = 0.0f;
+    accumulate_wave<VEC, (VEC == 4 ? 8 : 16)>(a, a.rowptr[row], a.rowptr[row + 1], lane, acc);
+    epilogue<VEC>(a, (size_t)row * a.d + lane * VEC, acc);
 }
 
 // any d: wave per row, one 64-column slab at a time (re-walks the row per slab; d <= 64 is one pass)
@@ -681,6 +715,26 @@ extern "C" int tgcn_spmm_segmented_f32(const tgcn_segment_plan_t *plan, const in
     g.direct_rows = plan->direct_rows;
     g.n_tiles = plan->n_tiles, g.tile_entries = plan->tile_entries, g.n_direct = plan->n_direct_rows;
     const int unroll = (flags >> 8) & 0xff;
+    const bool two_phase = (flags >> 16) & 1u;       // tiles alone, then piece reduce + direct rows side by side
+    if (two_phase && plan->n_seg_rows > 0) {
+        const int n_direct = g.n_direct;
+        g.n_direct = 0;
+        const int grid = (g.n_tiles + 3) / 4;
+        if (grid > 0) {
+            const int rc = d == 64 ? launch_seg<1>(a, g, unroll, grid, s) : d == 128 ? launch_seg<2>(a, g, unroll, grid, s)
+                                                                                    : launch_seg<4>(a, g, unroll, grid, s);
+            if (rc != TGCN_OK)
+                return rc;
+        }
+        const int rgrid = (plan->n_seg_rows + n_direct + 3) / 4;
+        if (d == 64)
+            hipLaunchKernelGGL((k_spmm_reduce_direct<1>), dim3(rgrid), dim3(256), 0, s, a, plan->seg_rows, plan->row_slot_ptr, plan->row_slots, plan->n_seg_rows, plan->direct_rows, n_direct);
+        else if (d == 128)
+            hipLaunchKernelGGL((k_spmm_reduce_direct<2>), dim3(rgrid), dim3(256), 0, s, a, plan->seg_rows, plan->row_slot_ptr, plan->row_slots, plan->n_seg_rows, plan->direct_rows, n_direct);
+        else
+            hipLaunchKernelGGL((k_spmm_reduce_direct<4>), dim3(rgrid), dim3(256), 0, s, a, plan->seg_rows, plan->row_slot_ptr, plan->row_slots, plan->n_seg_rows, plan->direct_rows, n_direct);
+        return check_launch("k_spmm_reduce_direct");
+    }
     const int grid = (g.n_tiles + g.n_direct + 3) / 4;
     if (grid > 0) {
         const int rc = d == 64 ? launch_seg<1>(a, g, unroll, grid, s) : d == 128 ? launch_seg<2>(a, g, unroll, grid, s)

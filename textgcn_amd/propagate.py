@@ -15,8 +15,11 @@ from .graph import NormGraph, segment_plan_arrays, split_plan_arrays
 DEFAULT_SPLIT_THRESHOLD = 1024
 L2_SHARE_BYTES = 3 << 20        # of an XCD's 4 MB L2 that a gathered table can count on next to the streaming traffic
 SEGMENT_CLASSES = 8             # one column-block class per XCD
-SEGMENT_TILE_ENTRIES = 1024     # entries per tile wave (measured on config 2: 512..1024 within 1 %, 256 -8 %, 2048 -30 %)
-SEGMENT_MIN_ROW_LEN = 32        # shorter rows stay direct: < 4 entries per block do not pay for a workspace slot (+3 %)
+SEGMENT_TILE_ENTRIES = 256      # entries per tile wave.  One launch for tiles + direct rows: 512..1024 within 1 %, 256 -8 %, 2048 -30 %;
+                                # two launches (below): 192..256 best (0.555-0.557 ms per config-2 forward against 0.592), 128 / 320 +2 %
+SEGMENT_MIN_ROW_LEN = 48        # shorter rows stay direct: < 6 entries per block do not pay for a workspace slot (0 / 16: +7 %; 32..64 within 1 %)
+SEGMENT_TWO_PHASE = True        # tiles alone (the XCDs' L2s hold only their block of the gathered table), then the piece reduce and the
+                                # direct rows side by side in a second launch (tgcn_spmm_segmented_f32 flags bit 16): config 2 -6 %, same bits
 
 
 def segment_blocks_auto(rowptr, colidx, spec, d):
@@ -230,7 +233,7 @@ def spmm(csr, x, y=None, acc_in=None, acc_out=None, acc_div=1.0, exact=False, va
     if seg is not None:
         rc = _capi.lib().tgcn_spmm_segmented_f32(
             seg, _capi.ptr(csr.rowptr), _capi.ptr(csr.colidx), _capi.ptr(vals), csr.n_rows, _capi.ptr(x), csr.n_src_rows, d,
-            _capi.ptr(y), _capi.ptr(acc_in), _capi.ptr(acc_out), float(acc_div), (unroll & 0xff) << 8,
+            _capi.ptr(y), _capi.ptr(acc_in), _capi.ptr(acc_out), float(acc_div), ((unroll & 0xff) << 8) | ((1 << 16) if SEGMENT_TWO_PHASE else 0),
             _capi.current_stream(dev))
         _capi.check(rc, 'tgcn_spmm_segmented_f32')
         return y if y is not None else acc_out

@@ -22,8 +22,10 @@ def main():
     ap.add_argument('--unroll', type=int, nargs='+', default=[0])
     ap.add_argument('--min-row-len', type=int, nargs='+', default=[0])
     ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--two-phase', action='store_true')
     args = ap.parse_args()
     from textgcn_amd import propagate, synth
+    propagate.SEGMENT_TWO_PHASE = args.two_phase
     from textgcn_amd.graph import NormGraph
     n_u, n_i, nnz, d, K = synth.CONFIGS[args.workload]
     u, i = synth.interactions(n_u, n_i, nnz, seed=0)
