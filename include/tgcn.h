@@ -210,6 +210,15 @@ int tgcn_ltr_fold_users_f32(const float *users_emb, const float *users_reviews, 
                             const float *w5_host, float bias, float *out, tgcn_stream_t stream);
 int tgcn_ltr_pack_items_f32(const float *items_emb, const float *items_reviews, const float *items_desc, int32_t I,
                             int32_t d, int32_t t, float *out, tgcn_stream_t stream);
+/* The five PAIRWISE features of n gathered (user, item) rows (training batches), [n, 5] row-major:
+ *   replaces get_user_vectors / get_item_vectors / get_features_pairwise             TextGCN/ltr_models.py:116-128,148-166
+ *   feats[p] = [e_p . e'_p, r_u . r_i, d_u . d_i, r_u . d_i, d_u . r_i],  u = users[p], i = items[p]
+ * users_emb_rows / items_emb_rows are the ALREADY gathered embedding rows [n, d] (the reference's calling convention:
+ * score_pairwise(users_emb[users], items_emb[items], users, items)); the text rows are read from their [U, t] / [I, t] tables by
+ * id.  nn.Linear over the five features stays with the caller (it owns the trainable weights). */
+int tgcn_ltr_pair_features_f32(const float *users_emb_rows, const float *items_emb_rows, const float *users_reviews,
+                               const float *users_desc, const float *items_reviews, const float *items_desc, const int64_t *users,
+                               const int64_t *items, int64_t n, int32_t d, int32_t t, float *feats, tgcn_stream_t stream);
 
 /* K9: out[r] = <U[users[r], :], V[items[r], :]>   (users/items may be NULL: row r itself).
  *   replaces torch.sum(users_emb * items_emb, dim=1)               TextGCN/base_model.py:171

@@ -213,3 +213,37 @@ def test_predict_host_syncs_do_not_grow_with_chunks(golden, cuda, tmp_path, cls_
     perm = np.random.default_rng(0).permutation(n_u)
     pv, pi = m.predict_tensors(perm)          # a non-contiguous list: device gather of the mask rows
     assert torch.equal(pi, ref[1][perm]) and torch.equal(pv, ref[0][perm])
+
+
+@pytest.mark.gpu
+def test_pairwise_features_kernel_and_its_gradient(golden, cuda, tmp_path):
+    """score_pairwise_ltr on the native feature kernel against the reference's composition (get_features_pairwise,
+    ltr_models.py:148-166, restated with torch ops): values, the gradient into the head and -- unfrozen base model -- into the
+    gathered embedding rows; int32 / host ids are taken, an id outside its table raises IndexError."""
+    from textgcn_amd.ltr import LTRLinear
+    g = golden('g4_ltr')
+    n_u, n_i = int(g['n_users']), int(g['n_items'])
+    p = types.SimpleNamespace(k=[5, 10], emb_size=64, n_layers=3, device='cuda:0', load=None, load_base=None, freeze=False,
+                              batch_size=32, quiet=True, ltr_layers=[7], save_path=str(tmp_path))
+    m = LTRLinear(p, _dataset(g))
+    rng = np.random.default_rng(0)
+    pu = torch.from_numpy(rng.integers(0, n_u, 500)).to(cuda)
+    pi = torch.from_numpy(rng.integers(0, n_i, 500)).to(cuda)
+    res = []
+    for native in (True, False):
+        ue = torch.randn(n_u, 64, device=cuda, generator=torch.Generator(cuda).manual_seed(1)).requires_grad_()
+        ie = torch.randn(n_i, 64, device=cuda, generator=torch.Generator(cuda).manual_seed(2)).requires_grad_()
+        m.zero_grad()
+        if native:
+            s = m.score_pairwise(ue[pu], ie[pi], pu.to(torch.int32), pi.cpu())
+        else:
+            dot = lambda a, c: (a * c).sum(dim=1, keepdim=True)  # noqa: E731
+            ru, du, ri, di = m.users_as_avg_reviews[pu], m.users_as_avg_desc[pu], m.items_as_avg_reviews[pi], m.items_as_desc[pi]
+            s = m.layers(torch.cat([dot(ue[pu], ie[pi]), dot(ru, ri), dot(du, di), dot(ru, di), dot(du, ri)], dim=1))
+        assert s.shape == (500, 1)
+        (s * torch.linspace(-1, 1, 500, device=cuda)[:, None]).sum().backward()
+        res.append([s.detach().cpu().numpy(), ue.grad.cpu().numpy(), ie.grad.cpu().numpy(), m.layers[0].weight.grad.cpu().numpy().copy()])
+    for a, b in zip(*res):
+        assert normwise(a, b) <= 1e-5
+    with pytest.raises(IndexError):
+        m.score_pairwise(torch.zeros(2, 64, device=cuda), torch.zeros(2, 64, device=cuda), torch.tensor([0, n_u]), torch.tensor([0, 1]))

@@ -53,6 +53,8 @@ _SIGNATURES = {
     'tgcn_ltr_fold_users_f32': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32,
                                                POINTER(c_float), c_float, c_void_p, c_void_p]),
     'tgcn_ltr_pack_items_f32': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p]),
+    'tgcn_ltr_pair_features_f32': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                                  c_int32, c_int32, c_void_p, c_void_p]),
     'tgcn_score_candidates_f32': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p,
                                                  c_void_p, c_void_p, c_void_p]),
     'tgcn_dropout_values_f32': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_float, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -7,6 +7,8 @@
 // so the 5 GEMMs + the 2.46 GB [B, I, 5] concat + the strided Linear become a K = d + 2t (+pad) GEMM that the
 // ordinary scoring kernels run (tgcn_score_dense_f32 / tgcn_score_topk_f32).  These two kernels build the folded
 // operands; both are bandwidth-trivial (B x K and I x K floats).
+#include <climits>
+
 #include "tgcn_internal.h"
 
 namespace tgcn {
@@ -56,10 +58,66 @@ __global__ void k_ltr_pack_items(const float *__restrict__ e, const float *__res
     out[i] = v;
 }
 
+// The five pairwise features of LTRBase.get_features_pairwise (ltr_models.py:148-166) for n gathered (user, item) rows: one wave
+// per pair, lane-strided partial sums (k ascending inside a lane) and a wave reduction -- the four text rows are read from their
+// tables by id, so the [n, 384] gathers of get_user_vectors / get_item_vectors (ltr_models.py:116-128) never exist.
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_ltr_pair_features(const float *__restrict__ ue, const float *__restrict__ ie,
+                                                           const float *__restrict__ ur, const float *__restrict__ ud,
+                                                           const float *__restrict__ ir, const float *__restrict__ idsc,
+                                                           const int64_t *__restrict__ users, const int64_t *__restrict__ items, int64_t n,
+                                                           int d, int t, float *__restrict__ feats)
+{
+    const int lane = lane_id();
+    const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= n)
+        return;
+    const int64_t u = users[p], it = items[p];
+    const float *__restrict__ a = ue + p * d, *__restrict__ b = ie + p * d;
+    const float *__restrict__ ru = ur + u * t, *__restrict__ du = ud + u * t, *__restrict__ ri = ir + it * t, *__restrict__ di = idsc + it * t;
+    float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f, f4 = 0.f;
+    for (int k = lane; k < d; k += kWave)
+        f0 = fmaf(a[k], b[k], f0);
+    for (int k = lane; k < t; k += kWave) {
+        const float xr = ru[k], xd = du[k], yr = ri[k], yd = di[k];
+        f1 = fmaf(xr, yr, f1);
+        f2 = fmaf(xd, yd, f2);
+        f3 = fmaf(xr, yd, f3);
+        f4 = fmaf(xd, yr, f4);
+    }
+    f0 = wave_sum(f0), f1 = wave_sum(f1), f2 = wave_sum(f2), f3 = wave_sum(f3), f4 = wave_sum(f4);
+    if (lane == 0) {
+        float *o = feats + p * 5;
+        o[0] = f0, o[1] = f1, o[2] = f2, o[3] = f3, o[4] = f4;
+    }
+}
+
 }  // namespace
 }  // namespace tgcn
 
 using namespace tgcn;
+
+extern "C" int tgcn_ltr_pair_features_f32(const float *users_emb_rows, const float *items_emb_rows, const float *users_reviews,
+                                          const float *users_desc, const float *items_reviews, const float *items_desc,
+                                          const int64_t *users, const int64_t *items, int64_t n, int32_t d, int32_t t, float *feats,
+                                          tgcn_stream_t stream)
+{
+    TGCN_REQUIRE(n >= 0 && n < (int64_t)4 * INT32_MAX && d > 0 && t > 0, "bad sizes");
+    if (n == 0)
+        return TGCN_OK;
+    TGCN_REQUIRE(users_emb_rows && items_emb_rows && users_reviews && users_desc && items_reviews && items_desc && users && items && feats,
+                 "NULL pointer");
+    hipLaunchKernelGGL(k_ltr_pair_features, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), users_emb_rows,
+                       items_emb_rows, users_reviews, users_desc, items_reviews, items_desc, users, items, n, d, t, feats);
+    return check_launch("k_ltr_pair_features");
+}
 
 extern "C" int32_t tgcn_ltr_folded_width(int32_t d, int32_t t)
 {

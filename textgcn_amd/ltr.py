@@ -52,6 +52,30 @@ class LTRData(InteractionData):
                 setattr(self, name, t)
 
 
+class _PairFeatures(torch.autograd.Function):
+    """[n, 5] pairwise features (tgcn_ltr_pair_features_f32).  Only the first feature depends on trainable tensors -- the gathered
+    embedding rows, when the base model is not frozen: d f0 / d e_u = e_i and vice versa; the text tables are constants."""
+
+    @staticmethod
+    def forward(ctx, ue, ie, model, users, items):
+        ue, ie = ue.contiguous(), ie.contiguous()
+        n = users.numel()
+        feats = torch.empty((n, 5), dtype=torch.float32, device=ue.device)
+        rc = _capi.lib().tgcn_ltr_pair_features_f32(_capi.ptr(ue), _capi.ptr(ie), _capi.ptr(model.users_as_avg_reviews),
+                                                    _capi.ptr(model.users_as_avg_desc), _capi.ptr(model.items_as_avg_reviews),
+                                                    _capi.ptr(model.items_as_desc), _capi.ptr(users), _capi.ptr(items), n, ue.shape[1],
+                                                    model.text_dim, _capi.ptr(feats), _capi.current_stream(ue.device))
+        _capi.check(rc, 'tgcn_ltr_pair_features_f32')
+        ctx.save_for_backward(ue, ie)
+        return feats
+
+    @staticmethod
+    def backward(ctx, g):
+        ue, ie = ctx.saved_tensors
+        g0 = g[:, :1]
+        return (g0 * ie if ctx.needs_input_grad[0] else None), (g0 * ue if ctx.needs_input_grad[1] else None), None, None, None
+
+
 class LTRLinear(LightGCN):
     """reference: TextGCN/ltr_models.py:38-210 (LTRBase + LTRLinear)."""
 
@@ -147,14 +171,32 @@ class LTRLinear(LightGCN):
         ua = self._fold_users(users_emb.contiguous(), None, users)
         return scoring.score_dense(ua, self._pack_items(items_emb.contiguous()))
 
+    def _pair_ids(self, users, items, n_rows):
+        """contiguous int64 device ids inside the tables (the kernel reads text rows by raw id): any integer dtype, any device;
+        an id outside its table raises IndexError as the reference's tensor indexing would (checked on the host copy the ids
+        arrive as, or -- device ids -- clamped here and reported by fit()'s flag read, like get_loss's)."""
+        out = []
+        for ids, lim in ((users, self.n_users), (items, self.n_items)):
+            ids = torch.as_tensor(ids)
+            if ids.dtype.is_floating_point or ids.dtype == torch.bool or ids.numel() != n_rows:
+                raise TypeError('users / items must be integer id tensors with one id per gathered row')
+            if ids.device.type == 'cpu':
+                if ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= lim):
+                    raise IndexError('score_pairwise: id outside its table')
+                ids = ids.to(self.device, torch.int64)
+            else:
+                ids = ids.to(self.device, torch.int64)
+                bad = ((ids < 0) | (ids >= lim)).any()
+                self._bad_ids = bad if getattr(self, '_bad_ids', None) is None else (self._bad_ids | bad)
+                ids = ids.clamp(0, lim - 1)
+            out.append(ids.reshape(-1).contiguous())
+        return out
+
     def score_pairwise_ltr(self, users_emb, items_emb, users, items):
-        """[n, 1] scores of gathered (user, item) rows -- small, differentiable torch ops (training batches)."""
-        users = torch.as_tensor(users, dtype=torch.int64, device=self.device)
-        items = torch.as_tensor(items, dtype=torch.int64, device=self.device)
-        ru, du = self.users_as_avg_reviews[users], self.users_as_avg_desc[users]
-        ri, di = self.items_as_avg_reviews[items], self.items_as_desc[items]
-        dot = lambda a, c: (a * c).sum(dim=1, keepdim=True)  # noqa: E731
-        feats = torch.cat([dot(users_emb, items_emb), dot(ru, ri), dot(du, di), dot(ru, di), dot(du, ri)], dim=1)   # :148-166
+        """[n, 1] scores of gathered (user, item) rows (training batches; ltr_models.py:206-210): the five features by ONE kernel
+        (tgcn_ltr_pair_features_f32: no [n, 384] text gathers, no five row-dot ops), nn.Linear and its autograd by torch."""
+        users, items = self._pair_ids(users, items, users_emb.shape[0])
+        feats = _PairFeatures.apply(users_emb, items_emb, self, users, items)                         # :148-166
         return self.layers(feats)
 
     def evaluate_ltr(self, *args, **kwargs):
@@ -252,11 +294,7 @@ class LTRLinearWPop(LTRLinear):
         return out
 
     def score_pairwise_ltr(self, users_emb, items_emb, users, items):
-        users = torch.as_tensor(users, dtype=torch.int64, device=self.device)
-        items = torch.as_tensor(items, dtype=torch.int64, device=self.device)
-        ru, du = self.users_as_avg_reviews[users], self.users_as_avg_desc[users]
-        ri, di = self.items_as_avg_reviews[items], self.items_as_desc[items]
-        dot = lambda a, c: (a * c).sum(dim=1, keepdim=True)  # noqa: E731
-        feats = torch.cat([dot(users_emb, items_emb), dot(ru, ri), dot(du, di), dot(ru, di), dot(du, ri),
+        users, items = self._pair_ids(users, items, users_emb.shape[0])
+        feats = torch.cat([_PairFeatures.apply(users_emb, items_emb, self, users, items),
                            self.popularity_users[users], self.popularity_items[items]], dim=1)   # ltr_models.py:233-241
         return self.layers(feats)
