@@ -522,8 +522,11 @@ inline unsigned wide_grid(int n_tiles, int splits)
 #define TGCN_WIDE_MFMA 1       // 0: no MFMAs (fragment reads stay)
 #endif
 #ifndef TGCN_WIDE_PF
-#define TGCN_WIDE_PF 4
+#define TGCN_WIDE_PF 2         // (measured: 2 / 3 / 4 / 6 k-steps of lead -> 8.6 k / 9.0 k / 9.7 k / 17 k cycles per unit: deeper is slower)
 #endif
+#ifndef TGCN_WIDE_STAGGER
+#define TGCN_WIDE_STAGGER 1    // s_sleep units (64 cycles) waves 4-7 wait after every stage barrier, so that the two waves of a SIMD do not
+#endif                         // reach their fragment waits and their MFMAs together (0 / 1 / 3 / 8: 8.44 k / 8.18 k / 8.25 k / 8.42 k cycles per unit)
 #ifndef TGCN_WIDE_LDSREAD
 #define TGCN_WIDE_LDSREAD 1    // 0: the item fragments are read once per stage instead of once per k-step
 #endif
@@ -735,6 +738,10 @@ __global__ __launch_bounds__(512) void k_score_prefilter_wide(const PreWideArgs 
         f32x16 c0, c1;
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
+#if TGCN_WIDE_STAGGER
+            if (hk)
+                __builtin_amdgcn_s_sleep(TGCN_WIDE_STAGGER);      // (64 cycles each) take the pair out of lockstep
+#endif
             const unsigned char *pi = smem[buf] + r32 * RBL + hk * (HK * 32) + 16 * h;
             // the stage after the next goes into the buffer the previous stage was read from (every wave is past that stage's
             // barrier); past the split: copies nobody reads
