@@ -172,10 +172,16 @@ def main():
     fs, wsz = summary.get('bench_FETCH_SIZE', {}), summary.get('bench_WRITE_SIZE', {})
     dr_name = 'bench_TCC_EA0_RDREQ_DRAM_32B_sum_TCC_HIT_sum_TCC_MISS_sum'
     dr = summary.get(dr_name, {})
-    main = [k for k in fs if k.startswith(('k_spmm_seg<', 'k_spmm_wave', 'k_spmm_group', 'k_spmm_hub'))]
-    main = sorted(main, key=lambda k: -fs[k]['FETCH_SIZE']['mean'] * fs[k]['FETCH_SIZE']['n'])[:1]
-    spmm = main + [k for k in fs if k.startswith(('k_spmm_seg_reduce', 'k_spmm_long_reduce')) and main
-                   and (k.startswith('k_spmm_seg_reduce') == main[0].startswith('k_spmm_seg<'))]
+    # the layer launches of the workload: the segmented pair when the workload runs it (bench.py's live random-row probe also
+    # launches k_spmm_wave, with more bytes per launch than a layer: it must not be mistaken for the layer), else the
+    # one-wave-per-row kernel and its long-row reduce
+    seg = [k for k in fs if k.startswith('k_spmm_seg<')]
+    if seg:
+        spmm = seg[:1] + [k for k in fs if k.startswith(('k_spmm_reduce_direct', 'k_spmm_seg_reduce'))]
+    else:
+        main = [k for k in fs if k.startswith('k_spmm_wave')]
+        main = sorted(main, key=lambda k: -fs[k]['FETCH_SIZE']['mean'] * fs[k]['FETCH_SIZE']['n'])[:1]
+        spmm = main + [k for k in fs if k.startswith('k_spmm_long_reduce') and main]
     if spmm:
         k = spmm[0]
         n_main = fs[k]['FETCH_SIZE']['n']
