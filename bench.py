@@ -15,13 +15,20 @@ other single-GPU configurations -- "c4_1gpu" (config 4, U=5M I=2M nnz=100M, the 
 on, on ONE GPU), "c3" (d=128, K=4 + full-catalogue scoring) and "c5" (ltr_linear head) -- each with its own roofline,
 cpu_baseline and verify entries (--sub to choose).
 N > 1: config 4 itself, row-sharded over the N ranks (fixed total work -> "strong"), one RCCL all-gather of the
-propagated user block and one of the item block per layer, chunked so they run under the SpMM launches.
+propagated user block and one of the item block per layer, chunked so they run under the SpMM launches.  The graph is built once per
+node (rank 0) and memory-mapped by the other ranks; the line carries the ranks' device identities and a per-layer split of
+SpMM time / time waiting for a gathered block.
 
 roofline: HBM-bound SpMM.  `achieved` = ALGORITHMIC (compulsory) bytes of one layer launch / its mean duration (HIP events
 on the launch stream around the timed region), bytes = nnz*8 + (rows+1)*4 + n_src*d*4 + rows*d*4 + fused layer-sum
-traffic; `traffic` = HBM bytes per layer launch from the rocprofv3 PMC pass committed under profiles/
-(`traffic_source` names it; null when the SpMM sources changed since that pass); `gather_bound` = what the same launch
-would take if every stored entry's 4d-byte row gather ran at the random-row rate measured live for a table of this size.
+traffic (DESIGN.md §4); `traffic` = bytes that crossed the L2's fabric side per layer launch (L2 misses + write-backs;
+Infinity-Cache hits are INSIDE this figure) from the rocprofv3 PMC pass committed under profiles/, built with counter factors
+measured on known-traffic gathers (`traffic_source` names both; null when the SpMM sources changed since that pass);
+`hbm_bytes_model` = what an ideal 256 MB Infinity Cache would leave for HBM (gfx950 exposes no counter behind that cache);
+`gather_bound` = what the same launch would take if every stored entry's 4d-byte row gather ran at the random-row rate
+measured live for a table of this size.  The default scoring path (bf16 candidates + fp32 chains) carries its own roofline:
+the largest of its three floors (bf16 MFMA time, candidates' row gathers at the live random-row rate, pack + pass-bit streams)
+over the measured time of a call (`scoring.bf16_candidates.roofline`).
 cpu_baseline: the torch CPU calls the reference makes (torch.sparse.mm on the coalesced COO x K, stack+mean), timed on
 this host with all threads and with one (kind "port": oracle/torch_port.py); its output doubles as the `verify` check of
 the timed GPU output (outside the timed region).
