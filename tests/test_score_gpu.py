@@ -507,6 +507,26 @@ def test_prefilter_wide_rows_identical(cuda):
     _fused_vs_dense(cuda, u, it2.astype(np.float32), k, mask=_rand_mask(rng, b, i, 0, 60), round4=False)
 
 
+@pytest.mark.parametrize('b,i,d', [(33000, 8200, 264), (700, 16500, 960), (4100, 9000, 512)])
+def test_prefilter_wide_split_counts(cuda, b, i, d):
+    """The wide filter takes as few item splits as fill the chip once (tgcn_score_fused.hip make_plan): 1 split for hundreds of user
+    tiles, 16 for a handful, with the per-segment log capacity scaled to match (4 segments per split and user, 4096 log entries per
+    user in all).  Both ends of that range, and an odd tile count, against the fp32 path bit for bit."""
+    from textgcn_amd import scoring
+    rng = np.random.default_rng(b + d)
+    u = torch.from_numpy((rng.standard_normal((b, d)) * 0.1).astype(np.float32)).to(cuda)
+    it = torch.from_numpy((rng.standard_normal((i, d)) * 0.1).astype(np.float32)).to(cuda)
+    rp, items = _rand_mask(rng, b, i, 0, 12)
+    rpd, imd = torch.from_numpy(rp.astype(np.int32)).to(cuda), torch.from_numpy(items.astype(np.int32)).to(cuda)
+    rv, ri = scoring.score_topk(u, it, 40, mask_rowptr=rpd, mask_items=imd, round4=False)
+    pv, pi = scoring.score_topk(u, it, 40, mask_rowptr=rpd, mask_items=imd, round4=False, prefilter=True, slot=5)
+    torch.cuda.synchronize()
+    assert torch.equal(pi, ri) and np.array_equal(bits(pv.cpu().numpy()), bits(rv.cpu().numpy()))
+    st = scoring.call_stats(cuda, b, i, d, 40, True, slot=5)
+    assert st['fallback_users'] <= max(2, b // 2000), st
+    assert b * 40 <= st['kept_pairs'] <= st['rescored_pairs'] <= st['logged_pairs'], st
+
+
 @pytest.mark.parametrize('b,i,d', [(2048, 50000, 64), (2048, 60000, 128)])
 def test_prefilter_keeps_the_fallback_rare(cuda, b, i, d):
     """The exact fallback hides a filter that loses or floods candidates (the results stay right, the call gets slow): on
