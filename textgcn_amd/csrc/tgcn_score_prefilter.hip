@@ -770,7 +770,8 @@ __global__ __launch_bounds__(512) void k_score_prefilter_wide(const PreWideArgs 
                     if (ch == 0 && s == 0)
                         for (int r = 0; r < 16; ++r)
                             c0[r] = 0.f, c1[r] = 0.f;
-                    c0[s & 15] += __builtin_bit_cast(f32x16, (unsigned __attribute__((ext_vector_type(16)))){0})[0] + __uint_as_float(__builtin_bit_cast(uint4, f0[s]).x ^ __builtin_bit_cast(uint4, bfr[ch * HK + s]).x);
+                    // (two vector adds that consume what the MFMA pair would: the fragments must still arrive)
+                    c0[s & 15] += __uint_as_float(__builtin_bit_cast(uint4, f0[s]).x ^ __builtin_bit_cast(uint4, bfr[ch * HK + s]).x);
                     c1[s & 15] += __uint_as_float(__builtin_bit_cast(uint4, f1[s]).x);
                 } else if (ch == 0 && s == 0) {       // a unit's first k-step starts its sums from zero (no register clearing)
                     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
