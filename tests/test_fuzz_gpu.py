@@ -89,3 +89,65 @@ def test_spmm_random_graphs_vs_oracle(cuda, oracle, block):
         # entries summed in chunks instead of one chain) reach 2.3e-5 after three layers at 25x scale; everything else stays < 1e-5
         out = prop.forward(xd, K, single=single).cpu().numpy()
         assert normwise(out, want) <= 1e-4, (what, 'forward', K, single)
+
+
+def _ltr_case(seed, tmp_path, pop):
+    import types
+
+    import pandas as pd
+    from textgcn_amd import synth
+    from textgcn_amd.graph import NormGraph
+    from textgcn_amd.ltr import LTRLinear, LTRLinearWPop
+    rng = np.random.default_rng(20_000 + seed)
+    n_u = int(rng.choice([3, 33, 130, 700]))
+    n_i = int(rng.choice([5, 64, 257, 2100]))
+    d = int(rng.choice([8, 16, 48, 64, 128]))
+    tw = int(rng.choice([4, 8, 20, 100, 384]))
+    nnz = int(min(n_u * n_i // 2, rng.choice([10, 300, 4000])))
+    u, i = synth.interactions(n_u, n_i, max(nnz, 1), seed=seed)
+    test_u = np.arange(n_u)
+    test_i = rng.integers(0, n_i, size=n_u)
+    train = pd.DataFrame({'user_id': u, 'asin': i})
+    test = pd.DataFrame({'user_id': test_u, 'asin': test_i})
+    t = lambda r, c: torch.from_numpy(rng.standard_normal((r, c)).astype(np.float32))  # noqa: E731
+    ds = types.SimpleNamespace(
+        n_users=n_u, n_items=n_i, graph=NormGraph.from_pairs(u, i, n_u, n_i), norm_matrix=None,
+        true_test_lil=test.groupby('user_id')['asin'].aggregate(list).values.tolist(),
+        train_user_dict=train.groupby('user_id')['asin'].aggregate(list), test_df=test,
+        user_mapping=pd.DataFrame({'remap_id': range(n_u), 'org_id': range(n_u)}),
+        item_mapping=pd.DataFrame({'remap_id': range(n_i), 'org_id': range(n_i)}), all_items=range(n_i),
+        items_as_desc=t(n_i, tw), items_as_avg_reviews=t(n_i, tw), users_as_avg_reviews=t(n_u, tw), users_as_avg_desc=t(n_u, tw),
+        popularity_users=t(n_u, 1), popularity_items=t(n_i, 1))
+    kmax = int(min(n_i - int(train.groupby('user_id').size().max()), rng.choice([1, 5, 40])))
+    p = types.SimpleNamespace(k=[max(kmax, 1)], emb_size=d, n_layers=int(rng.integers(1, 4)), device='cuda:0', load=None, load_base=None,
+                              freeze=True, batch_size=int(rng.choice([16, 2048])), quiet=True, ltr_layers=[[], [3]][int(rng.integers(0, 2))],
+                              save_path=str(tmp_path))
+    m = (LTRLinearWPop if pop else LTRLinear)(p, ds)
+    return m, ds, dict(seed=seed, n_users=n_u, n_items=n_i, d=d, text=tw, k=p.k, layers=p.ltr_layers, pop=pop)
+
+
+@pytest.mark.parametrize('pop', [False, True])
+def test_ltr_folded_scores_random_widths(cuda, tmp_path, pop):
+    """LTRLinear / LTRLinearWPop at table widths the goldens do not have: the folded one-GEMM score against the reference's
+    five-feature formula restated in torch (ltr_models.py:131-146, 181-190, 233-241), and predict_tensors (fold -> fused top-k,
+    bf16 candidates) against mask + top-k over the model's own [B, I] score matrix, bit for bit."""
+    from textgcn_amd import scoring
+    for seed in range(8 * SCALE):
+        m, ds, what = _ltr_case(seed, tmp_path, pop)
+        with torch.no_grad():
+            ue, ie = m.representation
+            users = torch.arange(m.n_users, device=cuda)
+            s = m.score_batchwise(ue[users], ie, users)
+            feats = [ue @ ie.T, m.users_as_avg_reviews @ m.items_as_avg_reviews.T, m.users_as_avg_desc @ m.items_as_desc.T,
+                     m.users_as_avg_reviews @ m.items_as_desc.T, m.users_as_avg_desc @ m.items_as_avg_reviews.T]
+            if pop:
+                feats += [m.popularity_users.expand(-1, m.n_items), m.popularity_items.T.expand(m.n_users, -1)]
+            ref = m.layers(torch.stack([f.double() for f in feats], dim=-1).float()).squeeze(-1)
+            assert normwise(s.cpu().numpy(), ref.cpu().numpy()) <= 1e-4, what
+            val, idx = m.predict_tensors(np.arange(m.n_users))
+            rp, items = ds.graph.train_mask()
+            sm = s.clone()
+            scoring.mask_train(sm, torch.as_tensor(rp, dtype=torch.int32, device=cuda), torch.as_tensor(items, dtype=torch.int32, device=cuda))
+            rv, ri = scoring.topk(sm, max(m.k), round4=True)
+        assert torch.equal(idx, ri), (what, int((idx != ri).sum()))
+        assert np.array_equal(bits(val.cpu().numpy()), bits(rv.cpu().numpy())), what
