@@ -151,3 +151,74 @@ def test_ltr_folded_scores_random_widths(cuda, tmp_path, pop):
             rv, ri = scoring.topk(sm, max(m.k), round4=True)
         assert torch.equal(idx, ri), (what, int((idx != ri).sum()))
         assert np.array_equal(bits(val.cpu().numpy()), bits(rv.cpu().numpy())), what
+
+
+def test_training_step_random_shapes_vs_float64_autograd(cuda, tmp_path):
+    """get_loss + backward of the fused native step (edge dropout as value masking, K-layer forward, BPR over 1-3 negatives, L2,
+    the transposed propagation) against the reference's formulas (base_model.py:77-86, 93-106, 181-210) restated densely in float64
+    with torch autograd on the CPU; the dropout draw is the reference's own CPU stream (dropout_rng='cpu')."""
+    import types
+
+    import pandas as pd
+    import torch.nn.functional as F
+    from textgcn_amd import synth
+    from textgcn_amd.graph import NormGraph
+    from textgcn_amd.model import LightGCN
+    for seed in range(10 * SCALE):
+        rng = np.random.default_rng(30_000 + seed)
+        n_u, n_i = int(rng.choice([2, 40, 300])), int(rng.choice([3, 65, 200]))
+        nnz = int(min(n_u * n_i // 2, rng.choice([5, 400, 3000])))
+        u, i = synth.interactions(n_u, n_i, max(nnz, 1), seed=seed, zipf=float(rng.choice([0.0, 1.0])))
+        gr = NormGraph.from_pairs(u, i, n_u, n_i)
+        d, K = int(rng.choice([8, 32, 64, 100, 128, 256])), int(rng.integers(1, 5))
+        n_neg, p = int(rng.integers(1, 4)), float(rng.choice([0.0, 0.3]))
+        single, exact = bool(rng.random() < 0.3), bool(rng.random() < 0.5)
+        b = int(rng.choice([1, 7, 64, 500]))
+        what = dict(seed=seed, n_users=n_u, n_items=n_i, nnz=int(gr.nnz), d=d, K=K, n_neg=n_neg, p=p, single=single, exact=exact, b=b)
+        train = pd.DataFrame({'user_id': u, 'asin': i})
+        ds = types.SimpleNamespace(n_users=n_u, n_items=n_i, graph=gr, norm_matrix=None, test_df=train,
+                                   true_test_lil=train.groupby('user_id')['asin'].aggregate(list).values.tolist(),
+                                   train_user_dict=train.groupby('user_id')['asin'].aggregate(list),
+                                   user_mapping=pd.DataFrame({'remap_id': range(n_u), 'org_id': range(n_u)}),
+                                   item_mapping=pd.DataFrame({'remap_id': range(n_i), 'org_id': range(n_i)}))
+        lam = float(rng.choice([0.0, 1e-4, 1e-2]))
+        m = LightGCN(types.SimpleNamespace(k=[1], emb_size=d, n_layers=K, device='cuda:0', load=None, batch_size=2048, quiet=True, save=False,
+                                           dropout=p, single=single, exact=exact, lr=1e-3, epochs=1, reg_lambda=lam, evaluate_every=1,
+                                           neg_samples=n_neg, save_path=str(tmp_path), uid='f', dropout_rng='cpu'), ds)
+        assert m._native_loss(), what
+        batch = np.concatenate([rng.integers(0, n_u, size=(b, 1)), rng.integers(0, n_i, size=(b, 1 + n_neg))], axis=1)
+        m.training = True
+        torch.manual_seed(seed)
+        loss = m.get_loss(torch.from_numpy(batch))
+        loss.backward()
+        # ---- the reference's step in float64 on the CPU
+        torch.manual_seed(seed)
+        idx, val = gr.to_coo()
+        v = torch.from_numpy(val).double()
+        if p > 0:
+            keep = torch.rand(gr.nnz) < 1 - p                            # base_model.py:82-84 (the same CPU stream)
+            v = torch.where(keep, v / (1 - p), torch.zeros_like(v))
+        A = torch.zeros((gr.n, gr.n), dtype=torch.float64)
+        A[torch.from_numpy(idx[0]), torch.from_numpy(idx[1])] = v
+        eu = m.embedding_user.weight.detach().cpu().double().requires_grad_(True)
+        ei = m.embedding_item.weight.detach().cpu().double().requires_grad_(True)
+        layers = [torch.cat([eu, ei])]
+        for _ in range(K):
+            layers.append(A @ layers[-1])
+        e = layers[-1] if single else torch.stack(layers).mean(0)
+        au, ai = e[:n_u], e[n_u:]
+        bt = torch.from_numpy(batch)
+        us, pos, negs = bt[:, 0], bt[:, 1], [bt[:, 2 + j] for j in range(n_neg)]
+        s_pos = (au[us] * ai[pos]).sum(1)
+        bpr = torch.stack([F.selu((au[us] * ai[n]).sum(1) - s_pos).mean() for n in negs]).sum() / n_neg
+        sq = lambda t: t.norm(2).pow(2)  # noqa: E731
+        reg = (sq(eu[us]) + sq(ei[pos]) + sq(ei[torch.stack(negs)]).mean()) * (lam / (2 * b))
+        (bpr + reg).backward()
+        ref = float((bpr + reg).detach())
+        assert abs(float(loss) - ref) <= 2e-5 * abs(ref) + 1e-7, (what, float(loss), ref)
+        # (a batch whose negative IS its positive has an exactly zero float64 gradient and fp32 rounding residue around it:
+        # the bar is relative to the largest gradient entry with a floor at the rounding of one term, eps * max|E0|)
+        floor = 1e-7 * float(max(eu.detach().abs().max(), ei.detach().abs().max()))
+        for got, want in ((m.embedding_user.weight.grad, eu.grad), (m.embedding_item.weight.grad, ei.grad)):
+            err = float((got.cpu().double() - want).abs().max())
+            assert err <= 1e-4 * float(want.abs().max()) + floor, (what, err, float(want.abs().max()))
