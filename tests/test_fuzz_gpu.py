@@ -215,7 +215,7 @@ def test_training_step_random_shapes_vs_float64_autograd(cuda, tmp_path):
         reg = (sq(eu[us]) + sq(ei[pos]) + sq(ei[torch.stack(negs)]).mean()) * (lam / (2 * b))
         (bpr + reg).backward()
         ref = float((bpr + reg).detach())
-        assert abs(float(loss) - ref) <= 2e-5 * abs(ref) + 1e-7, (what, float(loss), ref)
+        assert abs(float(loss.detach()) - ref) <= 2e-5 * abs(ref) + 1e-7, (what, float(loss.detach()), ref)
         # (a batch whose negative IS its positive has an exactly zero float64 gradient and fp32 rounding residue around it:
         # the bar is relative to the largest gradient entry with a floor at the rounding of one term, eps * max|E0|)
         floor = 1e-7 * float(max(eu.detach().abs().max(), ei.detach().abs().max()))
