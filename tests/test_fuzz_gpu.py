@@ -222,3 +222,62 @@ def test_training_step_random_shapes_vs_float64_autograd(cuda, tmp_path):
         for got, want in ((m.embedding_user.weight.grad, eu.grad), (m.embedding_item.weight.grad, ei.grad)):
             err = float((got.cpu().double() - want).abs().max())
             assert err <= 1e-4 * float(want.abs().max()) + floor, (what, err, float(want.abs().max()))
+
+
+def test_predict_and_evaluate_random_datasets_vs_oracle(cuda, oracle, tmp_path):
+    """The whole inference path of the model class (BaseModel.predict / evaluate, base_model.py:212-276) in exact mode against the
+    oracle chained end to end: propagate -> dense scores -> train mask -> top-k (+ round) -> metrics.  Lists and scores bit for
+    bit (finite prefix: the order among masked -inf items is undefined in the reference too), metrics to 1e-12; the users asked
+    for come as a shuffled subset, in chunks smaller and larger than the batch, with and without the bf16 candidate pass."""
+    import types
+
+    import pandas as pd
+    from textgcn_amd import synth
+    from textgcn_amd.graph import NormGraph
+    from textgcn_amd.model import LightGCN
+    for seed in range(8 * SCALE):
+        rng = np.random.default_rng(70_000 + seed)
+        n_u, n_i = int(rng.choice([3, 90, 700, 2300])), int(rng.choice([6, 130, 1100, 9000]))
+        nnz = int(min(n_u * n_i // 3, rng.choice([20, 900, 12000])))
+        u, i = synth.interactions(n_u, n_i, max(nnz, 1), seed=seed, zipf=float(rng.choice([0.0, 0.8])))
+        gr = NormGraph.from_pairs(u, i, n_u, n_i)
+        max_train = int(np.bincount(u, minlength=n_u).max())
+        ks = sorted(set(int(k) for k in rng.choice(np.arange(1, max(2, min(n_i - max_train, 50))), size=2)))
+        d, K, single = int(rng.choice([16, 64, 100, 128])), int(rng.integers(1, 5)), bool(rng.random() < 0.3)
+        test_u = rng.integers(0, n_u, size=max(1, n_u // 2))
+        test = pd.DataFrame({'user_id': test_u, 'asin': rng.integers(0, n_i, size=len(test_u))}).sort_values('user_id')
+        train = pd.DataFrame({'user_id': u, 'asin': i})
+        ds = types.SimpleNamespace(n_users=n_u, n_items=n_i, graph=gr, norm_matrix=None, test_df=test,
+                                   true_test_lil=test.groupby('user_id')['asin'].aggregate(list).values.tolist(),
+                                   train_user_dict=train.groupby('user_id')['asin'].aggregate(list),
+                                   user_mapping=pd.DataFrame({'remap_id': range(n_u), 'org_id': range(n_u)}),
+                                   item_mapping=pd.DataFrame({'remap_id': range(n_i), 'org_id': range(n_i)}))
+        m = LightGCN(types.SimpleNamespace(k=ks, emb_size=d, n_layers=K, device='cuda:0', load=None, batch_size=int(rng.choice([7, 256, 2048])),
+                                           quiet=True, save=False, dropout=0.4, single=single, exact=True, lr=1e-3, epochs=1, reg_lambda=1e-4,
+                                           evaluate_every=1, neg_samples=1, save_path=str(tmp_path), uid='p'), ds)
+        m.score_prefilter = bool(rng.random() < 0.6)
+        what = dict(seed=seed, n_users=n_u, n_items=n_i, nnz=int(gr.nnz), d=d, K=K, single=single, ks=ks, batch=m.batch_size,
+                    prefilter=m.score_prefilter)
+        e0 = np.concatenate([m.embedding_user.weight.detach().cpu().numpy(), m.embedding_item.weight.detach().cpu().numpy()])
+        idx, val = gr.to_coo()
+        rep, _ = oracle.propagate(idx, val, e0, K, single=single)
+        users = rng.permutation(n_u)[:max(1, int(n_u * rng.random()))]
+        s = oracle.score_dense(rep[:n_u][users], rep[n_u:])
+        rp, items = oracle.train_mask_csr(u, i, users)
+        oracle.mask_train(s, rp, items)
+        want_v, want_i = oracle.topk(s, max(ks), round4=True)
+        pred, scores = m.predict(users, with_scores=True)
+        pred, scores = np.asarray(pred), np.asarray(scores, dtype=np.float32)
+        fin = np.isfinite(want_v)
+        assert np.array_equal(pred[fin], want_i[fin]), (what, int((pred[fin] != want_i[fin]).sum()))
+        assert np.array_equal(bits(scores[fin]), bits(want_v[fin])), what
+        # evaluate(): the test users, metrics of the reference's calculate_metrics
+        tu = np.sort(test['user_id'].unique())
+        s = oracle.score_dense(rep[:n_u][tu], rep[n_u:])
+        rp, items = oracle.train_mask_csr(u, i, tu)
+        oracle.mask_train(s, rp, items)
+        _, ti = oracle.topk(s, max(ks), round4=True)
+        want = oracle.metrics(ds.true_test_lil, ti, ks)
+        got = m.evaluate()
+        for name in ('recall', 'precision', 'hit', 'ndcg', 'f1'):
+            assert np.allclose(got[name], want[name], atol=1e-12), (what, name)
