@@ -57,6 +57,24 @@ def test_sharded_forward_matches_oracle_gloo(oracle, tmp_path, world, balance, c
         assert len(set(np.diff(got['item_bounds']))) > 1
 
 
+@pytest.mark.parametrize('world,n_users,n_items,nnz,d,chunks,balance', [
+    (2, 3, 2, 4, 8, 2, 'nnz'),          # fewer rows than ranks x chunks: empty chunks, a rank without item rows
+    (3, 5, 97, 300, 16, 4, 'rows'),     # user blocks of one or two rows, four chunks each
+    (3, 203, 2, 300, 64, 1, 'nnz'),     # two items for three ranks: one rank owns no item row at all
+    (4, 61, 7, 200, 32, 3, 'nnz'),      # world 4
+    (2, 1, 1, 1, 100, 1, 'rows'),       # one edge, a width that is no power of two
+])
+def test_sharded_forward_corner_shapes_gloo(oracle, tmp_path, world, n_users, n_items, nnz, d, chunks, balance):
+    """Blocks, padding and chunking at shapes where some rank's block (or chunk) is empty: still the oracle's bits."""
+    out = str(tmp_path / 'r0.npz')
+    run_ranks(world, 'cpu', out, extra=('--balance', balance, '--chunks', str(chunks), '--n-users', str(n_users), '--n-items', str(n_items),
+                                        '--nnz', str(nnz), '--d', str(d), '--layers', '2'))
+    got = np.load(out)
+    ru, ri = reference(oracle, n_users=n_users, n_items=n_items, nnz=nnz, d=d, layers=2)
+    assert np.array_equal(bits(got['users']), bits(ru))
+    assert np.array_equal(bits(got['items']), bits(ri))
+
+
 def test_padded_layout_and_local_blocks():
     from textgcn_amd.dist import BlockLayout, equal_row_bounds, padded_layout
     assert padded_layout(203, 97, 3) == (68, 33, 204, 99)
