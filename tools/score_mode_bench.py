@@ -32,10 +32,15 @@ def main():
     ap.add_argument('--reps', type=int, default=10)
     ap.add_argument('--k', type=int, default=40)
     ap.add_argument('--streams', default='1,3')
+    ap.add_argument('--users', type=int, default=0, help='users per call instead of the shape\'s (same number of calls)')
+    ap.add_argument('--calls', type=int, default=0)
+    ap.add_argument('--modes', default='fp32,prefilter,prefilter+pack')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     for name in args.shapes.split(','):
         b, calls, n_items, d = SHAPES[name]
+        b = args.users or b
+        calls = args.calls or calls
         g = torch.Generator().manual_seed(0)
         n_users = b * calls
         ue = (torch.randn(n_users, d, generator=g) * 0.1).to(dev)
@@ -55,6 +60,8 @@ def main():
                  'prefilter+pack': dict(prefilter=True, item_pack=pack)}
         ref = None
         for mode, kw in modes.items():
+            if mode not in args.modes.split(',') and mode != 'fp32':
+                continue
             for n_streams in [int(x) for x in args.streams.split(',')]:
                 main_s = torch.cuda.current_stream(dev)
                 side = [torch.cuda.Stream(dev) for _ in range(n_streams)]
