@@ -114,6 +114,9 @@ bool prefilter_supports(int d);
 int launch_item_norms(const float *It, int I, int d, float *norms /* [I][2] */, hipStream_t stream);
 int launch_sample_bf16(const float *U, const int64_t *user_ids, int B, const float *It, int m, int d, int stride, float *S, int64_t ld,
                        hipStream_t stream);      // d <= 128
+bool sample_top_supports(int d, int m);     // m sampled items
+int launch_sample_top(const float *U, const int64_t *user_ids, int B, const float *It, int m, int d, int stride, const int *mask_rowptr,
+                      const int *mask_items, unsigned *bits, float *S, int64_t ld, hipStream_t stream);      // d <= 128
 int launch_user_bound(const float *U, const int64_t *user_ids, int B, int d, float *ubound /* [B][2] */, hipStream_t stream);
 size_t item_pack_bytes(int I, int d);      // 0: no bf16 candidate pass for this width
 int launch_item_pack(const float *It, int I, int d, void *pack, hipStream_t stream);

@@ -4,11 +4,12 @@
 // TextGCN/base_model.py:254-263.  gfx950 only.
 //
 // Plan (all launches on one stream, no host round trip):
-//   1. threshold estimate.  Score every user against a strided sample of the items (every `kSampleStride`-th
-//      item, same MFMA kernel as the dense path), mask the sampled train items, take the r-th largest sample
-//      score as tau_u.  With r = 10 and stride 32 the true rank of tau_u among all items is ~320 +- 100, and the
-//      chance that it falls below k = 40 (10 of a user's true top-40 inside the 1/32 sample) is ~7e-7 (r = 8: 7e-5,
-//      which at 16384 users per call meant a fallback launch with real work in two calls out of three).
+//   1. threshold estimate.  Score every user against a strided sample of the items (every 32nd item, every 16th for
+//      narrow rows -- make_plan), mask the sampled train items, take the r-th largest sample score as tau_u.  The bar
+//      must not land above the user's k-th best score (the user then pays step 4): that takes r of its best k - 1 items
+//      inside the sample, P(Bin(k - 1, 1 / stride) >= r); r is the smallest rank that keeps this under 3e-6 per user
+//      (k = 40: r = 10 at stride 32, ~320 candidates per user; r = 12 at stride 16, ~190.  At 7e-5, r = 8 of 32, a
+//      16384-user call had a fallback launch with real work two times out of three).
 //   2. k_score_filter: the fp32 MFMA GEMM over ALL items; the 32x32 accumulators are compared against tau_u in
 //      registers and only scores > tau_u are written, as (score, item) pairs, to a log private to the lane that
 //      owns that (user, row-half) -- no atomics, no [B, I] traffic.  Items on MFMA rows (A operand, staged
@@ -33,8 +34,8 @@ namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int kSampleStride = 32;  // items per sampled item
-constexpr int kTauRank = 10;       // tau = kTauRank-th largest masked sample score
+constexpr int kSampleStride = 32;  // items per sampled item (16 where the denser sample pays: make_plan)
+constexpr double kBarRisk = 3e-6;  // per user: the chance that the bar tau_u lands above the user's k-th best score (-> exact fallback)
 constexpr int kUsersPerWG = 128;   // 4 waves x 32 users
 constexpr int kStage = 64;         // items per LDS stage (2 MFMA sub-tiles of 32)
 constexpr int kSmallI = 8192;      // below this the dense path (score -> mask -> top-k) is used
@@ -485,9 +486,9 @@ struct SelectArgs {
 constexpr int kMaskCache = 512;  // train items per user cached in LDS for the membership test
 
 // ---- threshold from the strided sample: one wave per user ---------------------------------------------------------------
-// tau_u = the kTauRank-th largest of the user's sampled scores after its sampled train items are dropped.  The row is
+// tau_u = the rank-th largest of the user's sampled scores after its sampled train items are dropped.  The row is
 // staged in LDS (coalesced load, mask applied by the lanes that own the train items), read back VPL values per lane, and
-// the maximum is extracted kTauRank times (per-lane max, wave max, the owning lane retires one copy).  Replaces the
+// the maximum is extracted `rank` times (per-lane max, wave max, the owning lane retires one copy).  Replaces the
 // k_mask + k_topk pair on the sample (28 us for 2048 x 1563 -> ~4 us) and zeroes the fallback counter for this call.
 // Prefilter mode (ubound != NULL): the user's factors {n_u, r_u} of tgcn_score_prefilter.hip's bound are written too -- the row
 // is fetched before the rounds and costs no extra launch.
@@ -495,7 +496,7 @@ template <int VPL>
 __global__ __launch_bounds__(256) void k_tau(const float *__restrict__ Ss, int m_ld, int B, int m, const int *__restrict__ mask_rowptr,
                                              const int *__restrict__ mask_items, float *__restrict__ tau, int *__restrict__ flagged,
                                              int *__restrict__ done, const float *__restrict__ U, const int64_t *__restrict__ user_ids,
-                                             int d, float *__restrict__ ubound, int *__restrict__ totals)
+                                             int d, float *__restrict__ ubound, int *__restrict__ totals, int stride, int rank)
 {
     extern __shared__ float srow[];   // [4][64 * VPL]
     const int lane = lane_id();
@@ -543,14 +544,14 @@ __global__ __launch_bounds__(256) void k_tau(const float *__restrict__ Ss, int m
     {
         for (int e = mb + lane; e < me; e += kWave) {
             const int it = mask_items[e];
-            if (it % kSampleStride == 0 && it / kSampleStride < m)
-                row[it / kSampleStride] = -INFINITY;
+            if (it % stride == 0 && it / stride < m)
+                row[it / stride] = -INFINITY;
         }
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
-    // the lane's two largest values, then kTauRank rounds of (wave maximum, its first owner retires one copy).  A lane that
-    // holds three or more of the row's kTauRank largest gives a slightly lower tau than the exact rank: tau is only a bar that
+    // the lane's two largest values, then `rank` rounds of (wave maximum, its first owner retires one copy).  A lane that
+    // holds three or more of the row's `rank` largest gives a slightly lower tau than the exact rank: tau is only a bar that
     // at least k items must clear (k_select checks that), not a result.
     float a0 = -INFINITY, a1 = -INFINITY;
 #pragma unroll
@@ -560,7 +561,7 @@ __global__ __launch_bounds__(256) void k_tau(const float *__restrict__ Ss, int m
         a0 = fmaxf(a0, x);
     }
     float t = -INFINITY;
-    for (int r = 0; r < kTauRank; ++r) {
+    for (int r = 0; r < rank; ++r) {
         t = wave_max_all(a0);
         const int owner = __ffsll((long long)__ballot(a0 == t)) - 1;
         if (lane == owner) {
@@ -1159,6 +1160,10 @@ __global__ __launch_bounds__(kBruteWaves * 64) void k_brute_part(const BruteArgs
 
 struct Plan {
     int S, items_per_split, cap2, m, m_ld;  // m = sampled items
+    int stride, rank;                       // the sample: every stride-th item; tau = the rank-th largest sampled score
+    int m_rank;                             // values per user k_tau ranks: m, or (top form) the two largest of every 128-sample block
+    bool top;                               // d <= 128: the sample's scores stay inside the sample kernel (launch_sample_top)
+    size_t off_bits;                        // top form: train-item bitmap over the sample, [B][4 ceil(m / 128)] words
     int S_w, ips_w, cap2_w;                 // wide bf16 filter: its own (at most 16) item splits -- 4 log segments of cap2_w per split and user
     int Wh;                                 // mask words per (user, row half): the 64-item units of the catalogue, padded to 4
     size_t off_mask;
@@ -1170,9 +1175,30 @@ struct Plan {
 
 size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
+// The bar tau_u must not land above the user's k-th best score, or the user pays the exact fallback: that takes `rank` of its best
+// k - 1 items inside the sample, P = P(Bin(k - 1, 1 / stride) >= rank).  The smallest rank with P <= kBarRisk; the candidates
+// a user then brings to the filter's logs / the rescoring number ~rank x stride.
+int bar_rank(int k, int stride)
+{
+    const int n = max(k - 1, 0);
+    const double q = 1.0 / stride;
+    for (int r = 4; r < 64; ++r) {
+        double pmf = 1.0, tail = 0.0;       // pmf(j) = C(n, j) q^j (1 - q)^(n - j), built up from j = 0
+        for (int j = 0; j < n; ++j)
+            pmf *= 1.0 - q;
+        for (int j = 0; j <= n; ++j) {
+            if (j >= r)
+                tail += pmf;
+            pmf *= (double)(n - j) / (j + 1) * q / (1.0 - q);
+        }
+        if (tail <= kBarRisk)
+            return r;
+    }
+    return 64;
+}
+
 Plan make_plan(int B, int I, int d, int k)
 {
-    (void)k;
     Plan p{};
     p.small = I <= kSmallI;
     if (p.small) {
@@ -1191,12 +1217,26 @@ Plan make_plan(int B, int I, int d, int k)
     p.cap2 = max(32, 1024 / (2 * p.S));
     if (d > 128 && prefilter_supports(d))
         p.cap2 = max(p.cap2, 64);      // the wide bf16 filter logs its (more numerous) raised candidates in these segments
-    p.m = (I + kSampleStride - 1) / kSampleStride;
-    p.m_ld = (p.m + 3) & ~3;  // row stride of the sample score matrix (16-byte aligned rows)
+    // A sample twice as dense halves the distance between the bar and the k-th score: k = 40 -> rank 10 of every 32nd item = ~320
+    // candidates per user, rank 12 of every 16th = ~190 -- the fp32 rescoring of the bf16 path (a third of a narrow call, at the
+    // random-row rate) and the filters' appends shrink with them.  Narrow rows only: their sample runs on the bf16 pipe and keeps
+    // its scores to itself (the TOP form of k_sample_bf16: two values per user and 128-sample block reach k_tau), so the denser
+    // sample costs MFMAs, not traffic.  At K = 960 the sample is a tenth of the filter and k_refine's second bar decides what is
+    // rescored: every 32nd item, all scores to k_tau, as before.
+    p.top = sample_top_supports(d, (I + 15) / 16);      // (up to 1.5 M items: the bitmap row of k_sample_bits lives in LDS)
+    p.stride = p.top ? 16 : kSampleStride;
+    p.rank = bar_rank(k, p.stride);
+    p.m = (I + p.stride - 1) / p.stride;
+    const int n_blk = (p.m + 127) / 128;
+    p.m_rank = p.top ? 2 * n_blk : p.m;
+    p.m_ld = (p.m_rank + 3) & ~3;  // row stride of the sample score matrix (16-byte aligned rows)
     size_t o = 0;
     p.off_sample = o, o += align256((size_t)B * p.m_ld * sizeof(float));
-    p.off_tauv = o, o += align256((size_t)B * kTauRank * sizeof(float));
-    p.off_taui = o, o += align256((size_t)B * kTauRank * sizeof(int64_t));
+    p.off_bits = o;
+    if (p.top)
+        o += align256((size_t)B * 4 * n_blk * sizeof(unsigned));
+    p.off_tauv = o, o += align256((size_t)B * p.rank * sizeof(float));
+    p.off_taui = o, o += align256((size_t)B * p.rank * sizeof(int64_t));
     p.off_tau = o, o += align256((size_t)B * sizeof(float));
     p.off_ubound = o, o += align256((size_t)B * 2 * sizeof(float));         // prefilter mode: the users' factors of the bound
     p.off_ipack = o;                                                       // ... and the packed item operand (unless the caller
@@ -1390,21 +1430,26 @@ int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const fl
     int *done = reinterpret_cast<int *>(ws + p.off_done);
     int *totals = prefilter ? reinterpret_cast<int *>(ws + p.off_totals) : nullptr;
     // (the sample is only ranked -- tau is a bar, never a result: up to d = 128 it comes from the bf16 pipe in both entry points)
-    if ((rc = d <= 128    ? launch_sample_bf16(U, user_ids, B, It, p.m, d, kSampleStride, Ss, p.m_ld, s)
-              : prefilter ? launch_sample_wide(U, user_ids, B, ipack, I, p.m, d, kSampleStride, Ss, p.m_ld, s)      // (from the pack)
-                          : launch_score_dense(U, user_ids, B, It, p.m, d, kSampleStride, Ss, p.m_ld, s)) != TGCN_OK)
+    if ((rc = p.top       ? launch_sample_top(U, user_ids, B, It, p.m, d, p.stride, mask_rowptr, mask_items,
+                                              reinterpret_cast<unsigned *>(ws + p.off_bits), Ss, p.m_ld, s)     // (train items masked inside)
+              : d <= 128  ? launch_sample_bf16(U, user_ids, B, It, p.m, d, p.stride, Ss, p.m_ld, s)
+              : prefilter ? launch_sample_wide(U, user_ids, B, ipack, I, p.m, d, p.stride, Ss, p.m_ld, s)      // (from the pack)
+                          : launch_score_dense(U, user_ids, B, It, p.m, d, p.stride, Ss, p.m_ld, s)) != TGCN_OK)
         return rc;
     const float *tau_ptr;
     int tau_stride;
-    if (p.m <= 64 * kWave) {   // one wave per user: mask + rank-kTauRank selection in one launch
+    const int *mask_rowptr_tau = mask_rowptr;      // (the top form's values are masked already)
+    if (p.m_rank <= 64 * kWave) {   // one wave per user: mask + rank selection in one launch
         const dim3 grid((B + 3) / 4);
-        const int vpl = p.m <= 8 * kWave ? 8 : p.m <= 16 * kWave ? 16 : p.m <= 32 * kWave ? 32 : 64;
+        const int vpl = p.m_rank <= 8 * kWave ? 8 : p.m_rank <= 16 * kWave ? 16 : p.m_rank <= 32 * kWave ? 32 : 64;
         const size_t lds = (size_t)4 * kWave * vpl * sizeof(float);
+        if (p.top)
+            mask_rowptr_tau = nullptr;
         switch (vpl) {
-            case 8: hipLaunchKernelGGL((k_tau<8>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, tau1, flagged, done, U, user_ids, d, ubound, totals); break;
-            case 16: hipLaunchKernelGGL((k_tau<16>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, tau1, flagged, done, U, user_ids, d, ubound, totals); break;
-            case 32: hipLaunchKernelGGL((k_tau<32>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, tau1, flagged, done, U, user_ids, d, ubound, totals); break;
-            default: hipLaunchKernelGGL((k_tau<64>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, tau1, flagged, done, U, user_ids, d, ubound, totals); break;
+            case 8: hipLaunchKernelGGL((k_tau<8>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m_rank, mask_rowptr_tau, mask_items, tau1, flagged, done, U, user_ids, d, ubound, totals, p.stride, p.rank); break;
+            case 16: hipLaunchKernelGGL((k_tau<16>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m_rank, mask_rowptr_tau, mask_items, tau1, flagged, done, U, user_ids, d, ubound, totals, p.stride, p.rank); break;
+            case 32: hipLaunchKernelGGL((k_tau<32>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m_rank, mask_rowptr_tau, mask_items, tau1, flagged, done, U, user_ids, d, ubound, totals, p.stride, p.rank); break;
+            default: hipLaunchKernelGGL((k_tau<64>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m_rank, mask_rowptr_tau, mask_items, tau1, flagged, done, U, user_ids, d, ubound, totals, p.stride, p.rank); break;
         }
         if ((rc = check_launch("k_tau")) != TGCN_OK)
             return rc;
@@ -1413,11 +1458,11 @@ int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const fl
         // the fallback's flag count and arrival counters start from zero (the workspace arrives uninitialised)
         if (hipMemsetAsync(flagged, 0, (size_t)(ws + p.off_totals - reinterpret_cast<char *>(flagged)) + (size_t)B * sizeof(int), s) != hipSuccess)
             return check_launch("hipMemsetAsync(flagged, done)");
-        if (mask_rowptr && (rc = launch_mask(Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, kSampleStride, s)) != TGCN_OK)
+        if (mask_rowptr && (rc = launch_mask(Ss, p.m_ld, B, p.m, mask_rowptr, mask_items, p.stride, s)) != TGCN_OK)
             return rc;
-        if ((rc = launch_topk(Ss, p.m_ld, B, p.m, kTauRank, 0, tauv, taui, s)) != TGCN_OK)
+        if ((rc = launch_topk(Ss, p.m_ld, B, p.m, p.rank, 0, tauv, taui, s)) != TGCN_OK)
             return rc;
-        tau_ptr = tauv + (kTauRank - 1), tau_stride = kTauRank;
+        tau_ptr = tauv + (p.rank - 1), tau_stride = p.rank;
     }
     // 2. filtered GEMM over all items
     FilterArgs fa;

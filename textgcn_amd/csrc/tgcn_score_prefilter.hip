@@ -862,6 +862,14 @@ __global__ __launch_bounds__(512) void k_score_prefilter_wide(const PreWideArgs 
 // (A operand), items on columns: accumulator register t of lane l holds (user (t & 3) + 8 (t >> 2) + 4 (l >> 5), item l & 31),
 // so one store instruction writes 128 contiguous bytes of two user rows.  One workgroup = 256 users x 128 sampled items, no
 // loop: 16 384 users x 1563 samples took 61 us as an fp32 GEMM (k_score_dense on every 32nd item row).
+//
+// TOP form (round 3): the scores never leave the kernel.  k_tau needs the r-th largest of a user's m sampled scores; a workgroup
+// holds 128 of them per user, so it writes only each (user, block)'s TWO largest -- S[b][2 blk], S[b][2 blk + 1] -- and k_tau ranks
+// 2 ceil(m / 128) values instead of m (16 384 users x 3125 samples: 205 MB written and read back -> 3.3 MB; sample + k_tau
+// 46 + 61 us -> see DESIGN.md 4.2b).  A block that holds three or more of the user's r largest makes the bar one rank lower than
+// the exact one: more candidates, never fewer.  The sampled TRAIN items must not count: k_sample_bits turns every user's train
+// list into a bitmap over the sample first (bit j = sampled item j is a train item; 4 words per (user, block)), and the masked
+// scores enter the top-2 as -inf, as do the columns past the sample's end.
 struct SampleArgs {
     const float *__restrict__ U;
     const int64_t *__restrict__ user_ids;
@@ -869,21 +877,74 @@ struct SampleArgs {
     float *__restrict__ S;
     int64_t ld;
     int B, m, d, stride;
+    const unsigned *__restrict__ bits;   // TOP: [B][bits_words] train-item bitmap over the sample, or NULL (no mask)
+    int bits_words;
 };
 
-template <int KS, bool FULLK>
+constexpr int kSampleBitsMaxWords = 3072;     // LDS row of k_sample_bits (4 waves x 12 KB): 768 blocks = 98 304 sampled items
+
+__global__ __launch_bounds__(256) void k_sample_bits(const int *__restrict__ mask_rowptr, const int *__restrict__ mask_items,
+                                                     unsigned *__restrict__ bits, int B, int words, int stride, int m)
+{
+    extern __shared__ unsigned brow[];            // [4][words]: the wave's row is built here (ds_or), then stored once
+    const int lane = lane_id();
+    const int w = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + w;
+    if (b >= B)
+        return;
+    unsigned *row = brow + w * words;
+    const int mb = mask_rowptr[b], me = mask_rowptr[b + 1];
+    for (int j = lane; j < words; j += kWave)
+        row[j] = 0u;
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    for (int e = mb + lane; e < me; e += kWave) {
+        const int it = mask_items[e];
+        const int j = it / stride;
+        if (it % stride == 0 && j < m)
+            atomicOr(&row[j >> 5], 1u << (j & 31));
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    unsigned *__restrict__ out = bits + (size_t)b * words;
+    for (int j = lane; j < words; j += kWave)
+        out[j] = row[j];
+}
+
+// the two largest of a value pair list across the 32 lanes of a row half: DPP inside the rows of 16 (quad_perm, quad_perm,
+// row_half_mirror, row_mirror: every step pairs disjoint groups), one ds_bpermute step between the two rows
+template <int CTRL>
+__device__ __forceinline__ void top2_dpp_step(float &a0, float &a1)
+{
+    const int x0 = __float_as_int(a0), x1 = __float_as_int(a1);
+    const float p0 = __int_as_float(__builtin_amdgcn_update_dpp(x0, x0, CTRL, 0xf, 0xf, false));
+    const float p1 = __int_as_float(__builtin_amdgcn_update_dpp(x1, x1, CTRL, 0xf, 0xf, false));
+    a1 = fmaxf(fminf(a0, p0), fmaxf(a1, p1));
+    a0 = fmaxf(a0, p0);
+}
+
+template <int KS, bool FULLK, bool TOP>
 __global__ __launch_bounds__(512) void k_sample_bf16(const SampleArgs a)
 {
     constexpr int T = 512, UT = 256, SI = 128;     // threads, users and sampled items per workgroup
     constexpr int DQ = 4 * KS, RB = 32 * KS + 16;
     constexpr int NU = UT * DQ / T, NI = SI * DQ / T;
     __shared__ __attribute__((aligned(16))) unsigned char smem[(UT + SI) * RB];
+    __shared__ __attribute__((aligned(16))) unsigned mwords[TOP ? UT * 4 : 4];     // TOP: the four bitmap words of (user, this block)
     const int lane = lane_id();
     const int w = threadIdx.x >> 6;
     const int r32 = lane & 31;
     const int h = lane >> 5;
     const int u0 = blockIdx.x * UT;
     const int j0 = blockIdx.y * SI;
+    if constexpr (TOP) {
+        if (threadIdx.x < UT) {
+            const int user = min(u0 + (int)threadIdx.x, a.B - 1);
+            const u32x4 z = {0u, 0u, 0u, 0u};
+            *reinterpret_cast<u32x4 *>(mwords + 4 * threadIdx.x) =
+                a.bits ? *reinterpret_cast<const u32x4 *>(a.bits + (size_t)user * a.bits_words + 4 * blockIdx.y) : z;
+        }
+    }
     float4 vu[NU], vi[NI];
     size_t ru[NU], ri[NI];
 #pragma unroll
@@ -922,6 +983,12 @@ __global__ __launch_bounds__(512) void k_sample_bf16(const SampleArgs a)
 #pragma unroll
     for (int s = 0; s < KS; ++s)
         fu[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(smem + (w * 32 + r32) * RB + 32 * s + 16 * h));
+    float t0[TOP ? 16 : 1], t1[TOP ? 16 : 1];
+    if constexpr (TOP) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+            t0[t] = -INFINITY, t1[t] = -INFINITY;
+    }
 #pragma unroll
     for (int un = 0; un < SI / 64; ++un) {
         f32x16 c0, c1;
@@ -937,16 +1004,46 @@ __global__ __launch_bounds__(512) void k_sample_bf16(const SampleArgs a)
             c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fu[s], f1, c1, 0, 0, 0);
         }
         const int j = j0 + un * 64 + r32;
+        if constexpr (TOP) {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const uint2 mw = *reinterpret_cast<const uint2 *>(mwords + 4 * (w * 32 + (t & 3) + 8 * (t >> 2) + 4 * h) + 2 * un);
+                const unsigned w0 = mw.x, w1 = mw.y;
+                const float x0 = (j < a.m && !((w0 >> r32) & 1u)) ? c0[t] : -INFINITY;
+                const float x1 = (j + 32 < a.m && !((w1 >> r32) & 1u)) ? c1[t] : -INFINITY;
+                const float hi = fmaxf(x0, x1), lo = fminf(x0, x1);      // (a NaN score drops out: the bar is built from the rest)
+                t1[t] = fmaxf(fminf(t0[t], hi), fmaxf(t1[t], lo));
+                t0[t] = fmaxf(t0[t], hi);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int user = u0 + w * 32 + (t & 3) + 8 * (t >> 2) + 4 * h;
+                if (user < a.B) {
+                    float *__restrict__ row = a.S + (size_t)user * a.ld;
+                    if (j < a.m)
+                        row[j] = c0[t];
+                    if (j + 32 < a.m)
+                        row[j + 32] = c1[t];
+                }
+            }
+        }
+    }
+    if constexpr (TOP) {      // the two largest over the 32 lanes of the row half (the 128 columns of user t), then one 8-byte store
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-            const int user = u0 + w * 32 + (t & 3) + 8 * (t >> 2) + 4 * h;
-            if (user < a.B) {
-                float *__restrict__ row = a.S + (size_t)user * a.ld;
-                if (j < a.m)
-                    row[j] = c0[t];
-                if (j + 32 < a.m)
-                    row[j + 32] = c1[t];
+            top2_dpp_step<0xB1>(t0[t], t1[t]);      // quad_perm [1,0,3,2]
+            top2_dpp_step<0x4E>(t0[t], t1[t]);      // quad_perm [2,3,0,1]
+            top2_dpp_step<0x141>(t0[t], t1[t]);     // row_half_mirror
+            top2_dpp_step<0x140>(t0[t], t1[t]);     // row_mirror: every lane holds the two largest of its row of 16
+            {
+                const float p0 = __shfl_xor(t0[t], 16), p1 = __shfl_xor(t1[t], 16);
+                t1[t] = fmaxf(fminf(t0[t], p0), fmaxf(t1[t], p1));
+                t0[t] = fmaxf(t0[t], p0);
             }
+            const int user = u0 + w * 32 + (t & 3) + 8 * (t >> 2) + 4 * h;
+            if (r32 == 0 && user < a.B)
+                *reinterpret_cast<float2 *>(a.S + (size_t)user * a.ld + 2 * blockIdx.y) = make_float2(t0[t], t1[t]);
         }
     }
 }
@@ -1186,17 +1283,45 @@ int launch_item_norms(const float *It, int I, int d, float *norms, hipStream_t s
 int launch_sample_bf16(const float *U, const int64_t *user_ids, int B, const float *It, int m, int d, int stride, float *S, int64_t ld,
                        hipStream_t s)
 {
-    SampleArgs a{U, user_ids, It, S, ld, B, m, d, stride};
+    SampleArgs a{U, user_ids, It, S, ld, B, m, d, stride, nullptr, 0};
     const dim3 grid((B + 255) / 256, (m + 127) / 128), block(512);
     if (d == 64)
-        hipLaunchKernelGGL((k_sample_bf16<4, true>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((k_sample_bf16<4, true, false>), grid, block, 0, s, a);
     else if (d < 64)
-        hipLaunchKernelGGL((k_sample_bf16<4, false>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((k_sample_bf16<4, false, false>), grid, block, 0, s, a);
     else if (d == 128)
-        hipLaunchKernelGGL((k_sample_bf16<8, true>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((k_sample_bf16<8, true, false>), grid, block, 0, s, a);
     else
-        hipLaunchKernelGGL((k_sample_bf16<8, false>), grid, block, 0, s, a);
+        hipLaunchKernelGGL((k_sample_bf16<8, false, false>), grid, block, 0, s, a);
     return check_launch("k_sample_bf16");
+}
+
+// the TOP form: S[b][2 blk .. 2 blk + 1] = the two largest unmasked sample scores of user b in block blk (128 sampled items);
+// bits: workspace of B x 4 ceil(m / 128) words for the train-item bitmap (written here when a mask is given)
+bool sample_top_supports(int d, int m) { return d <= 128 && 4 * ((m + 127) / 128) <= kSampleBitsMaxWords; }
+
+int launch_sample_top(const float *U, const int64_t *user_ids, int B, const float *It, int m, int d, int stride, const int *mask_rowptr,
+                      const int *mask_items, unsigned *bits, float *S, int64_t ld, hipStream_t s)
+{
+    const int n_blk = (m + 127) / 128;
+    if (mask_rowptr) {
+        hipLaunchKernelGGL(k_sample_bits, dim3((B + 3) / 4), dim3(256), (size_t)4 * 4 * n_blk * sizeof(unsigned), s, mask_rowptr, mask_items, bits,
+                           B, 4 * n_blk, stride, m);
+        const int rc = check_launch("k_sample_bits");
+        if (rc != TGCN_OK)
+            return rc;
+    }
+    SampleArgs a{U, user_ids, It, S, ld, B, m, d, stride, mask_rowptr ? bits : nullptr, 4 * n_blk};
+    const dim3 grid((B + 255) / 256, n_blk), block(512);
+    if (d == 64)
+        hipLaunchKernelGGL((k_sample_bf16<4, true, true>), grid, block, 0, s, a);
+    else if (d < 64)
+        hipLaunchKernelGGL((k_sample_bf16<4, false, true>), grid, block, 0, s, a);
+    else if (d == 128)
+        hipLaunchKernelGGL((k_sample_bf16<8, true, true>), grid, block, 0, s, a);
+    else
+        hipLaunchKernelGGL((k_sample_bf16<8, false, true>), grid, block, 0, s, a);
+    return check_launch("k_sample_bf16<top>");
 }
 
 int launch_user_bound(const float *U, const int64_t *user_ids, int B, int d, float *ubound, hipStream_t s)
