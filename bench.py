@@ -315,7 +315,9 @@ def candidate_path_roofline(b, n_items, d, k_top, t_call, dev, slot=0):
             'mfma_frac_of_bf16_peak': round(t_mfma / t_call, 4), 'bf16_flop': flop, 'peak_TF': MFMA_BF16_PEAK_TF,
             'users': b, 'rescored_pairs_per_user': round(st['rescored_pairs'] / b, 1), 'kept_pairs_per_user': round(st['kept_pairs'] / b, 1),
             'logged_pairs_per_user': round(st['logged_pairs'] / b, 1), 'fallback_users': st['fallback_users'],
-            'random_row_rate_GBs': round(rate / 1e9, 1), 'gather_bytes': int(gather_bytes), 'stream_bytes': int(stream_bytes)}
+            'random_row_rate_GBs': round(rate / 1e9, 1), 'gather_bytes': int(gather_bytes), 'stream_bytes': int(stream_bytes),
+            'note': 'the gather floor is what THIS call rescored, not a constant of the shape: a tighter bar (fewer rescored pairs per user) '
+                    'lowers the floor and frac together with call_us -- compare call_us across builds, frac within one'}
 
 
 def scoring_region(ue, ie, batches, k_top, dev, barrier, prefilter=False):
