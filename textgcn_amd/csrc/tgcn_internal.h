@@ -117,6 +117,8 @@ int launch_sample_bf16(const float *U, const int64_t *user_ids, int B, const flo
 bool sample_top_supports(int d, int m);     // m sampled items
 int launch_sample_top(const float *U, const int64_t *user_ids, int B, const float *It, int m, int d, int stride, const int *mask_rowptr,
                       const int *mask_items, unsigned *bits, float *S, int64_t ld, hipStream_t stream);      // d <= 128
+int launch_sample_pack_top(const float *U, const int64_t *user_ids, int B, const void *ipack, int m, int d, int stride, const int *mask_rowptr,
+                           const int *mask_items, unsigned *bits, float *S, int64_t ld, hipStream_t stream);  // the same, rows from the pack
 int launch_user_bound(const float *U, const int64_t *user_ids, int B, int d, float *ubound /* [B][2] */, hipStream_t stream);
 size_t item_pack_bytes(int I, int d);      // 0: no bf16 candidate pass for this width
 int launch_item_pack(const float *It, int I, int d, void *pack, hipStream_t stream);

@@ -1197,6 +1197,25 @@ int bar_rank(int k, int stride)
     return 64;
 }
 
+// The threshold sample.  A sample twice as dense halves the distance between the bar and the k-th score: k = 40 -> rank 10 of every
+// 32nd item = ~320 candidates per user, rank 12 of every 16th = ~190, rank 17 of every 8th = ~140 -- the fp32 rescoring of the bf16
+// path (a third of a narrow call, at the random-row rate) and the filters' appends shrink with them.  Narrow rows only: their sample
+// runs on the bf16 pipe and keeps its scores to itself (the TOP forms: two values per user and 128-sample block reach k_tau), so a
+// denser sample costs MFMAs, not traffic.  The prefiltered entry point reads the sampled rows from the pack (k_sample_pack_top,
+// 19 us per 16 384 x 6250 x 64): every 8th item; the fp32 entry point converts them itself (k_sample_bf16, twice the time): every
+// 16th.  At K = 960 the sample is a tenth of the filter and k_refine's second bar decides what is rescored: every 32nd item, all
+// scores to k_tau, as before; so do catalogues whose bitmap row would not fit k_sample_bits' LDS (above 0.8 / 1.5 M items).
+void set_sample(Plan &p, int I, int d, int k, bool from_pack)
+{
+    const int dense = from_pack ? 8 : 16;
+    p.top = sample_top_supports(d, (I + dense - 1) / dense);
+    p.stride = p.top ? dense : kSampleStride;
+    p.rank = bar_rank(k, p.stride);
+    p.m = (I + p.stride - 1) / p.stride;
+    p.m_rank = p.top ? 2 * ((p.m + 127) / 128) : p.m;
+    p.m_ld = (p.m_rank + 3) & ~3;  // row stride of the sample score matrix (16-byte aligned rows)
+}
+
 Plan make_plan(int B, int I, int d, int k)
 {
     Plan p{};
@@ -1217,26 +1236,17 @@ Plan make_plan(int B, int I, int d, int k)
     p.cap2 = max(32, 1024 / (2 * p.S));
     if (d > 128 && prefilter_supports(d))
         p.cap2 = max(p.cap2, 64);      // the wide bf16 filter logs its (more numerous) raised candidates in these segments
-    // A sample twice as dense halves the distance between the bar and the k-th score: k = 40 -> rank 10 of every 32nd item = ~320
-    // candidates per user, rank 12 of every 16th = ~190 -- the fp32 rescoring of the bf16 path (a third of a narrow call, at the
-    // random-row rate) and the filters' appends shrink with them.  Narrow rows only: their sample runs on the bf16 pipe and keeps
-    // its scores to itself (the TOP form of k_sample_bf16: two values per user and 128-sample block reach k_tau), so the denser
-    // sample costs MFMAs, not traffic.  At K = 960 the sample is a tenth of the filter and k_refine's second bar decides what is
-    // rescored: every 32nd item, all scores to k_tau, as before.
-    p.top = sample_top_supports(d, (I + 15) / 16);      // (up to 1.5 M items: the bitmap row of k_sample_bits lives in LDS)
-    p.stride = p.top ? 16 : kSampleStride;
-    p.rank = bar_rank(k, p.stride);
-    p.m = (I + p.stride - 1) / p.stride;
-    const int n_blk = (p.m + 127) / 128;
-    p.m_rank = p.top ? 2 * n_blk : p.m;
-    p.m_ld = (p.m_rank + 3) & ~3;  // row stride of the sample score matrix (16-byte aligned rows)
+    // the threshold sample of either entry point (set_sample); the regions hold the larger of the two
+    Plan q = p;
+    set_sample(p, I, d, k, true);
+    set_sample(q, I, d, k, false);
     size_t o = 0;
-    p.off_sample = o, o += align256((size_t)B * p.m_ld * sizeof(float));
+    p.off_sample = o, o += align256((size_t)B * max(p.m_ld, q.m_ld) * sizeof(float));
     p.off_bits = o;
-    if (p.top)
-        o += align256((size_t)B * 4 * n_blk * sizeof(unsigned));
-    p.off_tauv = o, o += align256((size_t)B * p.rank * sizeof(float));
-    p.off_taui = o, o += align256((size_t)B * p.rank * sizeof(int64_t));
+    if (p.top || q.top)
+        o += align256((size_t)B * 4 * ((max(p.top ? p.m : 0, q.top ? q.m : 0) + 127) / 128) * sizeof(unsigned));
+    p.off_tauv = o, o += align256((size_t)B * max(p.rank, q.rank) * sizeof(float));
+    p.off_taui = o, o += align256((size_t)B * max(p.rank, q.rank) * sizeof(int64_t));
     p.off_tau = o, o += align256((size_t)B * sizeof(float));
     p.off_ubound = o, o += align256((size_t)B * 2 * sizeof(float));         // prefilter mode: the users' factors of the bound
     p.off_ipack = o;                                                       // ... and the packed item operand (unless the caller
@@ -1396,7 +1406,7 @@ int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const fl
     TGCN_REQUIRE(!mask_rowptr || mask_items, "mask_rowptr without mask_items");
     TGCN_REQUIRE(B <= 65535 * kUsersPerWG, "B too large for one launch");
     TGCN_REQUIRE(((size_t)item_pack & 15) == 0, "item_pack must be 16-byte aligned");
-    const Plan p = make_plan(B, I, d, k);
+    Plan p = make_plan(B, I, d, k);
     TGCN_REQUIRE(workspace && workspace_bytes >= (int64_t)p.total, "workspace too small (tgcn_score_topk_workspace_bytes)");
     TGCN_REQUIRE(((size_t)workspace & 255) == 0, "workspace must be 256-byte aligned");
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1422,6 +1432,8 @@ int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const fl
         ipack = ws + p.off_ipack;
     }
     // 1. tau from a strided item sample
+    if (!prefilter)
+        set_sample(p, I, d, k, false);       // (make_plan holds the prefiltered entry point's; the regions fit both)
     float *Ss = reinterpret_cast<float *>(ws + p.off_sample);
     float *tauv = reinterpret_cast<float *>(ws + p.off_tauv);
     int64_t *taui = reinterpret_cast<int64_t *>(ws + p.off_taui);
@@ -1430,7 +1442,9 @@ int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const fl
     int *done = reinterpret_cast<int *>(ws + p.off_done);
     int *totals = prefilter ? reinterpret_cast<int *>(ws + p.off_totals) : nullptr;
     // (the sample is only ranked -- tau is a bar, never a result: up to d = 128 it comes from the bf16 pipe in both entry points)
-    if ((rc = p.top       ? launch_sample_top(U, user_ids, B, It, p.m, d, p.stride, mask_rowptr, mask_items,
+    if ((rc = p.top && prefilter ? launch_sample_pack_top(U, user_ids, B, ipack, p.m, d, p.stride, mask_rowptr, mask_items,
+                                                          reinterpret_cast<unsigned *>(ws + p.off_bits), Ss, p.m_ld, s)     // (rows from the pack)
+              : p.top     ? launch_sample_top(U, user_ids, B, It, p.m, d, p.stride, mask_rowptr, mask_items,
                                               reinterpret_cast<unsigned *>(ws + p.off_bits), Ss, p.m_ld, s)     // (train items masked inside)
               : d <= 128  ? launch_sample_bf16(U, user_ids, B, It, p.m, d, p.stride, Ss, p.m_ld, s)
               : prefilter ? launch_sample_wide(U, user_ids, B, ipack, I, p.m, d, p.stride, Ss, p.m_ld, s)      // (from the pack)
@@ -1573,7 +1587,7 @@ extern "C" int tgcn_score_topk_fallback_count(const void *workspace, int32_t B, 
 {
     TGCN_REQUIRE(workspace && out_host, "NULL pointer");
     TGCN_REQUIRE(B > 0 && I > 0 && d > 0, "empty call");
-    const Plan p = make_plan(B, I, d, k);
+    Plan p = make_plan(B, I, d, k);
     *out_host = 0;
     if (p.small)
         return TGCN_OK;
@@ -1589,7 +1603,7 @@ extern "C" int tgcn_score_topk_stats(void *workspace, int32_t B, int32_t I, int3
 {
     TGCN_REQUIRE(workspace && out_host, "NULL pointer");
     TGCN_REQUIRE(B > 0 && I > 0 && d > 0, "empty call");
-    const Plan p = make_plan(B, I, d, k);
+    Plan p = make_plan(B, I, d, k);
     out_host[0] = out_host[1] = out_host[2] = out_host[3] = 0;
     if (p.small)
         return TGCN_OK;

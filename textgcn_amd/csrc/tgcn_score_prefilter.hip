@@ -1048,6 +1048,169 @@ __global__ __launch_bounds__(512) void k_sample_bf16(const SampleArgs a)
     }
 }
 
+// ---- the TOP sample from the item PACK (the prefiltered entry point: the bf16 rows exist already) ---------------------------
+// Same result layout as k_sample_bf16<.., TOP> -- S[b][2 blk .. 2 blk + 1] = the two largest unmasked scores of user b among the
+// sampled items of block blk -- in the filter kernel's shape instead: 8 waves x 32 users keep their fragments in registers for the
+// whole launch, the sampled rows come straight from the pack (row j * stride: 16-byte pieces, no conversion) through two LDS
+// stages, items on MFMA rows and the wave's users on columns, so a lane's 64 results of a block belong to ONE user and its two
+// largest are a v_med3 / v_max chain in the lane -- one shuffle joins the two row halves.  (k_sample_bf16's users-on-rows form
+// needs a five-step cross-lane merge per accumulator register: 40 us per 16 384 x 3125 x 64 sample against 6.5 GFLOP of MFMA.)
+struct SamplePackArgs {
+    const float *__restrict__ U;
+    const int64_t *__restrict__ user_ids;
+    const unsigned char *__restrict__ ipack;   // [I][RB] (k_item_pack)
+    float *__restrict__ S;
+    int64_t ld;
+    int B, m, d, stride;
+    const unsigned *__restrict__ bits;         // [B][bits_words] train-item bitmap over the sample (k_sample_bits), or NULL
+    int bits_words;
+    int bpw;                                   // blocks of 128 sampled items per workgroup
+};
+
+template <int KS, bool FULLK>
+__global__ __launch_bounds__(512) void k_sample_pack_top(const SamplePackArgs a)
+{
+    constexpr int T = 512, UT = 256, SI = 128;
+    constexpr int DQ = 4 * KS, RB = 32 * KS + 16;
+    constexpr int PPR = RB / 16;                        // 16-byte pieces of a packed row
+    constexpr int NP = (SI * PPR + T - 1) / T;          // ... of a block, per thread
+    constexpr int SB = SI * RB;                         // bytes of a stage
+    constexpr int NU = UT * DQ / T;
+    static_assert(UT * RB <= 2 * SB, "the user tile passes through the two stage buffers");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * SB];
+    const int lane = lane_id();
+    const int w = threadIdx.x >> 6;
+    const int r32 = lane & 31;
+    const int h = lane >> 5;
+    const int u0 = blockIdx.x * UT;
+    const int n_blk = (a.m + SI - 1) / SI;
+    const int blk0 = blockIdx.y * a.bpw, blk_end = min(blk0 + a.bpw, n_blk);
+    if (blk0 >= blk_end)
+        return;
+    const int user = u0 + w * 32 + r32;                 // the lane's user (both row halves)
+    const unsigned *__restrict__ brow = a.bits ? a.bits + (size_t)min(user, a.B - 1) * a.bits_words : nullptr;
+
+    u32x4 nxt[NP];
+    u32x4 mnx = {0u, 0u, 0u, 0u};
+    auto request = [&](int blk) {      // every load unconditional: pieces past the block clamp to its last one and are not stored
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int idx = min(i * T + (int)threadIdx.x, SI * PPR - 1);
+            const int row = idx / PPR, pc = idx % PPR;
+            const size_t item = (size_t)min(blk * SI + row, a.m - 1) * a.stride;
+            nxt[i] = *reinterpret_cast<const u32x4 *>(a.ipack + item * RB + pc * 16);
+        }
+        if (brow)
+            mnx = *reinterpret_cast<const u32x4 *>(brow + 4 * blk);
+    };
+    auto publish = [&](unsigned char *dst) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int idx = i * T + threadIdx.x;
+            if (idx < SI * PPR)
+                *reinterpret_cast<u32x4 *>(dst + (idx / PPR) * RB + (idx % PPR) * 16) = nxt[i];
+        }
+    };
+    {   // the user tile: fp32 rows -> bf16 rows in LDS (both stage buffers), requested together with the first block
+        float4 vu[NU];
+        size_t ru[NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const int r = min(u0 + (i * T + (int)threadIdx.x) / DQ, a.B - 1);
+            ru[i] = a.user_ids ? (size_t)a.user_ids[r] : (size_t)r;
+        }
+        request(blk0);
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const int k = ((i * T + (int)threadIdx.x) % DQ) * 4;
+            const float *__restrict__ p = a.U + ru[i] * a.d;
+            if constexpr (FULLK)
+                vu[i] = *reinterpret_cast<const float4 *>(p + k);
+            else
+                vu[i] = make_float4(k + 0 < a.d ? p[k + 0] : 0.0f, k + 1 < a.d ? p[k + 1] : 0.0f, k + 2 < a.d ? p[k + 2] : 0.0f,
+                                    k + 3 < a.d ? p[k + 3] : 0.0f);
+        }
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const int f = i * T + threadIdx.x;
+            *reinterpret_cast<uint2 *>(smem + (f / DQ) * RB + (f % DQ) * 8) = make_uint2(pack_bf16(vu[i].x, vu[i].y), pack_bf16(vu[i].z, vu[i].w));
+        }
+    }
+    __syncthreads();
+    bf16x8 bfr[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+        bfr[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(smem + (w * 32 + r32) * RB + 32 * s + 16 * h));
+    __syncthreads();
+    publish(smem);
+    u32x4 mcur = mnx;
+    __syncthreads();
+    int buf = 0;
+    for (int blk = blk0; blk < blk_end; ++blk) {
+        request(min(blk + 1, blk_end - 1));       // travels under this block's MFMAs (the last iteration's copy is never published)
+        // columns past the sample's end count as masked
+        const int nv = a.m - blk * SI;
+        u32x4 mw = mcur;
+        if (nv < SI) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const unsigned inv = nv >= 32 * (q + 1) ? 0u : nv <= 32 * q ? 0xFFFFFFFFu : 0xFFFFFFFFu << (nv - 32 * q);
+                mw[q] |= inv;
+            }
+        }
+        const bool any_masked = __any((mw.x | mw.y | mw.z | mw.w) != 0u);
+        float t0 = -INFINITY, t1 = -INFINITY;      // the lane's two largest of this block (its user, its row half)
+#pragma unroll
+        for (int un = 0; un < SI / 64; ++un) {
+            f32x16 c0, c1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                c0[r] = 0.0f, c1[r] = 0.0f;
+            const unsigned char *pi = smem + buf * SB + (un * 64 + r32) * RB;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const bf16x8 f0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pi + 32 * s + 16 * h));
+                const bf16x8 f1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pi + 32 * RB + 32 * s + 16 * h));
+                c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0, bfr[s], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1, bfr[s], c1, 0, 0, 0);
+            }
+            // register t: item row (t & 3) + 8 (t >> 2) + 4 h of the unit's first (c0) / second (c1) 32 rows
+            if (any_masked) {
+                const unsigned w0 = (un == 0 ? mw.x : mw.z) >> (4 * h), w1 = (un == 0 ? mw.y : mw.w) >> (4 * h);
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int bit = (t & 3) + 8 * (t >> 2);
+                    const float x0 = ((w0 >> bit) & 1u) ? -INFINITY : c0[t];
+                    const float x1 = ((w1 >> bit) & 1u) ? -INFINITY : c1[t];
+                    t1 = __builtin_amdgcn_fmed3f(t0, t1, x0);      // (a NaN score leaves both unchanged: v_med3 / v_max return the others)
+                    t0 = fmaxf(t0, x0);
+                    t1 = __builtin_amdgcn_fmed3f(t0, t1, x1);
+                    t0 = fmaxf(t0, x1);
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    t1 = __builtin_amdgcn_fmed3f(t0, t1, c0[t]);
+                    t0 = fmaxf(t0, c0[t]);
+                    t1 = __builtin_amdgcn_fmed3f(t0, t1, c1[t]);
+                    t0 = fmaxf(t0, c1[t]);
+                }
+            }
+        }
+        {   // the other row half of the same user
+            const float p0 = __shfl_xor(t0, 32), p1 = __shfl_xor(t1, 32);
+            t1 = fmaxf(fminf(t0, p0), fmaxf(t1, p1));
+            t0 = fmaxf(t0, p0);
+        }
+        if (h == 0 && user < a.B)
+            *reinterpret_cast<float2 *>(a.S + (size_t)user * a.ld + 2 * blk) = make_float2(t0, t1);
+        publish(smem + (buf ^ 1) * SB);      // (read last in the previous iteration: every wave has passed its barrier since)
+        mcur = mnx;
+        __syncthreads();
+        buf ^= 1;
+    }
+}
+
 // ---- candidates from the pass bits, fp32 scores, compact lists -----------------------------------------------------------
 // One WAVE per user, no workgroup-level synchronisation.  (1) the user's 2 Wh mask words are read 32 per lane at a time (all
 // loads of a chunk in flight together), counted, scanned once per chunk, and the set bits become item ids in LDS (more than
@@ -1299,6 +1462,34 @@ int launch_sample_bf16(const float *U, const int64_t *user_ids, int B, const flo
 // the TOP form: S[b][2 blk .. 2 blk + 1] = the two largest unmasked sample scores of user b in block blk (128 sampled items);
 // bits: workspace of B x 4 ceil(m / 128) words for the train-item bitmap (written here when a mask is given)
 bool sample_top_supports(int d, int m) { return d <= 128 && 4 * ((m + 127) / 128) <= kSampleBitsMaxWords; }
+
+// the same sample from the packed item operand (prefiltered entry point)
+int launch_sample_pack_top(const float *U, const int64_t *user_ids, int B, const void *ipack, int m, int d, int stride, const int *mask_rowptr,
+                           const int *mask_items, unsigned *bits, float *S, int64_t ld, hipStream_t s)
+{
+    const int n_blk = (m + 127) / 128;
+    if (mask_rowptr) {
+        hipLaunchKernelGGL(k_sample_bits, dim3((B + 3) / 4), dim3(256), (size_t)4 * 4 * n_blk * sizeof(unsigned), s, mask_rowptr, mask_items, bits,
+                           B, 4 * n_blk, stride, m);
+        const int rc = check_launch("k_sample_bits");
+        if (rc != TGCN_OK)
+            return rc;
+    }
+    // as many blocks per workgroup as still leave the chip two workgroups per CU: the users' fragments are built once per workgroup
+    const int tiles = (B + 255) / 256;
+    const int bpw = max(1, min(n_blk, tiles * n_blk / 256));
+    SamplePackArgs a{U, user_ids, static_cast<const unsigned char *>(ipack), S, ld, B, m, d, stride, mask_rowptr ? bits : nullptr, 4 * n_blk, bpw};
+    const dim3 grid(tiles, (n_blk + bpw - 1) / bpw), block(512);
+    if (d == 64)
+        hipLaunchKernelGGL((k_sample_pack_top<4, true>), grid, block, 0, s, a);
+    else if (d < 64)
+        hipLaunchKernelGGL((k_sample_pack_top<4, false>), grid, block, 0, s, a);
+    else if (d == 128)
+        hipLaunchKernelGGL((k_sample_pack_top<8, true>), grid, block, 0, s, a);
+    else
+        hipLaunchKernelGGL((k_sample_pack_top<8, false>), grid, block, 0, s, a);
+    return check_launch("k_sample_pack_top");
+}
 
 int launch_sample_top(const float *U, const int64_t *user_ids, int B, const float *It, int m, int d, int stride, const int *mask_rowptr,
                       const int *mask_items, unsigned *bits, float *S, int64_t ld, hipStream_t s)
