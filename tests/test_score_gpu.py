@@ -337,11 +337,14 @@ def test_scoring_at_config5_folded_width(cuda, oracle):
     assert np.array_equal(bits(v.cpu().numpy()[rows]), bits(rv))
 
 
-def test_fused_topk_very_large_catalogue(cuda):
-    """Catalogues beyond 131 072 items (config 4 has 2 M): the threshold comes from the mask + workgroup-per-row top-k on the
-    sample instead of k_tau, and the fallback bookkeeping is cleared by a memset.  Same contract: equal to the dense path."""
+@pytest.mark.parametrize('b,i,d', [(300, 200_000, 64), (48, 1_000_000, 64), (48, 1_700_000, 64), (64, 140_000, 256)])
+def test_fused_topk_very_large_catalogue(cuda, b, i, d):
+    """Large catalogues (config 4 has 2 M items).  Narrow rows keep the in-kernel sample while a user's bitmap row fits LDS (every 8th
+    item up to 0.8 M items, every 16th up to 1.5 M: 200 000 and 1 000 000); beyond that, and for wide rows beyond 131 072 items, the
+    threshold comes from the mask + workgroup-per-row top-k on a stride-32 sample instead of k_tau, and the fallback bookkeeping is
+    cleared by a memset (1 700 000; 140 000 x 256).  Same contract everywhere: equal to the dense path."""
     rng = np.random.default_rng(77)
-    b, i, d, k = 300, 200_000, 64, 40
+    k = 40
     u = (rng.standard_normal((b, d)) * 0.1).astype(np.float32)
     it = (rng.standard_normal((i, d)) * 0.1).astype(np.float32)
     _fused_vs_dense(cuda, u, it, k, mask=_rand_mask(rng, b, i, 0, 60))

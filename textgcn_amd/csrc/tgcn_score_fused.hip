@@ -1207,7 +1207,9 @@ int bar_rank(int k, int stride)
 // scores to k_tau, as before; so do catalogues whose bitmap row would not fit k_sample_bits' LDS (above 0.8 / 1.5 M items).
 void set_sample(Plan &p, int I, int d, int k, bool from_pack)
 {
-    const int dense = from_pack ? 8 : 16;
+    int dense = from_pack ? 8 : 16;
+    if (dense == 8 && !sample_top_supports(d, (I + 7) / 8))
+        dense = 16;          // (0.8 - 1.5 M items: the bitmap row fits at every 16th item)
     p.top = sample_top_supports(d, (I + dense - 1) / dense);
     p.stride = p.top ? dense : kSampleStride;
     p.rank = bar_rank(k, p.stride);
