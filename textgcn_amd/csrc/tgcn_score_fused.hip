@@ -1514,10 +1514,17 @@ int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const fl
         } else {
         const bool wide = B > 4096;
         int ips_pre = p.items_per_split;
-        if (d > 64 && I <= (1 << 18))
+        if (wide) {
+            // as few item splits as fill the chip ONCE (a 512-thread workgroup per CU: 256 workgroups).  A workgroup's prologue -- its
+            // 256 users' rows by two dependent round trips, their bf16 image through LDS into fragments -- hides under nothing, and
+            // with 28 splits a 16 384-user launch paid it in seven generations of workgroups: with the MFMAs alone left in the loop
+            // (tools/wide_ablate.py pre_onlymfma) the launch still took 109 us for 53 us of matrix work.
+            const int tiles = (B + 255) / 256;
+            const int s_target = max(1, min(32, 256 / tiles));
+            ips_pre = (((I + s_target - 1) / s_target + 255) / 256) * 256;
+        } else if (d > 64 && I <= (1 << 18)) {
             ips_pre = 1024;      // (768 / 1280 / 2048 with the packed operand: 54 / 53 / 56 us against 46)
-        else if (wide)
-            ips_pre = ((p.items_per_split + 255) / 256) * 256;
+        }
         if ((rc = launch_prefilter(U, user_ids, B, ipack, I, d, tau_ptr, tau_stride, ubound, mask, p.Wh, (I + ips_pre - 1) / ips_pre,
                                    ips_pre, wide, s)) != TGCN_OK)
             return rc;

@@ -209,6 +209,21 @@ __global__ __launch_bounds__(256) void k_user_bound(const float *__restrict__ U,
         *reinterpret_cast<float2 *>(ubound + 2 * (size_t)b) = make_float2(bound_factor(s), bound_factor(e));
 }
 
+// development switches of the narrow filter (tools/wide_ablate.py builds private copies with one ingredient of the loop compiled
+// out to price it; the shipped library has all of them on)
+#ifndef TGCN_PRE_TESTS
+#define TGCN_PRE_TESTS 1       // 0: no threshold tests (the pass words stay 0)
+#endif
+#ifndef TGCN_PRE_STAGE
+#define TGCN_PRE_STAGE 1       // 0: no stage requests / LDS stores inside the loop (the first stage is multiplied over and over)
+#endif
+#ifndef TGCN_PRE_LDSREAD
+#define TGCN_PRE_LDSREAD 1     // 0: the item fragments are read once per launch
+#endif
+#ifndef TGCN_PRE_MFMA
+#define TGCN_PRE_MFMA 1        // 0: no MFMAs
+#endif
+
 // ---- the bf16 filter ------------------------------------------------------------------------------------------------------
 struct PreArgs {
     const float *__restrict__ U;
@@ -376,6 +391,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
             store_words(mrow + ((t >> 6) - (UPS - 1)));
         }
     };
+#if !TGCN_PRE_LDSREAD
+    bf16x8 abl_fa0[KS + 1], abl_fa1[KS + 1];
+    bool abl_loaded = false;
+#endif
     auto unit = [&](auto prev_tag, int t0, int un, f32x16 &c0, f32x16 &c1, const f32x16 &q0, const f32x16 &q1, int t_prev) {
         constexpr bool PREV = decltype(prev_tag)::value;
         constexpr int STEPS = KS + 1;                  // k-steps incl. the bound's
@@ -386,17 +405,25 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
             c0[r] = 0.0f, c1[r] = 0.0f;
         // all operand fragments of the unit are requested first (their LDS latency is paid once per unit, under the first tests,
         // not once per k-step), then per k-step: the previous unit's tests of that step, the MFMA pair
+#if TGCN_PRE_LDSREAD
         bf16x8 fa0[STEPS], fa1[STEPS];
+#else
+        bf16x8 (&fa0)[STEPS] = abl_fa0, (&fa1)[STEPS] = abl_fa1;
+        if (!abl_loaded)
+#endif
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
             const int off = s < KS ? 32 * s + 16 * h : 32 * KS;        // the bound's step: both halves read the pad chunk
             fa0[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pi + off));
             fa1[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pi + 32 * RB + off));
         }
+#if !TGCN_PRE_LDSREAD
+        abl_loaded = true;
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
-            if constexpr (PREV) {
+            if constexpr (PREV && TGCN_PRE_TESTS) {
 #pragma unroll
                 for (int t = (32 * s) / STEPS; t < (32 * (s + 1)) / STEPS; ++t) {
                     const float val = t < 16 ? q0[t & 15] : q1[t & 15];
@@ -404,8 +431,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
                 }
             }
             const bf16x8 bb = s < KS ? bfr[s < KS ? s : 0] : bfx;
+#if TGCN_PRE_MFMA
             c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[s], bb, c0, 0, 0, 0);
             c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[s], bb, c1, 0, 0, 0);
+#else
+            asm volatile("" ::"v"(fa0[s]), "v"(fa1[s]), "v"(bb));
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (PREV) {
@@ -447,7 +478,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
     // previous stage's words to store -- is its own instance of the body.
     auto stage = [&](auto first_tag, int s0) {
         constexpr bool FIRST = decltype(first_tag)::value;
+#if TGCN_PRE_STAGE
         load_stage(nxt, s0 + ST);
+#endif
 #pragma unroll
         for (int un = 0; un < UPS; un += 2) {
             const int t0 = s0 + un * kStage;     // first item of this 64-item unit
@@ -465,9 +498,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
             unit(Yes{}, t0 + kStage, un + 1, B0, B1, A0, A1, t0);
             t_last = t0 + kStage, last_is_a = false;
         }
+#if TGCN_PRE_STAGE
         store_stage(smem + (buf ^ 1) * SB, nxt);
+#endif
         __syncthreads();
+#if TGCN_PRE_STAGE
         buf ^= 1;
+#endif
     };
     stage(Yes{}, i_beg);
     for (int s0 = i_beg + ST; s0 < i_end; s0 += ST)

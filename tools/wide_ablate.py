@@ -12,7 +12,11 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VARIANTS = {'full': [], 'nodma': ['-DTGCN_WIDE_DMA=0'], 'notests': ['-DTGCN_WIDE_TESTS=0'], 'nomfma': ['-DTGCN_WIDE_MFMA=0'],
-            'noldsread': ['-DTGCN_WIDE_LDSREAD=0'], 'nodma_notests': ['-DTGCN_WIDE_DMA=0', '-DTGCN_WIDE_TESTS=0']}
+            'noldsread': ['-DTGCN_WIDE_LDSREAD=0'], 'nodma_notests': ['-DTGCN_WIDE_DMA=0', '-DTGCN_WIDE_TESTS=0'],
+            # the narrow filter (run with d = 64 or 128)
+            'pre_notests': ['-DTGCN_PRE_TESTS=0'], 'pre_nostage': ['-DTGCN_PRE_STAGE=0'], 'pre_noldsread': ['-DTGCN_PRE_LDSREAD=0'],
+            'pre_nomfma': ['-DTGCN_PRE_MFMA=0'], 'pre_nostage_notests': ['-DTGCN_PRE_STAGE=0', '-DTGCN_PRE_TESTS=0'],
+            'pre_onlymfma': ['-DTGCN_PRE_STAGE=0', '-DTGCN_PRE_TESTS=0', '-DTGCN_PRE_LDSREAD=0']}
 BIN = os.path.join(ROOT, 'tools', 'probes', 'bin')
 
 
@@ -21,7 +25,10 @@ def main():
     if sys.argv[1] == 'build':
         os.makedirs(BIN, exist_ok=True)
         srcs = [os.path.join(build.CSRC, s) for s in build.SOURCES]
+        only = sys.argv[2:]
         for name, flags in VARIANTS.items():
+            if only and name not in only:
+                continue
             so = os.path.join(BIN, f'libtgcn_{name}.so')
             subprocess.check_call([build.hipcc()] + build.compile_flags() + flags + srcs + build.link_flags() + ['-o', so])
             print(so)
