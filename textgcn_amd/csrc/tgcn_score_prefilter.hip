@@ -209,6 +209,28 @@ __global__ __launch_bounds__(256) void k_user_bound(const float *__restrict__ U,
         *reinterpret_cast<float2 *>(ubound + 2 * (size_t)b) = make_float2(bound_factor(s), bound_factor(e));
 }
 
+// ---- LDS-DMA pieces and counted waits (both bf16 filters) ---------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void wait_vmcnt()
+{
+    static_assert(N >= 0 && N < 64, "vmcnt");
+    __builtin_amdgcn_s_waitcnt((N & 0xF) | ((N >> 4) << 14) | (0x7 << 4) | (0xF << 8));
+}
+
+// One LDS-DMA piece: every lane's 16 bytes at `src` land at LDS offset lds_base + 16 lane (global_load_lds_dwordx4; M0 carries the
+// wave-uniform LDS offset, one wait state behind the write of M0).  As inline assembly ON PURPOSE: through
+// __builtin_amdgcn_global_load_lds hipcc's wait-count pass puts s_waitcnt vmcnt(0) in front of the next ds_read of ANY LDS
+// address (it cannot tell the ring's buffers apart), i.e. right behind the request -- no prefetch left.  Hidden from that pass,
+// the requests are ordered by hand (wait_vmcnt<N> + the stage barrier).  An uncounted VMEM operation can only make a
+// compiler-placed vmcnt wait longer, never shorter: returns are in issue order.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"      // "clobber list contains reserved registers: m0" -- it is written here
+__device__ __forceinline__ void lds_dma16(const void *src, unsigned lds_base)
+{
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_base), "v"(src) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+
 // development switches of the narrow filter (tools/wide_ablate.py builds private copies with one ingredient of the loop compiled
 // out to price it; the shipped library has all of them on)
 #ifndef TGCN_PRE_TESTS
@@ -310,6 +332,19 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
 #pragma unroll
         for (int i = 0; i < NP; ++i)
             v[i] = *reinterpret_cast<const u32x4 *>(a.ipack + min(base + (size_t)i * T * 16, a.pack_bytes - 16));
+    };
+    // inside the loop the next stage goes from the pack straight into the other LDS buffer (LDS-DMA, 16 bytes per lane, a wave
+    // instruction = 1 KB contiguous): no staging registers, no ds_write, and the buffer is free -- it was multiplied in the previous
+    // stage and every wave has passed that stage's barrier.  Issued at the stage's start, waited for at its end (vmcnt(0) + barrier).
+    // With the rows staged through registers the stage traffic cost a quarter of the launch (tools/wide_ablate.py pre_nostage: 155 ->
+    // 116 us at 16 384 users).
+    auto dma_stage = [&](int nb, int row0) {
+        const size_t base = (size_t)row0 * RB;
+        const unsigned lds0 = (unsigned)(uintptr_t)(smem + nb * SB);
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+            lds_dma16(a.ipack + min(base + (size_t)(i * T + (int)threadIdx.x) * 16, a.pack_bytes - 16),
+                      uniform((int)(lds0 + (unsigned)(i * T + w * kWave) * 16u)));
     };
     auto store_stage = [&](unsigned char *dst, const u32x4 (&v)[NP]) {
 #pragma unroll
@@ -479,7 +514,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
     auto stage = [&](auto first_tag, int s0) {
         constexpr bool FIRST = decltype(first_tag)::value;
 #if TGCN_PRE_STAGE
-        load_stage(nxt, s0 + ST);
+        dma_stage(buf ^ 1, s0 + ST);
 #endif
 #pragma unroll
         for (int un = 0; un < UPS; un += 2) {
@@ -498,9 +533,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
             unit(Yes{}, t0 + kStage, un + 1, B0, B1, A0, A1, t0);
             t_last = t0 + kStage, last_is_a = false;
         }
-#if TGCN_PRE_STAGE
-        store_stage(smem + (buf ^ 1) * SB, nxt);
-#endif
+        // this wave's pieces of the next stage have landed (the barrier: everyone's).  The per-unit form's word stores are YOUNGER
+        // than the stage's requests and the last of them is issued right here: a full stage lets exactly its own stores stay in flight
+        if (WIDE || s0 + ST > i_end)
+            wait_vmcnt<0>();
+        else
+            wait_vmcnt<FIRST ? UPS - 1 : UPS>();
         __syncthreads();
 #if TGCN_PRE_STAGE
         buf ^= 1;
@@ -584,27 +622,6 @@ struct WideStage {
 };
 
 // s_waitcnt vmcnt(N) alone (gfx9 encoding: vmcnt in bits 3:0 and 15:14, expcnt 6:4 and lgkmcnt 11:8 left at their maxima)
-template <int N>
-__device__ __forceinline__ void wait_vmcnt()
-{
-    static_assert(N >= 0 && N < 64, "vmcnt");
-    __builtin_amdgcn_s_waitcnt((N & 0xF) | ((N >> 4) << 14) | (0x7 << 4) | (0xF << 8));
-}
-
-// One LDS-DMA piece: every lane's 16 bytes at `src` land at LDS offset lds_base + 16 lane (global_load_lds_dwordx4; M0 carries the
-// wave-uniform LDS offset, one wait state behind the write of M0).  As inline assembly ON PURPOSE: through
-// __builtin_amdgcn_global_load_lds hipcc's wait-count pass puts s_waitcnt vmcnt(0) in front of the next ds_read of ANY LDS
-// address (it cannot tell the ring's buffers apart), i.e. right behind the request -- no prefetch left.  Hidden from that pass,
-// the requests are ordered by hand (wait_vmcnt<N> + the stage barrier).  An uncounted VMEM operation can only make a
-// compiler-placed vmcnt wait longer, never shorter: returns are in issue order.
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"      // "clobber list contains reserved registers: m0" -- it is written here
-__device__ __forceinline__ void lds_dma16(const void *src, unsigned lds_base)
-{
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_base), "v"(src) : "memory", "m0");
-}
-#pragma clang diagnostic pop
-
 template <int KS, bool SAMPLE>
 __global__ __launch_bounds__(512) void k_score_prefilter_wide(const PreWideArgs wa)
 {
