@@ -1204,18 +1204,24 @@ int bar_rank(int k, int stride)
 // denser sample costs MFMAs, not traffic.  The prefiltered entry point reads the sampled rows from the pack (k_sample_pack_top,
 // 19 us per 16 384 x 6250 x 64): every 8th item; the fp32 entry point converts them itself (k_sample_bf16, twice the time): every
 // 16th.  At K = 960 the sample is a tenth of the filter and k_refine's second bar decides what is rescored: every 32nd item, all
-// scores to k_tau, as before; so do catalogues whose bitmap row would not fit k_sample_bits' LDS (above 0.8 / 1.5 M items).
+// scores to k_tau, as before; so do catalogues whose bitmap row would not fit k_sample_bits' LDS (above 0.8 / 1.5 M items) and
+// catalogues too small for the blocks to resolve the rank (below ~35 000 items at k = 40).
 void set_sample(Plan &p, int I, int d, int k, bool from_pack)
 {
-    int dense = from_pack ? 8 : 16;
-    if (dense == 8 && !sample_top_supports(d, (I + 7) / 8))
-        dense = 16;          // (0.8 - 1.5 M items: the bitmap row fits at every 16th item)
-    p.top = sample_top_supports(d, (I + dense - 1) / dense);
-    p.stride = p.top ? dense : kSampleStride;
-    p.rank = bar_rank(k, p.stride);
-    p.m = (I + p.stride - 1) / p.stride;
-    p.m_rank = p.top ? 2 * ((p.m + 127) / 128) : p.m;
-    p.m_ld = (p.m_rank + 3) & ~3;  // row stride of the sample score matrix (16-byte aligned rows)
+    // the densest TOP form whose blocks still resolve the rank: k_tau sees two values per block of 128 sampled items, and with fewer
+    // than ~2 rank blocks several of a user's `rank` best share a block (the bar then sits ranks lower than asked for -- at 9 blocks
+    // and rank 22 it would fall off the end: tau = -inf, every user to the exact fallback)
+    for (int dense = from_pack ? 8 : 16; dense <= 16; dense *= 2) {
+        const int m = (I + dense - 1) / dense, n_blk = (m + 127) / 128, rank = bar_rank(k, dense);
+        if (sample_top_supports(d, m) && n_blk >= 2 * rank) {
+            p.top = true, p.stride = dense, p.rank = rank, p.m = m, p.m_rank = 2 * n_blk;
+            p.m_ld = (p.m_rank + 3) & ~3;  // row stride of the sample score matrix (16-byte aligned rows)
+            return;
+        }
+    }
+    p.top = false, p.stride = kSampleStride, p.rank = bar_rank(k, p.stride);
+    p.m = (I + p.stride - 1) / p.stride, p.m_rank = p.m;
+    p.m_ld = (p.m_rank + 3) & ~3;
 }
 
 Plan make_plan(int B, int I, int d, int k)
