@@ -37,6 +37,59 @@ __global__ void k_ltr_fold_users(const float *__restrict__ e, const float *__res
     out[i] = v;
 }
 
+// The same rows, a wave per row and 16 bytes per lane (d, t and the row pitch multiples of 4, 16-byte aligned tables): every text
+// element is read once for both of its columns, no 64-bit division per element.  8192 users x 960 columns: 150-220 us -> see
+// DESIGN.md 4.2c (the element-per-thread form above was a tenth of config 5's predict).
+__global__ __launch_bounds__(256) void k_ltr_fold_users_v4(const float *__restrict__ e, const float *__restrict__ r,
+                                                           const float *__restrict__ dsc, const int64_t *__restrict__ emb_ids,
+                                                           const int64_t *__restrict__ text_ids, int B, int d, int t, int k_pad, float w0,
+                                                           float w1, float w2, float w3, float w4, float bias, float *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B)
+        return;
+    const int64_t ue = emb_ids ? emb_ids[b] : b;
+    const int64_t ut = text_ids ? text_ids[b] : b;
+    float *__restrict__ row = out + (size_t)b * k_pad;
+    const float *__restrict__ pe = e + ue * d;
+    const float *__restrict__ pr = r + ut * t;
+    const float *__restrict__ pd = dsc + ut * t;
+    for (int c = lane * 4; c < d; c += 256) {
+        const float4 x = *reinterpret_cast<const float4 *>(pe + c);
+        *reinterpret_cast<float4 *>(row + c) = make_float4(w0 * x.x, w0 * x.y, w0 * x.z, w0 * x.w);
+    }
+    for (int c = lane * 4; c < t; c += 256) {
+        const float4 x = *reinterpret_cast<const float4 *>(pr + c);
+        const float4 y = *reinterpret_cast<const float4 *>(pd + c);
+        *reinterpret_cast<float4 *>(row + d + c) =
+            make_float4(fmaf(w4, y.x, w1 * x.x), fmaf(w4, y.y, w1 * x.y), fmaf(w4, y.z, w1 * x.z), fmaf(w4, y.w, w1 * x.w));
+        *reinterpret_cast<float4 *>(row + d + t + c) =
+            make_float4(fmaf(w3, x.x, w2 * y.x), fmaf(w3, x.y, w2 * y.y), fmaf(w3, x.z, w2 * y.z), fmaf(w3, x.w, w2 * y.w));
+    }
+    for (int c = d + 2 * t + lane; c < k_pad; c += 64)
+        row[c] = c == d + 2 * t ? bias : 0.0f;
+}
+
+__global__ __launch_bounds__(256) void k_ltr_pack_items_v4(const float *__restrict__ e, const float *__restrict__ r,
+                                                           const float *__restrict__ dsc, int I, int d, int t, int k_pad,
+                                                           float *__restrict__ out)
+{
+    const int lane = threadIdx.x & 63;
+    const int it = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (it >= I)
+        return;
+    float *__restrict__ row = out + (size_t)it * k_pad;
+    for (int c = lane * 4; c < d; c += 256)
+        *reinterpret_cast<float4 *>(row + c) = *reinterpret_cast<const float4 *>(e + (size_t)it * d + c);
+    for (int c = lane * 4; c < t; c += 256) {
+        *reinterpret_cast<float4 *>(row + d + c) = *reinterpret_cast<const float4 *>(r + (size_t)it * t + c);
+        *reinterpret_cast<float4 *>(row + d + t + c) = *reinterpret_cast<const float4 *>(dsc + (size_t)it * t + c);
+    }
+    for (int c = d + 2 * t + lane; c < k_pad; c += 64)
+        row[c] = c == d + 2 * t ? 1.0f : 0.0f;
+}
+
 // Ia[i, :] = [ e_i | r_i | d_i | 1, 0... ]
 __global__ void k_ltr_pack_items(const float *__restrict__ e, const float *__restrict__ r, const float *__restrict__ dsc, int I,
                                  int d, int t, int k_pad, float *__restrict__ out)
@@ -134,6 +187,13 @@ extern "C" int tgcn_ltr_fold_users_f32(const float *users_emb, const float *user
     TGCN_REQUIRE(users_emb && users_reviews && users_desc && w5_host && out, "NULL pointer");
     const int k_pad = tgcn_ltr_folded_width(d, t);
     const int64_t n = (int64_t)B * k_pad;
+    if (d % 4 == 0 && t % 4 == 0 && k_pad % 4 == 0 &&
+        (((size_t)users_emb | (size_t)users_reviews | (size_t)users_desc | (size_t)out) & 15) == 0) {
+        hipLaunchKernelGGL(k_ltr_fold_users_v4, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), users_emb,
+                           users_reviews, users_desc, emb_ids, text_ids, B, d, t, k_pad, w5_host[0], w5_host[1], w5_host[2], w5_host[3],
+                           w5_host[4], bias, out);
+        return check_launch("k_ltr_fold_users_v4");
+    }
     hipLaunchKernelGGL(k_ltr_fold_users, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        users_emb, users_reviews, users_desc, emb_ids, text_ids, B, d, t, k_pad, w5_host[0], w5_host[1], w5_host[2],
                        w5_host[3], w5_host[4], bias, out);
@@ -149,6 +209,12 @@ extern "C" int tgcn_ltr_pack_items_f32(const float *items_emb, const float *item
     TGCN_REQUIRE(items_emb && items_reviews && items_desc && out, "NULL pointer");
     const int k_pad = tgcn_ltr_folded_width(d, t);
     const int64_t n = (int64_t)I * k_pad;
+    if (d % 4 == 0 && t % 4 == 0 && k_pad % 4 == 0 &&
+        (((size_t)items_emb | (size_t)items_reviews | (size_t)items_desc | (size_t)out) & 15) == 0) {
+        hipLaunchKernelGGL(k_ltr_pack_items_v4, dim3((unsigned)((I + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), items_emb,
+                           items_reviews, items_desc, I, d, t, k_pad, out);
+        return check_launch("k_ltr_pack_items_v4");
+    }
     hipLaunchKernelGGL(k_ltr_pack_items, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                        items_emb, items_reviews, items_desc, I, d, t, k_pad, out);
     return check_launch("k_ltr_pack_items");
