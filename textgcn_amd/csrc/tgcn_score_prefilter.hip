@@ -23,8 +23,10 @@
 // anybody else's test.  Non-finite data: a non-finite factor becomes +inf, the accumulator +inf or NaN, and the test is
 // !(acc <= tau) -- the pair is kept and decided by its fp32 score.
 //
-// In this file: k_item_pack (the item operand, once per table), k_sample_bf16 / the SAMPLE form of k_score_prefilter_wide (the
-// threshold sample k_tau ranks), k_score_prefilter (d <= 128: pass bits), k_score_prefilter_wide (128 < d <= 1024: the users'
+// In this file: k_item_pack (the item operand, once per table), the threshold sample k_tau ranks -- k_sample_bits (the call's train
+// items as a bitmap over the sample) + k_sample_pack_top (rows from the pack) or k_sample_bf16<.., TOP> (fp32 rows): two values per
+// user and 128-sample block; k_sample_bf16 / the SAMPLE form of k_score_prefilter_wide: every score -- the LDS-DMA helpers of
+// both filters, k_score_prefilter (d <= 128: pass bits), k_score_prefilter_wide (128 < d <= 1024: the users'
 // fragments in registers, the passing pairs LOGGED with their raised scores -- k_refine in tgcn_score_fused.hip turns those into a
 // second threshold, the k-th largest lower bound, and only what can still reach the top k is rescored), k_rescore (the fp32
 // chains, from the pass bits or from k_refine's id lists).
