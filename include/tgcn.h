@@ -142,7 +142,9 @@ int tgcn_mask_f32(float *S, int64_t lds, int32_t B, int32_t I, const int32_t *ma
  *   (ATen: nearbyintf(x * 1e4f) / 1e4f).  1 <= k <= 64, k <= I.
  * NaN scores: the order is built on `>` / `==`, so a NaN never enters a list (it ranks below -inf), whereas torch.topk
  * ranks NaN first.  The reference asserts a NaN-free loss every step (base_model.py:123) and the path produces none from
- * finite inputs; callers that can hold NaN scores must clean them first. */
+ * finite inputs; callers that can hold NaN scores must clean them first.  A row with fewer than k non-NaN scores leaves
+ * (-inf, TGCN_NO_ITEM) in the list positions nothing could fill: NOT an index -- check before using the ids as positions. */
+#define TGCN_NO_ITEM 2147483647
 int tgcn_topk_f32(const float *S, int64_t lds, int32_t B, int32_t I, int32_t k, int32_t round4,
                   float *out_val, int64_t *out_idx, tgcn_stream_t stream);
 

@@ -572,3 +572,34 @@ def test_prefilter_identical_over_random_shapes(cuda):
         torch.cuda.synchronize()
         assert torch.equal(pi, ri), (trial, b, i, d, k, int((pi != ri).sum()))
         assert np.array_equal(bits(pv.cpu().numpy()), bits(rv.cpu().numpy())), (trial, b, i, d, k)
+
+
+def test_rows_with_fewer_scores_than_k_do_not_become_positions(cuda):
+    """A row with fewer than k non-NaN scores leaves NO_ITEM (2^31 - 1) in the unfilled list positions.  The multi-pass wrappers for
+    k > 64 retire a pass's ids before the next pass; used raw as positions those entries are out of range (a torch scatter with them
+    took the GPU down in a random sweep: 65 items, k = 65, one NaN item, a user row with -inf).  They must be retired as duplicates."""
+    from textgcn_amd import scoring
+    rng = np.random.default_rng(3)
+    b, i, d, k = 40, 65, 6, 65
+    u = rng.standard_normal((b, d)).astype(np.float32)
+    it = rng.standard_normal((i, d)).astype(np.float32)
+    it[7, 2] = np.nan          # one NaN score in every row
+    it[9, 1], it[9, 3] = np.inf, 1.0
+    u[5, 1], u[5, 3] = 1.0, -np.inf          # this row: +-inf everywhere, NaN against item 7 and (inf - inf) item 9 -> 63 scores for k = 65
+    ud, itd = torch.from_numpy(u).to(cuda), torch.from_numpy(it).to(cuda)
+    s = scoring.score_dense(ud, itd)
+    assert int(torch.isnan(s[5]).sum()) == 2 and int(torch.isnan(s[0]).sum()) == 1
+    v, idx = scoring.topk(s, k)
+    torch.cuda.synchronize()
+    n_scores = (~torch.isnan(s)).sum(dim=1)
+    assert int(n_scores[5]) == 63 and int(n_scores[0]) == 64
+    assert int((idx == scoring.NO_ITEM).sum()) > 0          # the case does leave unfilled positions
+    for row in range(b):         # the first n_scores positions: every non-NaN item exactly once (what follows them is unspecified)
+        n = int(n_scores[row])
+        assert sorted(idx[row, :n].tolist()) == [j for j in range(i) if not bool(torch.isnan(s[row, j]))]
+    for pre in (False, True):    # the fused entry points' multi-pass wrapper: the same lists on the filled positions
+        fv, fi = scoring.score_topk(ud, itd, k, prefilter=pre)
+        torch.cuda.synchronize()
+        for row in range(b):
+            n = int(n_scores[row])
+            assert torch.equal(fi[row, :n], idx[row, :n]) and torch.equal(fv[row, :n].view(torch.int32), v[row, :n].view(torch.int32))
