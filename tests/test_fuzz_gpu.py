@@ -242,7 +242,7 @@ def test_predict_and_evaluate_random_datasets_vs_oracle(cuda, oracle, tmp_path):
         u, i = synth.interactions(n_u, n_i, max(nnz, 1), seed=seed, zipf=float(rng.choice([0.0, 0.8])))
         gr = NormGraph.from_pairs(u, i, n_u, n_i)
         max_train = int(np.bincount(u, minlength=n_u).max())
-        ks = sorted(set(int(k) for k in rng.choice(np.arange(1, max(2, min(n_i - max_train, 50))), size=2)))
+        ks = sorted(set(int(k) for k in rng.choice(np.arange(1, max(2, min(n_i - max_train, 130 if seed % 3 == 0 else 50))), size=2)))      # (above 64: the multi-pass wrapper)
         d, K, single = int(rng.choice([16, 64, 100, 128])), int(rng.integers(1, 5)), bool(rng.random() < 0.3)
         test_u = rng.integers(0, n_u, size=max(1, n_u // 2))
         test = pd.DataFrame({'user_id': test_u, 'asin': rng.integers(0, n_i, size=len(test_u))}).sort_values('user_id')
