@@ -110,3 +110,24 @@ def test_c_abi_rejects_bad_arguments_with_message(built_lib):
     rc = lib.tgcn_comm_init_rank(None, 2, 0, None)
     assert rc == -1
     assert lib.tgcn_comm_destroy(None) == 0
+
+
+def test_workspace_plan_over_a_grid_of_shapes(built_lib):
+    """tgcn_score_topk_workspace_bytes is host arithmetic (the plan of the fused top-k: splits, the threshold sample of either entry
+    point, log / list / bitmap regions): positive, finite, monotone in the number of users, and the same on every call, over
+    shapes on both sides of every regime switch (small catalogues, the in-kernel sample's lower and upper catalogue bounds, wide rows)."""
+    from textgcn_amd import _capi
+    lib = _capi.lib()
+    for d in (1, 6, 64, 100, 128, 136, 256, 960, 1024):
+        for n_items in (1, 63, 8192, 8193, 20_000, 35_000, 50_000, 131_072, 131_073, 800_000, 1_500_000, 1_600_000, 2_000_000):
+            for k in (1, 10, 40, 64):
+                if k > n_items:
+                    continue
+                prev = 0
+                for b in (1, 255, 2048, 4097, 16384, 65536):
+                    need = lib.tgcn_score_topk_workspace_bytes(b, n_items, d, k)
+                    assert 0 < need < (1 << 42), (b, n_items, d, k, need)
+                    assert need == lib.tgcn_score_topk_workspace_bytes(b, n_items, d, k)
+                    assert need >= prev, (b, n_items, d, k)
+                    prev = need
+    assert lib.tgcn_item_pack_bytes(50_000, 64) == 50_000 * 144 and lib.tgcn_item_pack_bytes(60_000, 960) == 60_000 * (2 * 960 + 16)
