@@ -1463,11 +1463,12 @@ int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const fl
     const int *mask_rowptr_tau = mask_rowptr;      // (the top form's values are masked already)
     if (p.m_rank <= 64 * kWave) {   // one wave per user: mask + rank selection in one launch
         const dim3 grid((B + 3) / 4);
-        const int vpl = p.m_rank <= 8 * kWave ? 8 : p.m_rank <= 16 * kWave ? 16 : p.m_rank <= 32 * kWave ? 32 : 64;
+        const int vpl = p.m_rank <= 2 * kWave ? 2 : p.m_rank <= 8 * kWave ? 8 : p.m_rank <= 16 * kWave ? 16 : p.m_rank <= 32 * kWave ? 32 : 64;
         const size_t lds = (size_t)4 * kWave * vpl * sizeof(float);
         if (p.top)
             mask_rowptr_tau = nullptr;
         switch (vpl) {
+            case 2: hipLaunchKernelGGL((k_tau<2>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m_rank, mask_rowptr_tau, mask_items, tau1, flagged, done, U, user_ids, d, ubound, totals, p.stride, p.rank); break;      // (the in-kernel sample's 2 x blocks values)
             case 8: hipLaunchKernelGGL((k_tau<8>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m_rank, mask_rowptr_tau, mask_items, tau1, flagged, done, U, user_ids, d, ubound, totals, p.stride, p.rank); break;
             case 16: hipLaunchKernelGGL((k_tau<16>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m_rank, mask_rowptr_tau, mask_items, tau1, flagged, done, U, user_ids, d, ubound, totals, p.stride, p.rank); break;
             case 32: hipLaunchKernelGGL((k_tau<32>), grid, dim3(256), lds, s, Ss, p.m_ld, B, p.m_rank, mask_rowptr_tau, mask_items, tau1, flagged, done, U, user_ids, d, ubound, totals, p.stride, p.rank); break;
