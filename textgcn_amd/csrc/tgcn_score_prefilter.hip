@@ -282,7 +282,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
     constexpr int NU = (kStage * DQ) / T;      // ... per 64-user piece of the user tile
     static_assert(ST % kStage == 0 && 2 * ST >= UT && (kStage * DQ) % T == 0, "the user tile passes through the stage buffers");
     static_assert(SB >= ST * RB && 2 * SB >= UT * RB, "stage buffers (the user tile passes through both)");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * SB];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * SB];      // a ring of three stages: one multiplied, two on their way
     const int lane = lane_id();
     const int w = threadIdx.x >> 6;
     const int r32 = lane & 31;
@@ -384,6 +384,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
     if (i_beg >= i_end)
         return;
     store_stage(smem, nxt);
+#if TGCN_PRE_STAGE
+    dma_stage(1, i_beg + ST);      // (the user tile is out of the buffers: its fragments are in registers)
+#endif
     __syncthreads();
     // tau has arrived before the loop: a first use inside it makes hipcc's wait-count pass put s_waitcnt vmcnt(0) in front of
     // EVERY test (the loop-carried state merges the pending tau load with the stage prefetch), which serialises the prefetch
@@ -516,7 +519,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
     auto stage = [&](auto first_tag, int s0) {
         constexpr bool FIRST = decltype(first_tag)::value;
 #if TGCN_PRE_STAGE
-        dma_stage(buf ^ 1, s0 + ST);
+        dma_stage(buf >= 1 ? buf - 1 : 2, s0 + 2 * ST);     // ring position (buf + 2) % 3: multiplied last in the previous stage
 #endif
 #pragma unroll
         for (int un = 0; un < UPS; un += 2) {
@@ -537,13 +540,17 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
         }
         // this wave's pieces of the next stage have landed (the barrier: everyone's).  The per-unit form's word stores are YOUNGER
         // than the stage's requests and the last of them is issued right here: a full stage lets exactly its own stores stay in flight
-        if (WIDE || s0 + ST > i_end)
+        // what may stay in flight: the NP pieces requested at this stage's start (two stages ahead) and this stage's own word stores,
+        // all younger than the next stage's pieces.  The split's last stages request nothing real and drain everything.
+        if (s0 + ST >= i_end)
             wait_vmcnt<0>();
+        else if (WIDE)
+            wait_vmcnt<NP + (FIRST ? 0 : 1)>();
         else
-            wait_vmcnt<FIRST ? UPS - 1 : UPS>();
+            wait_vmcnt<NP + (FIRST ? UPS - 1 : UPS)>();
         __syncthreads();
 #if TGCN_PRE_STAGE
-        buf ^= 1;
+        buf = buf == 2 ? 0 : buf + 1;
 #endif
     };
     stage(Yes{}, i_beg);
