@@ -260,6 +260,7 @@ struct PreArgs {
     unsigned *__restrict__ mask;    // [B padded to 256][2][Wh] pass bits: word (user, h, unit), register t of the unit on bit 31 - t
     int Wh;
     int B, I, d, items_per_split;
+    int n_tiles, n_splits;          // user tiles of 256 x item splits; the grid is linear: 8 ceil(n_tiles n_splits / 8) workgroups
 };
 
 // KS = 16-wide k-steps per dot product (d <= 16 KS).  Items on MFMA rows (A operand, LDS stages of ST rows of bf16), the wave's
@@ -287,8 +288,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
     const int w = threadIdx.x >> 6;
     const int r32 = lane & 31;
     const int h = lane >> 5;
-    const int u0 = blockIdx.x * UT;
-    const int split = blockIdx.y;
+    // linear grid, XCD-affine: workgroups are dealt to the 8 XCDs round-robin, and XCD x takes the (split, user tile) pairs
+    // [x per, (x + 1) per) in split-major order -- the user tiles of a split run side by side on ONE XCD and share its rows in that
+    // L2 (2048 users x 2 M items: every XCD streamed the whole 288 MB pack, 2.3 GB per launch)
+    const int per = (a.n_splits * a.n_tiles + 7) / 8;
+    const int pair = (int)(blockIdx.x & 7u) * per + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= per || pair >= a.n_splits * a.n_tiles)
+        return;
+    const int u0 = (pair % a.n_tiles) * UT;
+    const int split = pair / a.n_tiles;
     const int i_beg = split * a.items_per_split;
     const int i_end = min(a.I, i_beg + a.items_per_split);
 
@@ -1595,10 +1603,11 @@ int launch_item_pack(const float *It, int I, int d, void *pack, hipStream_t s)
 int launch_prefilter(const float *U, const int64_t *user_ids, int B, const void *ipack, int I, int d, const float *tau, int tau_stride,
                      const float *ubound, unsigned *mask, int Wh, int S, int items_per_split, bool wide, hipStream_t s)
 {
-    PreArgs a{U, user_ids, static_cast<const unsigned char *>(ipack), item_pack_bytes(I, d), tau, tau_stride, ubound, mask, Wh, B, I, d,
-              items_per_split};
     constexpr int UT = kPreWaves * 32;
-    const dim3 grid((B + UT - 1) / UT, S), block(kPreWaves * 64);
+    const int n_tiles = (B + UT - 1) / UT;
+    PreArgs a{U, user_ids, static_cast<const unsigned char *>(ipack), item_pack_bytes(I, d), tau, tau_stride, ubound, mask, Wh, B, I, d,
+              items_per_split, n_tiles, S};
+    const dim3 grid(8u * (unsigned)((n_tiles * S + 7) / 8)), block(kPreWaves * 64);
     wide = wide && items_per_split % 256 == 0;         // (a stage's words as one aligned store: the splits must be stage multiples)
 #define TGCN_PRE_LAUNCH(KS, FULLK, ST)                                                                          \
     do {                                                                                                        \
