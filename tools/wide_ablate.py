@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
-"""Ablation of the wide bf16 filter (k_score_prefilter_wide): private copies of the library with ONE ingredient of its loop
-compiled out (results of those copies are meaningless; only the kernel's duration is read).
+"""Ablation of the bf16 filters (k_score_prefilter_wide; the `pre_*` variants: the narrow k_score_prefilter): private copies of the
+library with ONE ingredient of the loop compiled out (results of those copies are meaningless; only the kernel's duration is read).
 
-    python tools/wide_ablate.py build                    # build container: tools/probes/bin/libtgcn_<variant>.so (travels to the box)
+    python tools/wide_ablate.py build [variant ...]      # build container: tools/probes/bin/libtgcn_<variant>.so (travels to the box)
     rocprofv3 --kernel-trace --stats ... -- python tools/wide_ablate.py run <variant> [d] [users] [items]     # GPU box, one variant per process
+                                                         # (wide: d = 960; narrow: run pre_notests 64 16384 50000)
 """
 import os
 import subprocess
