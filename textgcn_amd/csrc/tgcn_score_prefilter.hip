@@ -546,16 +546,16 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
             unit(Yes{}, t0 + kStage, un + 1, B0, B1, A0, A1, t0);
             t_last = t0 + kStage, last_is_a = false;
         }
-        // this wave's pieces of the next stage have landed (the barrier: everyone's).  The per-unit form's word stores are YOUNGER
-        // than the stage's requests and the last of them is issued right here: a full stage lets exactly its own stores stay in flight
-        // what may stay in flight: the NP pieces requested at this stage's start (two stages ahead) and this stage's own word stores,
-        // all younger than the next stage's pieces.  The split's last stages request nothing real and drain everything.
+        // The next stage's pieces have landed once at most NP vector-memory operations are in flight: loads complete in issue
+        // order, so whatever loads are still out are the NP youngest -- the pieces requested at THIS stage's start, two stages
+        // ahead.  The stage's own word stores count too (gfx9 keeps one counter) but need no ordering against the loads: they only
+        // use up allowance, and by now the pieces requested a whole stage ago are in, so the wait passes without the stores' round
+        // trip (with vmcnt(0) the last store's was paid every stage).  Register spills would be counted the same harmless way.  The
+        // split's last stage requests nothing real and drains everything before the workgroup's LDS is released.
         if (s0 + ST >= i_end)
             wait_vmcnt<0>();
-        else if (WIDE)
-            wait_vmcnt<NP + (FIRST ? 0 : 1)>();
         else
-            wait_vmcnt<NP + (FIRST ? UPS - 1 : UPS)>();
+            wait_vmcnt<NP>();
         __syncthreads();
 #if TGCN_PRE_STAGE
         buf = buf == 2 ? 0 : buf + 1;

@@ -17,7 +17,8 @@ VARIANTS = {'full': [], 'nodma': ['-DTGCN_WIDE_DMA=0'], 'notests': ['-DTGCN_WIDE
             # the narrow filter (run with d = 64 or 128)
             'pre_notests': ['-DTGCN_PRE_TESTS=0'], 'pre_nostage': ['-DTGCN_PRE_STAGE=0'], 'pre_noldsread': ['-DTGCN_PRE_LDSREAD=0'],
             'pre_nomfma': ['-DTGCN_PRE_MFMA=0'], 'pre_nostage_notests': ['-DTGCN_PRE_STAGE=0', '-DTGCN_PRE_TESTS=0'],
-            'pre_onlymfma': ['-DTGCN_PRE_STAGE=0', '-DTGCN_PRE_TESTS=0', '-DTGCN_PRE_LDSREAD=0']}
+            'pre_onlymfma': ['-DTGCN_PRE_STAGE=0', '-DTGCN_PRE_TESTS=0', '-DTGCN_PRE_LDSREAD=0'],
+            'pf1': ['-DTGCN_WIDE_PF=1']}
 BIN = os.path.join(ROOT, 'tools', 'probes', 'bin')
 
 
