@@ -45,7 +45,7 @@ class AdvSamplModel(LightGCN):
         s = scoring.score_candidates(users_emb.contiguous(), users, items_emb.contiguous(), cand, rp, it)
         kk = min(max(self.k), cand.shape[1])
         val, pos = scoring.topk(s, kk)
-        neg = torch.gather(cand, 1, scoring._taken_ids(pos))      # (NO_ITEM positions: value -inf, replaced by -1 below)
+        neg = torch.gather(cand, 1, scoring.retired_positions(pos))      # (NO_ITEM positions: value -inf, replaced by -1 below)
         return torch.where(torch.isneginf(val), torch.full_like(neg, -1), neg)
 
     def _mask_full(self):

@@ -74,7 +74,7 @@ def topk(scores, k, round4=False):
         for k0 in range(0, k, MAX_K_PER_PASS):
             v, i = topk(work, min(MAX_K_PER_PASS, k - k0), round4)
             vals.append(v), idxs.append(i)
-            work.scatter_(1, _taken_ids(i), float('-inf'))
+            work.scatter_(1, retired_positions(i), float('-inf'))
         return torch.cat(vals, dim=1), torch.cat(idxs, dim=1)
     b = scores.shape[0]
     val = torch.empty((b, k), dtype=torch.float32, device=dev)
@@ -88,7 +88,7 @@ def topk(scores, k, round4=False):
 NO_ITEM = 2 ** 31 - 1      # the id the kernels leave in a list position no score could fill (a row with fewer than k non-NaN scores)
 
 
-def _taken_ids(idx):
+def retired_positions(idx):
     """The ids of one pass as positions to retire before the next pass: NO_ITEM entries (nothing was taken there) are replaced by
     the row's first id -- already retired, so the duplicate changes nothing -- or by 0 on a row that took nothing at all.  (As
     raw positions they are out of range: a scatter with them faults the GPU.)"""
@@ -205,7 +205,7 @@ def score_topk(users_emb, items_emb, k, user_ids=None, mask_rowptr=None, mask_it
                               (keys % n_items).to(torch.int32) if keys.numel() else torch.zeros(1, dtype=torch.int32, device=dev),
                               round4, slot, prefilter, item_pack)
             vals.append(v), idxs.append(i)
-            keys = torch.sort(torch.cat([keys, (rows[:, None] * n_items + _taken_ids(i)).reshape(-1)]))[0]
+            keys = torch.sort(torch.cat([keys, (rows[:, None] * n_items + retired_positions(i)).reshape(-1)]))[0]
             rowptr = rowptr + kk * torch.arange(b + 1, device=dev, dtype=torch.int64)
         return torch.cat(vals, dim=1), torch.cat(idxs, dim=1)
     val = torch.empty((b, k), dtype=torch.float32, device=dev)
