@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
 """Benchmark of the MI355X LightGCN propagation + scoring path (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|small] ...
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...      (N > 1, one rank per GPU)
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c4|c2|c3|small] ...
+
+`python bench.py --gpus N` may be started plainly for ANY N: with N > 1 and no torch.distributed environment the process
+starts the N ranks itself as child processes (`python -m torch.distributed.run --nproc-per-node N ... bench.py <same
+arguments>`, before anything touches the GPU) and returns their exit code; started under torch.distributed.run
+(RANK / WORLD_SIZE set, as the driver does for N > 1) it is one of the ranks.
 
 One "step" = one K-layer propagation (the `representation` forward, TextGCN/base_model.py:93-106) over the
 synthetic graph, inputs resident in HBM.  Headline value = propagated directed edges per second
@@ -10,14 +14,17 @@ synthetic graph, inputs resident in HBM.  Headline value = propagated directed e
 user-item pairs/s: dense scores + train mask + top-40 per batch of 2048 users) is timed in a separate region
 and reported under "scoring" in the same JSON line.
 
-N = 1: the headline is BASELINE config 2 (U=100k, I=50k, nnz=5M, d=64, K=3); the same line carries sub-records for the
-other single-GPU configurations -- "c4_1gpu" (config 4, U=5M I=2M nnz=100M, the size the north-star target is stated
-on, on ONE GPU), "c3" (d=128, K=4 + full-catalogue scoring) and "c5" (ltr_linear head) -- each with its own roofline,
-cpu_baseline and verify entries (--sub to choose).
-N > 1: config 4 itself, row-sharded over the N ranks (fixed total work -> "strong"), one RCCL all-gather of the
-propagated user block and one of the item block per layer, chunked so they run under the SpMM launches.  The graph is built once per
-node (rank 0) and memory-mapped by the other ranks; the line carries the ranks' device identities and a per-layer split of
-SpMM time / time waiting for a gathered block.
+EVERY N times the same workload -- BASELINE config 4 (U=5M, I=2M, nnz=100M, d=64, K=3: the size the north-star target is
+stated on; it fits one GPU) -- so the N = 1, 2, 4, 8 values are one curve on one graph:
+N = 1: the whole graph on one GPU (this is the headline; `roofline`, `cpu_baseline` -- a 10 M-entry slice, labelled -- and
+`verify` belong to it); the same line carries sub-records for the other single-GPU configurations: "c2" (config 2 with
+scoring, training step, full CPU baseline), "c3" (d=128, K=4 + full-catalogue scoring) and "c5" (ltr_linear head), each with
+its own roofline, cpu_baseline and verify entries (--sub to choose).
+N > 1: config 4 row-sharded over the N ranks (fixed total work -> "strong"), one RCCL all-gather of the propagated user block
+and one of the item block per layer, chunked so they run under the SpMM launches.  The graph is built once per node (local
+rank 0) and memory-mapped by the other ranks; the line carries the ranks' device identities, a per-layer split of SpMM time /
+time waiting for a gathered block, and the two halves ALONE on the same ranks and buffers (`layers.spmm_alone_ms`,
+`layers.allgather_alone_ms`) with the overlap efficiency they imply.
 
 roofline: HBM-bound SpMM.  `achieved` = ALGORITHMIC (compulsory) bytes of one layer launch / its mean duration (HIP events
 on the launch stream around the timed region), bytes = nnz*8 + (rows+1)*4 + n_src*d*4 + rows*d*4 + fused layer-sum
@@ -37,6 +44,7 @@ import argparse
 import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 import types
@@ -232,7 +240,8 @@ def random_row_rate(n_rows, d, dev, entries=1 << 23):
     return len(cols) * 4.0 * d / (ev0.elapsed_time(ev1) / 1e3 / reps)
 
 
-def spmm_roofline(nnz_local, n_rows_local, n_src, d, K, t_dev, steps, traffic, traffic_src, dev, gather=True, deg=None):
+def spmm_roofline(nnz_local, n_rows_local, n_src, d, K, t_dev, steps, traffic, traffic_src, dev, gather=True, deg=None,
+                  kernel='one SpMM layer'):
     layer_bytes = [algorithmic_bytes_per_layer(nnz_local, n_rows_local, n_src, d, k, K, False) for k in range(1, K + 1)]
     mean_layer_s = t_dev / (steps * K)
     achieved = float(np.mean(layer_bytes)) / mean_layer_s / 1e9
@@ -241,7 +250,7 @@ def spmm_roofline(nnz_local, n_rows_local, n_src, d, K, t_dev, steps, traffic, t
          'traffic_kind': "L2-miss bytes on the L2's fabric side; Infinity-Cache hits included, so NOT an HBM byte count",
          # recorded fabric-side bytes (PMC pass, profiles/) over the live launch time: what the fabric moves
          'traffic_GBs': round(traffic / mean_layer_s / 1e9, 1) if traffic else None,
-         'kernel': 'one SpMM layer (k_spmm_seg + k_spmm_seg_reduce, or k_spmm_wave + k_spmm_long_reduce)',
+         'kernel': kernel,
          'algorithmic_bytes_per_launch': int(np.mean(layer_bytes)), 'launch_us': round(mean_layer_s * 1e6, 2),
          'gather_model_GBs': round((nnz_local * (8 + 4 * d) + n_rows_local * d * 4) / mean_layer_s / 1e9, 1)}
     if deg is not None:
@@ -295,7 +304,13 @@ def candidate_path_roofline(b, n_items, d, k_top, t_call, dev, slot=0):
     every call must move once (the item pack; the narrow path's pass-bit words, written and read).  bound = the largest of the
     three; frac = bound time / measured time of the call."""
     from textgcn_amd import scoring
-    st = scoring.call_stats(dev, b, n_items, d, k_top, True, slot=slot)
+    # a slot's workspace holds the plan of ITS last call: ask a slot whose last call had this very shape (the tail chunk of a user
+    # range is smaller and may have ended on any slot)
+    want = (int(b), int(n_items), int(d), int(min(k_top, scoring.MAX_K_PER_PASS)), True)
+    slots = [sl for sl in range(16) if scoring.last_call(dev, sl) == want]
+    if not slots:
+        return {'note': f'no stream slot ended on a call of shape {want}: per-call statistics unavailable'}
+    st = scoring.call_stats(dev, b, n_items, d, k_top, True, slot=slots[0])
     ks = pack_ksteps(d)
     flop = 2.0 * 16 * (ks + 1) * b * n_items
     t_mfma = flop / (MFMA_BF16_PEAK_TF * 1e12)
@@ -352,70 +367,182 @@ def scoring_region(ue, ie, batches, k_top, dev, barrier, prefilter=False):
     return ev0.elapsed_time(ev1) / 1e3, keep
 
 
-# ---------------------------------------------------------------------------------------------------- sub-records (N = 1)
-def record_c4_one_gpu(dev, steps=5, warmup=2, cpu=True):
-    """BASELINE config 4 on ONE GPU: the size the north-star's >= 60 % target is stated on."""
+# ---------------------------------------------------------------------------------------------------- single GPU (N = 1)
+def spmm_kernel_names(prop, exact, segmented):
+    if segmented:
+        return 'one SpMM layer = k_spmm_seg (column-block tiles) + k_spmm_reduce_groups (piece sums beside the direct rows, in row groups)'
+    names = 'k_spmm_groups (row groups; chunk waves of the rows the split plan cuts)'
+    if not exact and prop.csr.n_chunks:
+        names += ' + k_spmm_long_reduce'
+    return 'one SpMM layer = ' + names
+
+
+def cpu_slice_baseline_and_verify(graph, e0, prop, e0d, entries=10_000_000):
+    """CPU sample for a graph whose full CPU forward is minutes (config 4: ~25 s per layer on torch's single-threaded COO kernel):
+    the layer-1 product of the first user rows holding ~`entries` stored entries, all threads then one; the same
+    rows of the GPU's layer 1 are checked against it, and the hottest row (a ~1 M-entry item row cut into ~1000 chunks) against a
+    float64 dot over its entries."""
+    from textgcn_amd import propagate
+    r = int(np.searchsorted(graph.rowptr, entries))
+    e = int(graph.rowptr[r])
+    rows = np.repeat(np.arange(r, dtype=np.int64), np.diff(graph.rowptr[:r + 1]))
+    a = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, np.asarray(graph.colidx[:e]).astype(np.int64)])),
+                                torch.from_numpy(np.array(graph.vals[:e])), (r, graph.n)).coalesce()
+    del rows
+    all_threads = torch.get_num_threads()
+    recs = []
+    for threads in (all_threads, 1):
+        torch.set_num_threads(threads)
+        t0 = time.perf_counter()
+        ref = torch.sparse.mm(a, e0)
+        el = time.perf_counter() - t0
+        recs.append({'value': e / el, 'unit': 'edges/s', 'cores': threads, 'kind': 'port',
+                     'sample': f'ONE layer of the first {r} user rows ({e} stored entries, 1/{graph.nnz // e} of a layer) in '
+                               f'{el:.2f} s: torch.sparse.mm on the coalesced COO slice, {threads} thread(s) on {os.cpu_count()} host '
+                               f'cpus; the whole-forward rate is this rate (extrapolated, BASELINE.md §3)'})
+    torch.set_num_threads(all_threads)
+    y1 = torch.empty_like(e0d)
+    propagate.spmm(prop.csr, e0d, y=y1)
+    got = y1[:r].cpu().numpy()
+    hot = int(np.argmax(graph.degrees()))
+    a0, a1 = int(graph.rowptr[hot]), int(graph.rowptr[hot + 1])
+    ref_hot = (np.asarray(graph.vals[a0:a1]).astype(np.float64)[:, None] * e0.numpy()[np.asarray(graph.colidx[a0:a1])].astype(np.float64)).sum(axis=0)
+    got_hot = y1[hot].cpu().numpy().astype(np.float64)
+    v = {'what': f'layer 1 of the timed path: rows 0..{r} vs torch.sparse.mm on the CPU; hottest row {hot} ({a1 - a0} entries) '
+                 f'vs a float64 dot',
+         'normwise_max_err': float(np.abs(got.astype(np.float64) - ref.numpy()).max() / np.abs(ref.numpy()).max()),
+         'hottest_row_normwise_err': float(np.abs(got_hot - ref_hot).max() / np.abs(ref_hot).max()), 'bar': 1e-4}
+    v['ok'] = bool(v['normwise_max_err'] <= 1e-4 and v['hottest_row_normwise_err'] <= 1e-4)
+    return dict(recs[0], one_thread=recs[1]), v
+
+
+def scoring_record(ue, ie, users_all, mrp, mit, n_i, d, dev, args, barrier, world=1, reduce_max_sum=None, cpu=True, large=True):
+    """BASELINE metric 2 on the propagated tables: `args.score_batches` calls of `args.score_batch_size` users (fp32 MFMA filter =
+    the record's value; the bf16-candidate path -- the model classes' default -- beside it, outputs compared), the model
+    classes' 16384-user calls, and the CPU port on a bounded sample."""
+    from textgcn_amd import scoring as _sc
+    k_top = 40
+    bsz = args.score_batch_size
+    n_batches = min(args.score_batches, max(1, len(users_all) // bsz))
+    batches = [batch_masks(users_all[b * bsz:(b + 1) * bsz], mrp, mit, dev, ids_origin=users_all[0]) for b in range(n_batches)]
+    ts, keep = scoring_region(ue, ie, batches, k_top, dev, barrier)
+    first_topk = keep[0]
+    lc = [sl for sl in range(n_score_streams(False)) if _sc.last_call(dev, sl) == (int(batches[0][0].numel()), n_i, d, k_top, False)]
+    fb_fp32 = _sc.fallback_count(dev, int(batches[0][0].numel()), n_i, d, k_top, slot=lc[0]) if lc else None
+    pairs = sum(int(bt[0].numel()) for bt in batches) * n_i
+    if reduce_max_sum is not None:
+        mx, sm = reduce_max_sum([ts, float(pairs)])
+        ts, pairs = mx[0], sm[1]
+    flops = 2.0 * d * pairs
+    rec = {
+        'metric': f'scored user-item pairs/sec (scores + train mask + top-40 fused, B={bsz} per call, {n_score_streams(False)} streams)',
+        'value': pairs / ts, 'unit': 'pairs/s', 'batches': n_batches, 'ms_per_batch': ts / n_batches * 1e3, 'n_items': n_i,
+        'users_to_exact_fallback_last_call': fb_fp32,
+        'roofline': {'bound': 'mfma', 'achieved': round(flops / ts / 1e12 / max(world, 1), 2), 'peak': MFMA_F32_PEAK_TF,
+                     'unit': 'TFLOP/s', 'frac': round(flops / ts / 1e12 / max(world, 1) / MFMA_F32_PEAK_TF, 4), 'traffic': None},
+    }
+    # the same calls with the candidates found by the bf16 matrix pass (every score and the order still come from the
+    # fp32 chains): checked bit for bit against the fp32-filter outputs above, reported beside them -- `value` of this
+    # record stays the fp32 path
+    if d <= 128:
+        tp, keep_p = scoring_region(ue, ie, batches, k_top, dev, barrier, prefilter=True)
+        same = all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(keep, keep_p))
+        if reduce_max_sum is not None:
+            tp = reduce_max_sum([tp, 0.0])[0][0]
+        rec['bf16_candidates'] = {
+            'what': 'tgcn_score_topk_prefilter_f32: bf16 MFMA pass with a proven error bound keeps a superset of the candidates, '
+                    'k-ordered fp32 chains rescore them; top-k lists and scores identical to the fp32 path',
+            'value': pairs / tp, 'unit': 'pairs/s', 'ms_per_batch': tp / n_batches * 1e3, 'streams': n_score_streams(True),
+            'identical_to_fp32_path': bool(same), 'speedup': round(ts / tp, 3),
+            'roofline': candidate_path_roofline(int(batches[0][0].numel()), n_i, d, k_top, tp / n_batches, dev)}
+        del keep_p
+    # the model class scores 16384 users per call (LightGCN.predict_chunk); same kernels, fewer launches
+    big = min(16384, len(users_all))
+    if large and reduce_max_sum is None and big > bsz:
+        n_big = max(1, min(4, len(users_all) // big))
+        bb = [batch_masks(users_all[b * big:(b + 1) * big], mrp, mit, dev) for b in range(n_big)]
+        tb, _ = scoring_region(ue, ie, bb, k_top, dev, barrier)
+        pb = sum(int(bt[0].numel()) for bt in bb) * n_i
+        rec['large_batch'] = {'users_per_call': big, 'value': pb / tb, 'unit': 'pairs/s', 'ms_per_call': tb / n_big * 1e3,
+                              'mfma_frac': round(2.0 * d * pb / tb / 1e12 / MFMA_F32_PEAK_TF, 4)}
+        if d <= 128:
+            tbp, _ = scoring_region(ue, ie, bb, k_top, dev, barrier, prefilter=True)
+            rec['large_batch']['bf16_candidates'] = {
+                'value': pb / tbp, 'unit': 'pairs/s', 'ms_per_call': tbp / n_big * 1e3,
+                'roofline': candidate_path_roofline(big, n_i, d, k_top, tbp / n_big, dev)}
+    if cpu:
+        # bounded CPU sample: the [users, I] matrix of the reference's matmul is 4 I bytes per user (8 MB at config 4)
+        nb = int(min(batches[0][0].numel(), max(64, (1 << 30) // (4 * n_i))))
+        bt = batches[0]
+        rp = bt[1][:nb + 1].cpu().numpy()
+        rec['cpu_baseline'], rec['verify'] = cpu_baseline_scoring(
+            ue[bt[0][:nb]].cpu(), ie.cpu(), rp, bt[2][:int(rp[-1])].cpu().numpy() if int(rp[-1]) else np.zeros(1, dtype=np.int32), 40,
+            gpu_topk=(first_topk[0][:nb], first_topk[1][:nb]))
+    return rec
+
+
+def record_single_gpu(wl, dev, args, steps, warmup, cpu=True, scoring=True, train=False):
+    """One BASELINE configuration on ONE GPU, whole graph: timed K-layer forward, roofline, CPU baseline + verify, scoring."""
     from textgcn_amd import propagate, synth
     from textgcn_amd.graph import NormGraph
-    n_u, n_i, nnz, d, K = synth.CONFIGS['c4']
+    n_u, n_i, nnz, d, K = synth.CONFIGS[wl]
     t0 = time.time()
     u, i = synth.interactions(n_u, n_i, nnz, seed=0)
     graph = NormGraph.from_pairs(u, i, n_u, n_i)
-    del u, i
+    if not train:
+        del u, i
     e0 = synth.embeddings(graph.n, d, seed=0)
     build_s = time.time() - t0
-    prop = propagate.Propagator(graph, dev)
+    thr = args.split_threshold or propagate.DEFAULT_SPLIT_THRESHOLD
+    prop = propagate.Propagator(graph, dev, split_threshold=thr, segment=None if args.no_segment else 'auto')
     e0d = e0.to(dev)
     out = torch.empty_like(e0d)
 
     def barrier():
         torch.cuda.synchronize()
-    t_dev, t_wall = time_steps(lambda: prop.forward(e0d, K, out=out), steps, warmup, barrier)
-    t = max(t_dev, t_wall)
-    traffic, tsrc = load_traffic('c4')
-    rec = {'metric': 'propagated edges/sec (3-layer SpMM, d=64)', 'value': steps * K * graph.nnz / t, 'unit': 'edges/s',
-           'n_gpus': 1, 'steps': steps, 'warmup': warmup, 'ms_per_step': t / steps * 1e3, 'dtype': 'f32', 'data': 'synthetic',
-           'config': {'workload': f'c4: U={n_u} I={n_i} nnz={nnz} d={d} K={K}', 'nnz_A': graph.nnz, 'n_nodes': graph.n,
-                      'max_degree': int(graph.degrees().max()), 'sharding': 'none (whole graph on one GPU)',
-                      'graph_build_s': round(build_s, 1)},
-           'roofline': spmm_roofline(graph.nnz, graph.n, graph.n, d, K, t_dev, steps, traffic, tsrc, dev, deg=graph.degrees())}
+
+    def step():
+        prop.forward(e0d, K, exact=args.exact, out=out)
+    t_dev, t_wall = time_steps(step, steps, warmup, barrier)
+    t = max(t_wall, t_dev)
+    seg = bool(not args.exact and prop.csr.segment_blocks and any(prop.csr.segment_blocks))
+    seg_note = 'none'
+    if seg:
+        seg_note = (f'user rows x{prop.csr.segment_blocks[0]}, item rows x{prop.csr.segment_blocks[1]} column blocks, '
+                    f'{prop.csr.segment_tile}-entry tiles (tgcn_spmm_segmented_f32)')
+    if not args.exact and not args.no_segment:
+        traffic, tsrc = load_traffic(wl)    # the PMC pass was taken on the default path of the workload
+    else:
+        traffic, tsrc = None, 'no PMC pass for this mode'
+    rec = {
+        'metric': f'propagated edges/sec ({K}-layer SpMM, d={d})', 'value': steps * K * graph.nnz / t, 'unit': 'edges/s', 'n_gpus': 1,
+        'steps': steps, 'warmup': warmup, 'ms_per_step': t / steps * 1e3, 'higher_is_better': True, 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'{wl}: U={n_u} I={n_i} nnz={nnz} d={d} K={K}', 'nnz_A': graph.nnz, 'n_nodes': graph.n,
+                   'max_degree': int(graph.degrees().max()),
+                   'mode': 'exact (one fmaf chain per row)' if args.exact else f'rows in groups of consecutive rows, one wave each; rows > {thr} entries split in chunks',
+                   'parity_of_this_mode': 'bit-identical to the reference CPU forward' if args.exact else
+                   'rows cut by the long-row split / XCD segments are summed piecewise: normwise <= 1e-5 vs the exact chain '
+                   '(tests), bar 1e-4; all other rows bit-identical',
+                   'xcd_segments': seg_note, 'sharding': 'none (whole graph on one GPU)', 'graph_build_s': round(build_s, 1)},
+        'roofline': spmm_roofline(graph.nnz, graph.n, graph.n, d, K, t_dev, steps, traffic, tsrc, dev, deg=graph.degrees(),
+                                  kernel=spmm_kernel_names(prop, args.exact, seg)),
+    }
     if cpu:
-        # CPU sample: the layer-1 product of the first user rows holding ~10 M stored entries (the full forward is ~25 s per
-        # layer on torch's single-threaded COO kernel); the same rows of the GPU's layer 1 are checked against it
-        from oracle import torch_port
-        r = int(np.searchsorted(graph.rowptr, 10_000_000))
-        e = int(graph.rowptr[r])
-        rows = np.repeat(np.arange(r, dtype=np.int64), np.diff(graph.rowptr[:r + 1]))
-        a = torch.sparse_coo_tensor(torch.from_numpy(np.stack([rows, graph.colidx[:e].astype(np.int64)])),
-                                    torch.from_numpy(graph.vals[:e].copy()), (r, graph.n)).coalesce()
-        del rows
-        all_threads = torch.get_num_threads()
-        recs = []
-        for threads in (all_threads, 1):
-            torch.set_num_threads(threads)
-            t0 = time.perf_counter()
-            ref = torch.sparse.mm(a, e0)
-            el = time.perf_counter() - t0
-            recs.append({'value': e / el, 'unit': 'edges/s', 'cores': threads, 'kind': 'port',
-                         'sample': f'ONE layer of the first {r} user rows ({e} stored entries, 1/{graph.nnz // e} of a layer) in '
-                                   f'{el:.2f} s: torch.sparse.mm on the coalesced COO slice, {threads} thread(s); the whole-forward '
-                                   f'rate is this rate (extrapolated, BASELINE.md §3)'})
-        torch.set_num_threads(all_threads)
-        rec['cpu_baseline'] = dict(recs[0], one_thread=recs[1])
-        y1 = torch.empty_like(e0d)
-        propagate.spmm(prop.csr, e0d, y=y1)
-        got = y1[:r].cpu().numpy()
-        # the hottest row (the ~1 M-entry item row, split into ~1000 chunks) against a float64 dot over its entries
-        hot = int(np.argmax(graph.degrees()))
-        a0, a1 = int(graph.rowptr[hot]), int(graph.rowptr[hot + 1])
-        ref_hot = (graph.vals[a0:a1].astype(np.float64)[:, None] * e0.numpy()[graph.colidx[a0:a1]].astype(np.float64)).sum(axis=0)
-        got_hot = y1[hot].cpu().numpy().astype(np.float64)
-        v = {'what': f'layer 1 of the timed path: rows 0..{r} vs torch.sparse.mm on the CPU; hottest row {hot} ({a1 - a0} entries) '
-                     f'vs a float64 dot',
-             'normwise_max_err': float(np.abs(got.astype(np.float64) - ref.numpy()).max() / np.abs(ref.numpy()).max()),
-             'hottest_row_normwise_err': float(np.abs(got_hot - ref_hot).max() / np.abs(ref_hot).max()), 'bar': 1e-4}
-        v['ok'] = bool(v['normwise_max_err'] <= 1e-4 and v['hottest_row_normwise_err'] <= 1e-4)
-        rec['verify'] = v
+        if graph.nnz <= 30_000_000:
+            rec['cpu_baseline'], rec['verify'] = cpu_baseline_propagation(graph, e0, K, gpu_out=out)
+        else:
+            rec['cpu_baseline'], rec['verify'] = cpu_slice_baseline_and_verify(graph, e0, prop, e0d)
+    if scoring and not args.no_scoring:
+        step()
+        ue, ie = out[:n_u].contiguous(), out[n_u:].contiguous()
+        mrp, mit = graph.train_mask()      # = train_mask_csr(u, i, n_u): the generator's pairs are distinct
+        rec['scoring'] = scoring_record(ue, ie, np.arange(n_u), mrp, mit, n_i, d, dev, args, barrier, cpu=cpu, large=n_i <= 500_000)
+        del ue, ie
+    if train:
+        rec['training'] = record_train_step(dev, u, i, graph, n_u, n_i, d, K)
+    del prop, e0d, out
+    torch.cuda.empty_cache()
     return rec
 
 
@@ -481,7 +608,8 @@ def records_c3_c5(dev, want_c5=True, cpu=True):
           'steps': reps, 'ms_per_step': t_fwd * 1e3, 'dtype': 'f32', 'data': 'synthetic',
           'config': {'workload': f'c3: U={n_u} I={n_i} nnz={nnz} d={d} K={K}', 'nnz_A': g.nnz, 'graph_build_s': round(build_s, 1),
                      'through': 'textgcn_amd.LightGCN.representation / predict_tensors'},
-          'roofline': spmm_roofline(g.nnz, g.n, g.n, d, K, t_fwd, 1, traffic, tsrc, dev, deg=g.degrees()),
+          'roofline': spmm_roofline(g.nnz, g.n, g.n, d, K, t_fwd, 1, traffic, tsrc, dev, deg=g.degrees(),
+                                    kernel=spmm_kernel_names(m._engine, False, False)),
           'scoring': {'metric': 'scored user-item pairs/sec (full catalogue: every user x every item, mask + top-40 fused)',
                       'value': pairs / t_score, 'unit': 'pairs/s', 'ms_total': t_score * 1e3,
                       'roofline': {'bound': 'mfma', 'achieved': round(2.0 * d * pairs / t_score / 1e12, 2), 'peak': MFMA_F32_PEAK_TF,
@@ -615,20 +743,24 @@ def record_train_step(dev, u, i, graph, n_u, n_i, d, K, steps=10):
             'through': 'textgcn_amd.LightGCN._train_epoch (get_loss -> backward -> optimizer.step, as fit() does)'}
 
 
-def shared_workload(wl, rank, barrier):
-    """N > 1: the synthetic graph and E0 are generated ONCE per node -- rank 0 builds them (30 s and ~12 GB of host memory for
-    config 4; eight concurrent builds would be eight times both) and publishes the arrays as .npy files in a node-local
+def shared_workload(wl, rank, local_rank, barrier):
+    """N > 1: the synthetic graph and E0 are generated ONCE per node -- local rank 0 builds them (30 s and ~12 GB of host memory
+    for config 4; eight concurrent builds would be eight times both) and publishes the arrays as .npy files in a node-local
     directory (memory-backed /dev/shm when present), the other ranks wait at a barrier and memory-map them: a rank then only
     touches the pages of its own row blocks.  Returns (NormGraph over the mapped arrays, E0 as a torch tensor over the map,
-    directory -- removed by rank 0 at the end)."""
+    directory).  The building rank removes the directory at exit, whatever way the run ends (atexit + the finally of main)."""
+    import atexit
+    import shutil
     import tempfile
     from textgcn_amd import synth
     from textgcn_amd.graph import NormGraph
     n_u, n_i, nnz, d, _ = synth.CONFIGS[wl]
     base = '/dev/shm' if os.path.isdir('/dev/shm') and os.access('/dev/shm', os.W_OK) else tempfile.gettempdir()
     path = os.path.join(base, f"tgcn_bench_{os.environ.get('MASTER_PORT', '0')}_{wl}")
-    if rank == 0:
+    if local_rank == 0:
+        shutil.rmtree(path, ignore_errors=True)      # a crashed earlier run with the same port
         os.makedirs(path, exist_ok=True)
+        atexit.register(shutil.rmtree, path, ignore_errors=True)
         u, i = synth.interactions(n_u, n_i, nnz, seed=0)
         g = NormGraph.from_pairs(u, i, n_u, n_i)
         del u, i
@@ -648,20 +780,202 @@ def device_identity(dev):
     return f"{pci or 'pci?'} {getattr(p, 'uuid', '')} {p.name}".strip()
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a torch.distributed environment: start the N ranks as CHILD processes (never an exec;
+    this process has not touched the GPU) and hand back their exit code.  Rank 0's JSON line goes to this process's stdout."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // n)))
+    print(f'bench.py: starting {n} ranks: {" ".join(cmd)}', file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def run_sharded(args, world, rank, local_rank, dev, dev_index, rehearsal):
+    """N > 1 (or --force-sharded): BASELINE config 4 (default) row-sharded over the ranks."""
+    import torch.distributed as dist
+    from textgcn_amd import propagate, synth
+    from textgcn_amd.dist import ColumnShardedPropagator, ShardedPropagator
+    from textgcn_amd.graph import NormGraph
+    wl = args.workload or 'c4'
+    n_u, n_i, nnz, d, K = synth.CONFIGS[wl]
+    wl_name = f'{wl}: U={n_u} I={n_i} nnz={nnz} d={d} K={K}'
+    t0 = time.time()
+    share_dir = None
+    if world > 1:
+        graph, e0, share_dir = shared_workload(wl, rank, local_rank, dist.barrier)
+    else:
+        u, i = synth.interactions(n_u, n_i, nnz, seed=0)
+        graph = NormGraph.from_pairs(u, i, n_u, n_i)
+        del u, i
+        e0 = synth.embeddings(graph.n, d, seed=0)
+    build_s = time.time() - t0
+    thr = args.split_threshold or propagate.DEFAULT_SPLIT_THRESHOLD
+    chunks = args.chunks or (4 if graph.nnz >= 50_000_000 else 1)
+    if args.shard == 'features':
+        sp = ColumnShardedPropagator(graph, d, rank, world, dev, split_threshold=thr, force_collective=args.force_sharded)
+        e_cols = sp.local_e0(e0)
+
+        def step():      # the K layers on this rank's columns + the one all-gather that assembles the d columns everywhere
+            return sp.assemble(sp.forward(e_cols, K, exact=args.exact))
+        n_rows_local, n_src, nnz_local = graph.n, graph.n, graph.nnz
+    else:
+        sp = ShardedPropagator(graph, rank, world, dev, split_threshold=thr, balance=args.balance, chunks=chunks,
+                               force_collective=args.force_sharded)
+        eu, ei = sp.local_e0(e0)
+
+        def step():
+            sp.forward(eu, ei, K, exact=args.exact)
+        n_rows_local, n_src, nnz_local = sp.bu + sp.bi, sp.n_pad, sp.nnz_local
+
+    def barrier():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    def reduce_max_sum(vals):
+        """(max over ranks, sum over ranks) of a small list of floats"""
+        t = torch.tensor(vals, dtype=torch.float64, device='cpu' if rehearsal else dev)
+        mx, sm = t.clone(), t.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+        return mx.tolist(), sm.tolist()
+
+    try:
+        t_dev, t_wall = time_steps(step, args.steps, args.warmup, barrier)
+        t = reduce_max_sum([max(t_wall, t_dev)])[0][0]
+        d_local = sp.dl if args.shard == 'features' else d
+        roofline = spmm_roofline(nnz_local, n_rows_local, n_src, d_local, K, t_dev, args.steps, None, 'no PMC pass for this mode', dev,
+                                 gather=False, kernel='one SpMM layer on this rank = 2 x chunks launches of k_spmm_groups (+ k_spmm_long_reduce)')
+        roofline['note'] = 'per rank: this rank\'s row blocks, launch time includes waiting for the all-gathered tables'
+        result = {
+            'metric': f'propagated edges/sec ({K}-layer SpMM, d={d})', 'value': args.steps * K * graph.nnz / t, 'unit': 'edges/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': t / args.steps * 1e3, 'higher_is_better': True,
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': wl_name, 'nnz_A': graph.nnz, 'n_nodes': graph.n, 'max_degree': int(graph.degrees().max()),
+                       'mode': 'exact (one fmaf chain per row)' if args.exact else f'rows in groups of consecutive rows, one wave each; rows > {thr} entries split in chunks',
+                       'parity_of_this_mode': 'bit-identical to the reference CPU forward' if args.exact else
+                       'rows cut by the long-row split are summed piecewise: normwise <= 1e-5 vs the exact chain (tests), bar 1e-4; '
+                       'all other rows bit-identical; the result does not depend on the number of ranks',
+                       'xcd_segments': sp.segment_note() if hasattr(sp, 'segment_note') else 'none',
+                       'sharding': (
+                           f'feature-sharded x{world}: all rows, {sp.dl} of {d} columns per rank, no per-layer exchange, one RCCL all-gather of '
+                           f'the combined table per forward' if args.shard == 'features' else
+                           f'row-sharded x{world} ({args.balance}-balanced blocks padded to the largest, {sp.lay_u.chunks} row chunk(s) per '
+                           f'block), RCCL all-gather per chunk and layer (users || item half-step)'),
+                       'graph_build_s': round(build_s, 1)},
+            'roofline': roofline,
+        }
+        if args.shard == 'rows' and d % world == 0 and d // world in (8, 16, 32, 64) and args.feature_partition:
+            # the same forward under the feature partition (every rank: all rows, d / world columns, no per-layer exchange, one
+            # all-gather at the end), timed the same way in the same run: the record's `value` stays the row partition's
+            cp = ColumnShardedPropagator(graph, d, rank, world, dev, split_threshold=thr, force_collective=args.force_sharded)
+            e_cols = cp.local_e0(e0)
+
+            def step_cols():
+                return cp.assemble(cp.forward(e_cols, K, exact=args.exact))
+            tc_dev, tc_wall = time_steps(step_cols, args.steps, args.warmup, barrier)
+            tc = reduce_max_sum([max(tc_wall, tc_dev)])[0][0]
+            result['feature_partition'] = {
+                'what': f'all rows, {cp.dl} of {d} columns per rank, no per-layer exchange, one RCCL all-gather of the combined table per '
+                        f'forward (ColumnShardedPropagator); bit-identical to the row partition',
+                'value': args.steps * K * graph.nnz / tc, 'unit': 'edges/s', 'ms_per_step': tc / args.steps * 1e3}
+            cp.close()
+            del cp, e_cols
+            torch.cuda.empty_cache()
+        # evidence that N ranks ran on N distinct devices, and where a layer's time went on the slowest rank
+        ident = [None] * world
+        dist.all_gather_object(ident, f'rank {rank}: cuda:{dev_index} {device_identity(dev)}')
+        result['config']['world_size'] = dist.get_world_size()
+        result['config']['backend'] = dist.get_backend()
+        result['config']['devices'] = ident
+        result['config']['distinct_devices'] = len({x.split(': ', 1)[1] for x in ident})
+        if args.shard == 'rows':
+            sp.record_events = True
+            reps = 3
+            tot = None
+            for _ in range(reps):
+                step()
+                lt = sp.layer_times()
+                tot = lt if tot is None else [{'layer': a['layer'], 'compute_ms': a['compute_ms'] + b['compute_ms'],
+                                               'wait_on_gather_ms': a['wait_on_gather_ms'] + b['wait_on_gather_ms']}
+                                              for a, b in zip(tot, lt)]
+            sp.record_events = False
+            mine = [{'layer': a['layer'] if a['layer'] <= K else 'final gather', 'compute_ms': round(a['compute_ms'] / reps, 3),
+                     'wait_on_gather_ms': round(a['wait_on_gather_ms'] / reps, 3)} for a in tot]
+            # the two halves alone, same ranks, same buffers: all SpMM launches without a gather, all gathers without an SpMM
+            barrier()
+            alone = sp.phase_times(eu, ei, K, reps=3, exact=args.exact)
+            barrier()
+            every = [None] * world
+            dist.all_gather_object(every, (mine, alone))
+            spmm_alone = [max(r[1]['spmm_alone_ms'][j] for r in every) for j in range(K)]
+            gather_alone = [max(r[1]['allgather_alone_ms'][j] for r in every) for j in range(K)]
+            longer = max(sum(spmm_alone), sum(gather_alone))
+            result['layers'] = {
+                'what': 'per layer, HIP events on the launch stream (3 extra forwards after the timed region): ms the stream spent in '
+                        'its SpMM launches (both half-steps) and ms it sat waiting for an all-gathered block; then the two halves ALONE '
+                        '(3 passes each): every SpMM launch of the layer with no gather issued, every all-gather the layer issues with '
+                        'no SpMM launched (max over ranks)',
+                'rank0': mine,
+                'max_over_ranks': [{'layer': m['layer'], 'compute_ms': max(r[0][j]['compute_ms'] for r in every),
+                                    'wait_on_gather_ms': max(r[0][j]['wait_on_gather_ms'] for r in every)} for j, m in enumerate(mine)],
+                'spmm_alone_ms': spmm_alone, 'allgather_alone_ms': gather_alone,
+                'overlap_efficiency': round(longer / (t / args.steps * 1e3), 4) if t > 0 else None,
+                'overlap_efficiency_is': 'max(sum spmm_alone, sum allgather_alone) / measured ms_per_step: 1.0 = the shorter half is '
+                                         'completely hidden under the longer one'}
+        if world > 1:
+            result['scaling'] = 'strong'      # fixed total work (config 4) split over the ranks
+        result['config']['scaling_note'] = ('fixed total work (the same workload for every N, default BASELINE config 4) split over the '
+                                            'ranks; N = 1 = `bench.py --gpus 1`, the whole graph on one GPU')
+
+        # ---------------- second metric: scored pairs/s (every rank scores its own users)
+        if not args.no_scoring:
+            if args.shard == 'features':    # every rank holds the whole combined table; users are split evenly for scoring
+                full = step()
+                per = -(-n_u // world)
+                users_all = np.arange(rank * per, min((rank + 1) * per, n_u))
+                ue, ie = full[users_all[0]:users_all[-1] + 1], full[n_u:]
+            else:
+                ue, itab = sp.forward(eu, ei, K, exact=args.exact)
+                ie = sp.items_in_order(itab)
+                users_all = np.arange(*sp.user_range())
+            mrp, mit = graph.train_mask()
+            result['scoring'] = scoring_record(ue.contiguous(), ie.contiguous(), users_all, mrp, mit, n_i, d, dev, args, barrier, world=world,
+                                               reduce_max_sum=reduce_max_sum, cpu=False, large=False)
+        if rank == 0:
+            print(json.dumps(result), flush=True)
+    finally:
+        sp.close()
+        try:
+            dist.barrier()
+        except Exception:
+            pass
+        if share_dir is not None and local_rank == 0:
+            import shutil
+            shutil.rmtree(share_dir, ignore_errors=True)
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--workload', default=None, help='c2 (default at N = 1), c4 (default at N > 1), c3, small, tiny')
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', default=None, help='c4 (default for every N), c2, c3, small, tiny')
     ap.add_argument('--exact', action='store_true', help='no long-row split: bit-identical to the CPU reference')
     ap.add_argument('--split-threshold', type=int, default=None)
-    ap.add_argument('--no-segment', action='store_true', help='keep every row on the one-wave-per-row kernel (no XCD-affine segments)')
+    ap.add_argument('--no-segment', action='store_true', help='keep every row on the row-group kernel (no XCD-affine segments)')
     ap.add_argument('--score-batches', type=int, default=20)
     ap.add_argument('--score-batch-size', type=int, default=2048, help='users per scoring call (reference batch_size = 2048)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-scoring', action='store_true')
-    ap.add_argument('--sub', default=None, help="comma list of sub-records at N = 1: c4,c3,c5,train (default: all for the default "
+    ap.add_argument('--sub', default=None, help="comma list of sub-records at N = 1: c2,c3,c5,train (default: all for the default "
                                                 "workload, none otherwise); 'none' to skip")
     ap.add_argument('--chunks', type=int, default=None, help='row chunks per block for the pipelined all-gather (N > 1)')
     ap.add_argument('--balance', default='nnz', choices=['nnz', 'rows'])
@@ -679,24 +993,31 @@ def main():
     args = ap.parse_args()
     SCORE_STREAMS[False], SCORE_STREAMS[True] = args.streams_fp32, args.streams_prefilter
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N')
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs a ROCm GPU: the HIP path has no CPU fallback')
     # rehearsal switch for the one-GPU box: every rank on cuda:0, gloo staged through the host (tests only; the
     # driver's multi-GPU runs use RCCL, one GPU per rank).  Refused where more than one GPU is visible: there it could
     # only turn a real multi-GPU run into a silent one-GPU run.
     rehearsal = os.environ.get('TGCN_BENCH_REHEARSAL') == '1'
-    if rehearsal and torch.cuda.device_count() > 1:
-        raise SystemExit('TGCN_BENCH_REHEARSAL=1 (all ranks on cuda:0 over gloo) is for one-GPU boxes; '
-                         f'{torch.cuda.device_count()} GPUs are visible here -- unset it')
-    if world > 1 and not rehearsal and torch.cuda.device_count() < world:
-        raise SystemExit(f'--gpus {world} needs {world} visible GPUs (one per rank), found {torch.cuda.device_count()}')
+    n_visible = torch.cuda.device_count()        # counting does not initialise the GPU (no exec hazard, nothing allocated)
+    if rehearsal and n_visible > 1:
+        raise SystemExit(f'TGCN_BENCH_REHEARSAL=1 (all ranks on cuda:0 over gloo) is for one-GPU boxes; {n_visible} GPUs are visible here -- unset it')
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # started plainly (the form the driver's N = 1 command has): become the launcher
+        if not rehearsal and n_visible < args.gpus:
+            raise SystemExit(f'--gpus {args.gpus} needs {args.gpus} visible GPUs (one per rank), found {n_visible} '
+                             '(one-GPU rehearsal of the N > 1 path: TGCN_BENCH_REHEARSAL=1)')
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if world > 1 and int(os.environ.get('LOCAL_WORLD_SIZE', world)) != world:
+        raise SystemExit('bench.py is a single-node benchmark (the graph is shared through node-local memory): LOCAL_WORLD_SIZE != WORLD_SIZE')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a ROCm GPU: the HIP path has no CPU fallback')
+    if world > 1 and not rehearsal and n_visible < world:
+        raise SystemExit(f'--gpus {world} needs {world} visible GPUs (one per rank), found {n_visible}')
     dev_index = 0 if rehearsal else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
@@ -711,262 +1032,22 @@ def main():
             dist.init_process_group(backend='gloo')
         else:
             dist.init_process_group(backend='nccl', device_id=dev)
+        run_sharded(args, world, rank, local_rank, dev, dev_index, rehearsal)
+        return
 
-    from textgcn_amd import propagate, synth
-    from textgcn_amd.graph import NormGraph
-
+    # ---------------- N = 1: the headline workload (config 4 unless --workload), then the other single-GPU configurations
     default_wl = args.workload is None
-    wl = args.workload or ('c4' if sharded else 'c2')
-    n_u, n_i, nnz, d, K = synth.CONFIGS[wl]
-    wl_name = f'{wl}: U={n_u} I={n_i} nnz={nnz} d={d} K={K}'
-    t0 = time.time()
-    if world > 1:
-        graph, e0, share_dir = shared_workload(wl, rank, dist.barrier)
-        u = i = None
-    else:
-        u, i = synth.interactions(n_u, n_i, nnz, seed=0)
-        graph = NormGraph.from_pairs(u, i, n_u, n_i)
-        e0 = synth.embeddings(graph.n, d, seed=0)
-        share_dir = None
-    build_s = time.time() - t0
-    thr = args.split_threshold or propagate.DEFAULT_SPLIT_THRESHOLD
-
-    if not sharded:
-        prop = propagate.Propagator(graph, dev, split_threshold=thr, segment=None if args.no_segment else 'auto')
-        e0d = e0.to(dev)
-        out = torch.empty_like(e0d)
-
-        def step():
-            prop.forward(e0d, K, exact=args.exact, out=out)
-        n_rows_local, n_src, nnz_local = graph.n, graph.n, graph.nnz
-    else:
-        from textgcn_amd.dist import ColumnShardedPropagator, ShardedPropagator
-        chunks = args.chunks or (4 if graph.nnz >= 50_000_000 else 1)
-        if args.shard == 'features':
-            sp = ColumnShardedPropagator(graph, d, rank, world, dev, split_threshold=thr, force_collective=args.force_sharded)
-            e_cols = sp.local_e0(e0)
-
-            def step():      # the K layers on this rank's columns + the one all-gather that assembles the d columns everywhere
-                return sp.assemble(sp.forward(e_cols, K, exact=args.exact))
-            n_rows_local, n_src, nnz_local = graph.n, graph.n, graph.nnz
-        else:
-            sp = ShardedPropagator(graph, rank, world, dev, split_threshold=thr, balance=args.balance, chunks=chunks,
-                                   force_collective=args.force_sharded)
-            eu, ei = sp.local_e0(e0)
-
-            def step():
-                sp.forward(eu, ei, K, exact=args.exact)
-            n_rows_local, n_src, nnz_local = sp.bu + sp.bi, sp.n_pad, sp.nnz_local
-
-    def barrier():
-        torch.cuda.synchronize()
-        if sharded:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
-
-    def reduce_max_sum(vals):
-        """(max over ranks, sum over ranks) of a small list of floats"""
-        t = torch.tensor(vals, dtype=torch.float64, device='cpu' if rehearsal else dev)
-        mx, sm = t.clone(), t.clone()
-        torch.distributed.all_reduce(mx, op=torch.distributed.ReduceOp.MAX)
-        torch.distributed.all_reduce(sm, op=torch.distributed.ReduceOp.SUM)
-        return mx.tolist(), sm.tolist()
-
-    t_dev, t_wall = time_steps(step, args.steps, args.warmup, barrier)
-    t = max(t_wall, t_dev)
-    if sharded:
-        t = reduce_max_sum([t])[0][0]
-    value = args.steps * K * graph.nnz / t
-    seg_note = 'none'
-    if not sharded and not args.exact and prop.csr.segment_blocks and any(prop.csr.segment_blocks):
-        seg_note = (f'user rows x{prop.csr.segment_blocks[0]}, item rows x{prop.csr.segment_blocks[1]} column blocks, '
-                    f'{prop.csr.segment_tile}-entry tiles (tgcn_spmm_segmented_f32)')
-
-    # ---------------- roofline of the dominant kernel (one SpMM layer launch on this rank)
-    if not sharded and not args.exact and not args.no_segment:
-        traffic, tsrc = load_traffic(wl)    # the PMC pass was taken on the default path of the workload
-    else:
-        traffic, tsrc = None, 'no PMC pass for this mode'
-    d_local = sp.dl if (sharded and args.shard == 'features') else d
-    roofline = spmm_roofline(nnz_local, n_rows_local, n_src, d_local, K, t_dev, args.steps, traffic, tsrc, dev, gather=not sharded,
-                             deg=None if sharded else graph.degrees())
-    if sharded:
-        roofline['note'] = 'per rank: this rank\'s row blocks, launch time includes waiting for the all-gathered tables'
-
-    result = {
-        'metric': 'propagated edges/sec (3-layer SpMM, d=64)', 'value': value, 'unit': 'edges/s', 'n_gpus': world,
-        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': t / args.steps * 1e3, 'higher_is_better': True,
-        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': wl_name, 'nnz_A': graph.nnz, 'n_nodes': graph.n, 'max_degree': int(graph.degrees().max()),
-                   'mode': 'exact (one fmaf chain per row)' if args.exact else f'one-wave-per-row kernel: rows > {thr} entries split in chunks',
-                   'parity_of_this_mode': 'bit-identical to the reference CPU forward' if args.exact else
-                   'rows cut by the long-row split / XCD segments are summed piecewise: normwise <= 1e-5 vs the exact chain '
-                   '(tests), bar 1e-4; all other rows bit-identical',
-                   'xcd_segments': seg_note,
-                   'sharding': 'none' if not sharded else (
-                       f'feature-sharded x{world}: all rows, {sp.dl} of {d} columns per rank, no per-layer exchange, one RCCL all-gather of '
-                       f'the combined table per forward' if args.shard == 'features' else
-                       f'row-sharded x{world} ({args.balance}-balanced blocks padded to the largest, {sp.lay_u.chunks} row chunk(s) per '
-                       f'block), RCCL all-gather per chunk and layer (users || item half-step)'),
-                   'graph_build_s': round(build_s, 1)},
-        'roofline': roofline,
-    }
-    if sharded and args.shard == 'rows' and d % world == 0 and d // world in (8, 16, 32, 64) and args.feature_partition:
-        # the same forward under the feature partition (every rank: all rows, d / world columns, no per-layer exchange, one
-        # all-gather at the end), timed the same way in the same run: the record's `value` stays the row partition's
-        cp = ColumnShardedPropagator(graph, d, rank, world, dev, split_threshold=thr, force_collective=args.force_sharded)
-        e_cols = cp.local_e0(e0)
-
-        def step_cols():
-            return cp.assemble(cp.forward(e_cols, K, exact=args.exact))
-        tc_dev, tc_wall = time_steps(step_cols, args.steps, args.warmup, barrier)
-        tc = reduce_max_sum([max(tc_wall, tc_dev)])[0][0]
-        result['feature_partition'] = {
-            'what': f'all rows, {cp.dl} of {d} columns per rank, no per-layer exchange, one RCCL all-gather of the combined table per '
-                    f'forward (ColumnShardedPropagator); bit-identical to the row partition',
-            'value': args.steps * K * graph.nnz / tc, 'unit': 'edges/s', 'ms_per_step': tc / args.steps * 1e3}
-        cp.close()
-        del cp, e_cols
+    wl = args.workload or 'c4'
+    cpu = not args.no_cpu_baseline
+    result = record_single_gpu(wl, dev, args, args.steps, args.warmup, cpu=cpu)
+    sub = args.sub if args.sub is not None else ('c2,c3,c5,train' if default_wl else 'none')
+    sub = [] if sub == 'none' else [s.strip() for s in sub.split(',') if s.strip()]
+    if 'c2' in sub and wl != 'c2':
+        result['c2'] = record_single_gpu('c2', dev, args, 50, 5, cpu=cpu, train='train' in sub)
+    if 'c3' in sub or 'c5' in sub:
+        result.update(records_c3_c5(dev, want_c5='c5' in sub, cpu=cpu))
         torch.cuda.empty_cache()
-    if sharded:
-        # evidence that N ranks ran on N distinct devices, and where a layer's time went on the slowest rank
-        ident = [None] * world
-        torch.distributed.all_gather_object(ident, f'rank {rank}: cuda:{dev_index} {device_identity(dev)}')
-        result['config']['world_size'] = torch.distributed.get_world_size()
-        result['config']['backend'] = torch.distributed.get_backend()
-        result['config']['devices'] = ident
-        result['config']['distinct_devices'] = len({x.split(': ', 1)[1] for x in ident})
-        if args.shard == 'rows':
-            sp.record_events = True
-            reps = 3
-            tot = None
-            for _ in range(reps):
-                step()
-                lt = sp.layer_times()
-                tot = lt if tot is None else [{'layer': a['layer'], 'compute_ms': a['compute_ms'] + b['compute_ms'],
-                                               'wait_on_gather_ms': a['wait_on_gather_ms'] + b['wait_on_gather_ms']}
-                                              for a, b in zip(tot, lt)]
-            sp.record_events = False
-            mine = [{'layer': a['layer'] if a['layer'] <= K else 'final gather', 'compute_ms': round(a['compute_ms'] / reps, 3),
-                     'wait_on_gather_ms': round(a['wait_on_gather_ms'] / reps, 3)} for a in tot]
-            every = [None] * world
-            torch.distributed.all_gather_object(every, mine)
-            result['layers'] = {
-                'what': 'per layer, HIP events on the launch stream (3 extra forwards after the timed region): ms the stream spent in '
-                        'its SpMM launches (both half-steps) and ms it sat waiting for an all-gathered block',
-                'rank0': mine,
-                'max_over_ranks': [{'layer': m['layer'], 'compute_ms': max(r[j]['compute_ms'] for r in every),
-                                    'wait_on_gather_ms': max(r[j]['wait_on_gather_ms'] for r in every)} for j, m in enumerate(mine)]}
-    if world > 1:
-        result['scaling'] = 'strong'      # fixed total work (config 4) split over the ranks; a 1-GPU run has no scaling to name
-    if sharded:
-        result['config']['scaling_note'] = 'fixed total work (BASELINE config 4) split over the ranks; N = 1 of the same workload: ' \
-                                           'bench.py --gpus 1 reports it as the sub-record c4_1gpu'
-
-    # ---------------- second metric: scored pairs/s (rank 0's users; every rank scores its own users)
-    first_topk = batches = None
-    if not args.no_scoring:
-        k_top = 40
-        bsz = args.score_batch_size
-        if not sharded:
-            ue, ie = out[:n_u], out[n_u:]
-            users_all = np.arange(n_u)
-        elif args.shard == 'features':    # every rank holds the whole combined table; users are split evenly for scoring
-            full = step()
-            per = -(-n_u // world)
-            users_all = np.arange(rank * per, min((rank + 1) * per, n_u))
-            ue, ie = full[users_all[0]:users_all[-1] + 1], full[n_u:]
-        else:
-            ue, itab = sp.forward(eu, ei, K, exact=args.exact)
-            ie = sp.items_in_order(itab)
-            users_all = np.arange(*sp.user_range())
-        mrp, mit = graph.train_mask()      # = train_mask_csr(u, i, n_u): the generator's pairs are distinct
-        n_batches = min(args.score_batches, max(1, len(users_all) // bsz))
-        batches = [batch_masks(users_all[b * bsz:(b + 1) * bsz], mrp, mit, dev, ids_origin=users_all[0]) for b in range(n_batches)]
-        ue = ue.contiguous()
-        ie = ie.contiguous()
-        ts, keep = scoring_region(ue, ie, batches, k_top, dev, barrier)
-        first_topk = keep[0]
-        from textgcn_amd import scoring as _sc
-        fb_fp32 = _sc.fallback_count(dev, int(batches[0][0].numel()), n_i, d, k_top, slot=0)
-        pairs = sum(int(bt[0].numel()) for bt in batches) * n_i
-        if sharded:
-            mx, sm = reduce_max_sum([ts, float(pairs)])
-            ts, pairs = mx[0], sm[1]
-        flops = 2.0 * d * pairs
-        result['scoring'] = {
-            'metric': f'scored user-item pairs/sec (scores + train mask + top-40 fused, B={bsz} per call, {n_score_streams(False)} streams)', 'value': pairs / ts,
-            'unit': 'pairs/s', 'batches': n_batches, 'ms_per_batch': ts / n_batches * 1e3,
-            'users_to_exact_fallback_last_call': fb_fp32,
-            'roofline': {'bound': 'mfma', 'achieved': round(flops / ts / 1e12 / max(world, 1), 2), 'peak': MFMA_F32_PEAK_TF,
-                         'unit': 'TFLOP/s', 'frac': round(flops / ts / 1e12 / max(world, 1) / MFMA_F32_PEAK_TF, 4), 'traffic': None},
-        }
-        # the same calls with the candidates found by the bf16 matrix pass (every score and the order still come from the
-        # fp32 chains): checked bit for bit against the fp32-filter outputs above, reported beside them -- `value` of this
-        # record stays the fp32 path
-        if d <= 128:
-            tp, keep_p = scoring_region(ue, ie, batches, k_top, dev, barrier, prefilter=True)
-            same = all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(keep, keep_p))
-            if sharded:
-                tp = reduce_max_sum([tp, 0.0])[0][0]
-            result['scoring']['bf16_candidates'] = {
-                'what': 'tgcn_score_topk_prefilter_f32: bf16 MFMA pass with a proven error bound keeps a superset of the candidates, '
-                        'k-ordered fp32 chains rescore them; top-k lists and scores identical to the fp32 path',
-                'value': pairs / tp, 'unit': 'pairs/s', 'ms_per_batch': tp / n_batches * 1e3, 'streams': n_score_streams(True),
-                'identical_to_fp32_path': bool(same), 'speedup': round(ts / tp, 3),
-                'roofline': candidate_path_roofline(int(batches[0][0].numel()), n_i, d, k_top, tp / n_batches, dev)}
-        # the model class scores 16384 users per call (LightGCN.predict_chunk); same kernels, fewer launches
-        big = min(16384, len(users_all))
-        if not sharded and big > bsz:
-            n_big = max(1, min(4, len(users_all) // big))
-            bb = [batch_masks(users_all[b * big:(b + 1) * big], mrp, mit, dev) for b in range(n_big)]
-            tb, _ = scoring_region(ue, ie, bb, k_top, dev, barrier)
-            pb = sum(int(bt[0].numel()) for bt in bb) * n_i
-            result['scoring']['large_batch'] = {'users_per_call': big, 'value': pb / tb, 'unit': 'pairs/s',
-                                                'ms_per_call': tb / n_big * 1e3,
-                                                'mfma_frac': round(2.0 * d * pb / tb / 1e12 / MFMA_F32_PEAK_TF, 4)}
-            if d <= 128:
-                tbp, _ = scoring_region(ue, ie, bb, k_top, dev, barrier, prefilter=True)
-                result['scoring']['large_batch']['bf16_candidates'] = {
-                    'value': pb / tbp, 'unit': 'pairs/s', 'ms_per_call': tbp / n_big * 1e3,
-                    'roofline': candidate_path_roofline(big, n_i, d, k_top, tbp / n_big, dev)}
-
-    # ---------------- CPU baseline beside it + verification of the timed outputs (rank 0, N = 1 only; outside the timed regions)
-    if not sharded and not args.no_cpu_baseline:
-        if graph.nnz <= 30_000_000:
-            result['cpu_baseline'], result['verify'] = cpu_baseline_propagation(graph, e0, K, gpu_out=out)
-        if not args.no_scoring:
-            bt = batches[0]
-            result['scoring']['cpu_baseline'], result['scoring']['verify'] = cpu_baseline_scoring(
-                ue[bt[0]].cpu(), ie.cpu(), bt[1].cpu().numpy(), bt[2].cpu().numpy(), 40, gpu_topk=first_topk)
-
-    # ---------------- the other single-GPU configurations (N = 1)
-    if not sharded:
-        sub = args.sub if args.sub is not None else ('c4,c3,c5,train' if default_wl else 'none')
-        sub = [] if sub == 'none' else [s.strip() for s in sub.split(',') if s.strip()]
-        if 'train' in sub:
-            result['training'] = record_train_step(dev, u, i, graph, n_u, n_i, d, K)
-        del prop, e0d, out
-        if not args.no_scoring:
-            del ue, ie
-        torch.cuda.empty_cache()
-        cpu = not args.no_cpu_baseline
-        if 'c3' in sub or 'c5' in sub:
-            result.update(records_c3_c5(dev, want_c5='c5' in sub, cpu=cpu))
-            torch.cuda.empty_cache()
-        if 'c4' in sub:
-            del graph, e0, u, i
-            result['c4_1gpu'] = record_c4_one_gpu(dev, cpu=cpu)
-
-    if rank == 0:
-        print(json.dumps(result))
-    if sharded:
-        sp.close()
-        torch.distributed.barrier()
-        if share_dir is not None and rank == 0:
-            import shutil
-            shutil.rmtree(share_dir, ignore_errors=True)
-        torch.distributed.destroy_process_group()
+    print(json.dumps(result), flush=True)
 
 
 if __name__ == '__main__':

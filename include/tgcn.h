@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define TGCN_ABI_VERSION 8
+#define TGCN_ABI_VERSION 9
 
 #define TGCN_OK 0
 #define TGCN_ERR_ARG (-1)         /* bad argument (null pointer, size, unsupported d/k ...) */
@@ -85,6 +85,19 @@ int tgcn_spmm_csr_f32(const int32_t *rowptr, const int32_t *colidx, const float 
                       float *acc_out, float acc_div, const tgcn_split_plan_t *plan, const int32_t *row_order,
                       uint32_t flags, tgcn_stream_t stream);
 
+/* The same product with the rows at or below the split threshold handed out in GROUPS of consecutive rows (ABI v9; d in
+ * {64, 128, 256}; gathered table below 4 GB).  groups [n_groups][2] = {first row, rows}: 1 <= rows <= 8 (d = 256: 4); every row
+ * that the split plan does not cut must lie in exactly one group, no cut row in any.  One wavefront owns a group: the n + 1 row
+ * pointers are one load, the entries of consecutive rows one contiguous range walked with the row gathers in flight across row
+ * ends, the acc_in rows are requested before anything else and the n epilogues issued together.  Every row is still one
+ * sequential fmaf chain from +0 in column order: results are bit-identical to tgcn_spmm_csr_f32 (rows cut by `plan` as there).
+ * Groups are handed to wavefronts in array order (after the plan's chunks): longest first shortens the launch's tail.
+ * Built on the host by textgcn_amd.graph.row_groups.  flags: bits 8..15 = row gathers in flight per wavefront (0: default). */
+int tgcn_spmm_groups_f32(const int32_t *rowptr, const int32_t *colidx, const float *vals, int64_t n_rows,
+                         const float *X, int64_t n_src_rows, int32_t d, float *Y, const float *acc_in,
+                         float *acc_out, float acc_div, const tgcn_split_plan_t *plan, const int32_t *groups,
+                         int64_t n_groups, uint32_t flags, tgcn_stream_t stream);
+
 /* XCD-affine segmented form of the same product (d in {64, 128, 256}).  The plan holds its own copy of the
  * entries of the segmented rows, as streams: stream x of a row range keeps the entries whose column falls in column
  * blocks x, x+8, ... ordered by (block, row, column).  A row's run inside one block is a segment; streams are cut
@@ -117,6 +130,11 @@ typedef struct tgcn_segment_plan {
     const int32_t *row_slots;    /* [n_slots] a row's pieces in column order */
     const int32_t *direct_rows;  /* [n_direct_rows] local row ids */
     float *workspace;            /* [n_slots, d] fp32 scratch */
+    const int32_t *direct_groups; /* ABI v9, optional: [n_direct_groups][2] = {first row, rows}: the direct rows as groups of
+                                   * consecutive rows (see tgcn_spmm_groups_f32), each direct row in exactly one group; used by
+                                   * the two-launch form instead of one wavefront per direct row.  Same bits. */
+    int32_t n_direct_groups;      /* 0: one wavefront per direct row */
+    int32_t _pad2;
 } tgcn_segment_plan_t;
 
 int tgcn_spmm_segmented_f32(const tgcn_segment_plan_t *plan, const int32_t *rowptr, const int32_t *colidx,
@@ -264,7 +282,10 @@ int tgcn_dropout_values_f32(const float *stored_vals, const float *stored_vals_t
  *   and their autograd backward: with gradient tables given, d loss / d users_emb, d items_emb are ADDED (float atomics)
  *   into grad_users / grad_items, which the caller zero-fills; every gradient is multiplied by grad_scale (the layer mean's
  *   1 / (K + 1), folded in) and by *upstream, a DEVICE scalar (autograd's d L / d loss; NULL = 1) -- no host round trip.
- * terms or the gradient pair may be NULL (values only / gradients only). */
+ * terms or the gradient pair may be NULL (values only / gradients only).
+ * A row with users[r] < 0 is PADDING (ABI v9): its terms are 0, it adds no gradient, its other ids are not read -- ragged per-user
+ * triple lists (advanced_sampling.py:61-69) can stay a dense [B x P x N] block on the device; the caller then divides by its own
+ * count of real rows (fold count_all / count_real into *upstream for the gradients).  Same rule in tgcn_reg_rows_f32. */
 int tgcn_bpr_pairs_f32(const float *users_emb, const float *items_emb, const int64_t *users, const int64_t *pos,
                        const int64_t *negs, int32_t b, int32_t m, int32_t d, float grad_scale, const float *upstream,
                        float *terms, float *grad_users, float *grad_items, tgcn_stream_t stream);

@@ -54,6 +54,8 @@ def main():
     ap.add_argument('--graph-seed', type=int, default=1)
     ap.add_argument('--shard', choices=['rows', 'features'], default='rows')
     ap.add_argument('--device-per-rank', action='store_true', help='--mode nccl on a multi-GPU box: rank r uses cuda:r')
+    ap.add_argument('--split-threshold', type=int, default=64)
+    ap.add_argument('--exact', action='store_true')
     args = ap.parse_args()
 
     from textgcn_amd import synth
@@ -88,9 +90,10 @@ def main():
                                collective=args.collective, force_collective=True)
         assert sp.backend == 'nccl' and sp.uses_collective and (sp._capi_comm is not None) == (args.collective == 'capi')
     else:
-        sp = ShardedPropagator(g, args.rank, args.world, 'cuda:0', split_threshold=64, balance=args.balance, chunks=args.chunks)
+        sp = ShardedPropagator(g, args.rank, args.world, 'cuda:0', split_threshold=args.split_threshold, balance=args.balance,
+                               chunks=args.chunks)
     eu, ei = sp.local_e0(e0)
-    users_local, items_full = sp.forward(eu, ei, args.layers, single=args.single, exact=(args.mode == 'cpu'))
+    users_local, items_full = sp.forward(eu, ei, args.layers, single=args.single, exact=(args.mode == 'cpu' or args.exact))
     if args.sample:      # large graphs: seeded sample rows of rank 0's own users and of the gathered item table
         rng = np.random.default_rng(123)
         u0, u1 = sp.user_range()
@@ -105,7 +108,8 @@ def main():
         users_full = sp.gather_users(users_local)
         if args.rank == 0:
             np.savez(args.out, users=users_full.cpu().numpy(), items=sp.items_in_order(items_full).cpu().numpy(),
-                     nnz_local=sp.nnz_local, user_bounds=sp.lay_u.bounds, item_bounds=sp.lay_i.bounds)
+                     nnz_local=sp.nnz_local, user_bounds=sp.lay_u.bounds, item_bounds=sp.lay_i.bounds,
+                     segment_note=np.array(sp.segment_note() if hasattr(sp, 'segment_note') else 'none'))
     sp.close()
     dist.barrier()
     dist.destroy_process_group()

@@ -65,8 +65,9 @@ def test_adv_loss_and_step(cuda):
     loss.backward()
     opt.step()
     assert not torch.equal(before, m.embedding_item.weight.detach())
-    pos = m.sample_positives(users)
-    assert pos.shape == (32, 5)
+    pos = m.sample_positives(torch.from_numpy(users).to(cuda))
+    assert pos.is_cuda and tuple(pos.shape) == (32, 5)
+    pos = pos.cpu().numpy()
     rp, items = m._mask_rowptr_host, m._mask_items_host
     for r, x in enumerate(users):
         mine = set(items[rp[x]:rp[x + 1]])
@@ -102,7 +103,7 @@ def test_adv_get_loss_matches_reference(golden, cuda):
         batch = torch.from_numpy(g['batch'])
         neg = m.hard_negatives(batch[:, 0].contiguous().to(cuda), batch[:, 1:].contiguous().to(cuda)).cpu().numpy()
         assert np.array_equal(neg, g['negatives'])
-        m.sample_positives = lambda users_np: g['positives']          # the reference's random.sample draws (not reproducible)
+        m.sample_positives = lambda users: torch.from_numpy(g['positives'])   # the reference's random.sample draws (not reproducible)
         m._loss_values = defaultdict(float)
         m.training = True
         loss = m.get_loss(batch)
@@ -112,3 +113,49 @@ def test_adv_get_loss_matches_reference(golden, cuda):
         assert abs(float(m._loss_values['reg']) - float(g['reg'])) <= 1e-5 * abs(float(g['reg']))
         assert normwise(m.embedding_user.weight.grad.cpu().numpy(), g['grad_user']) <= 1e-4
         assert normwise(m.embedding_item.weight.grad.cpu().numpy(), g['grad_item']) <= 1e-4
+
+
+def test_adv_get_loss_never_waits_for_the_gpu(golden, cuda):
+    """AdvSamplModel.get_loss + backward under torch's sync debug mode: the candidate ranking, the positives (drawn on the device
+    from the device mask CSR), the pairing and the padded triple block make no host synchronisation (advanced_sampling.py:55-69 is
+    a Python loop with a .to(device) per user).  And the device draw is a uniform sample without replacement: every train item of
+    a user comes up, never twice in a row of the result."""
+    from textgcn_amd.adv_sampling import AdvSamplModel
+    from textgcn_amd.graph import NormGraph
+    g2 = golden('g2_synth60')
+    n_u, n_i = int(g2['n_users']), int(g2['n_items'])
+    train = pd.DataFrame({'user_id': g2['train_u'], 'asin': g2['train_i']})
+    test = pd.DataFrame({'user_id': g2['test_u'], 'asin': g2['test_i']})
+    ds = types.SimpleNamespace(n_users=n_u, n_items=n_i, graph=NormGraph.from_pairs(g2['train_u'], g2['train_i'], n_u, n_i), norm_matrix=None,
+                               true_test_lil=test.groupby('user_id')['asin'].aggregate(list).values.tolist(),
+                               train_user_dict=train.groupby('user_id')['asin'].aggregate(list), test_df=test,
+                               user_mapping=pd.DataFrame({'remap_id': range(n_u), 'org_id': range(n_u)}),
+                               item_mapping=pd.DataFrame({'remap_id': range(n_i), 'org_id': range(n_i)}), pos_samples=3, seed=0)
+    p = types.SimpleNamespace(k=[5, 10], emb_size=64, n_layers=3, device='cuda:0', load=None, quiet=True, dropout=0.4)
+    m = AdvSamplModel(p, ds)
+    rng = np.random.default_rng(0)
+    batch = torch.from_numpy(np.stack([np.concatenate([[u], rng.choice(n_i, 30, replace=False)]) for u in rng.integers(0, n_u, 24)]))
+    m.training = True
+    m.get_loss(batch).backward()          # warm-up: buffers, plans, lazily built device copies
+    torch.cuda.synchronize()
+    batch_dev = batch.to(cuda)
+    m.zero_grad()
+    torch.cuda.set_sync_debug_mode('error')
+    try:
+        loss = m.get_loss(batch_dev)
+        loss.backward()
+    finally:
+        torch.cuda.set_sync_debug_mode('default')
+    assert torch.isfinite(loss) and torch.isfinite(m.embedding_item.weight.grad).all()
+    # distribution of the device draw
+    rp, items = m._mask_rowptr_host, m._mask_items_host
+    u = int(np.argmax(np.diff(rp) >= 6))
+    mine = items[rp[u]:rp[u + 1]]
+    draws = m.sample_positives(torch.full((4000,), u, device=cuda)).cpu().numpy()
+    assert all(len(set(r)) == 3 for r in draws) and set(draws.ravel()) == set(mine)
+    freq = np.array([(draws == it).sum() for it in mine]) / draws.size
+    assert np.abs(freq - 1.0 / len(mine)).max() < 0.25 / len(mine)
+    with pytest.raises(IndexError):
+        bad = batch.clone()
+        bad[0, 5] = n_i
+        m.get_loss(bad)

@@ -74,9 +74,17 @@ def test_rccl_multi_gpu_feature_partition(tmp_path):
     assert np.array_equal(bits(got['users']), bits(ref[:n_u])) and np.array_equal(bits(got['items']), bits(ref[n_u:]))
 
 
+def _check_alone(r, K=3):
+    lay = r['layers']
+    assert len(lay['spmm_alone_ms']) == K and len(lay['allgather_alone_ms']) == K
+    assert all(x > 0 for x in lay['spmm_alone_ms']) and all(x >= 0 for x in lay['allgather_alone_ms'])
+    assert lay['overlap_efficiency'] is not None and lay['overlap_efficiency'] > 0
+
+
 def test_bench_two_gpus_rccl(tmp_path):
-    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one GPU per rank, RCCL) on the small workload: one JSON
-    line whose config shows two ranks on two distinct devices and a per-layer compute / wait split."""
+    """`python bench.py --gpus 2` started PLAINLY (no torch.distributed.run: the form the driver's N = 1 command has -- bench.py
+    starts the two ranks itself as child processes), one GPU per rank, RCCL, on the small workload: one JSON line whose config shows
+    two ranks on two distinct devices, a per-layer compute / wait split and the two halves alone."""
     if _n_gpus() < 2:
         pytest.skip(f'needs 2 GPUs, {_n_gpus()} visible')
     import json
@@ -84,16 +92,15 @@ def test_bench_two_gpus_rccl(tmp_path):
     import subprocess
     import sys
     from conftest import ROOT
-    from test_dist_cpu import free_port
-    env = {k: v for k, v in os.environ.items() if k != 'TGCN_BENCH_REHEARSAL'}
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+    env = {k: v for k, v in os.environ.items() if k not in ('TGCN_BENCH_REHEARSAL', 'RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
            '--workload', 'small', '--score-batches', '1', '--no-cpu-baseline']
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     r = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
     assert r['n_gpus'] == 2 and r['scaling'] == 'strong' and r['config']['world_size'] == 2 and r['config']['distinct_devices'] == 2
     assert r['config']['backend'] == 'nccl' and len(r['layers']['max_over_ranks']) == 4
+    _check_alone(r)
 
 
 @pytest.mark.parametrize('world,balance,chunks', [(2, 'nnz', 1), (3, 'nnz', 2), (3, 'rows', 1)])
@@ -115,20 +122,57 @@ def test_sharded_hip_forward_equals_single_gpu(cuda, tmp_path, world, balance, c
     assert np.array_equal(bits(got['items']), bits(ref[n_u:]))
 
 
-def test_bench_two_rank_rehearsal(cuda, tmp_path):
+def test_sharded_chunks_use_the_segmented_kernels(cuda, tmp_path):
+    """A shard whose gather table is a few L2 sizes (here: 750 item rows per rank of ~2000 entries over a 15 MB user table) runs the
+    XCD-affine segmented kernels, by the rule a whole-graph Propagator uses.  Rows cut at column-block boundaries are summed
+    piecewise: the 2-rank result equals the one-GPU one-chain result to rounding (normwise 1e-5; bar 1e-4), is identical run to
+    run, and exact=True -- which ignores the plans -- stays bit-identical."""
+    from conftest import normwise
+    from textgcn_amd import synth
+    from textgcn_amd.graph import NormGraph
+    from textgcn_amd.propagate import Propagator
+    n_u, n_i, nnz, d, K = 60000, 1500, 3_000_000, 64, 3
+    args = ('--n-users', str(n_u), '--n-items', str(n_i), '--nnz', str(nnz), '--split-threshold', '8192')
+    u, i = synth.interactions(n_u, n_i, nnz, seed=1)
+    g = NormGraph.from_pairs(u, i, n_u, n_i)
+    e0 = synth.embeddings(g.n, d, seed=2).to(cuda)
+    ref = Propagator(g, cuda, split_threshold=None, segment=None).forward(e0, K, exact=True).cpu().numpy()
+    outs = []
+    for rep in range(2):
+        out = str(tmp_path / f'r{rep}.npz')
+        run_ranks(2, 'gpu', out, extra=args)
+        got = np.load(out)
+        assert 'row chunks on this rank' in str(got['segment_note']), got['segment_note']
+        assert normwise(got['users'], ref[:n_u]) <= 1e-5 and normwise(got['items'], ref[n_u:]) <= 1e-5
+        outs.append((got['users'], got['items']))
+    assert np.array_equal(bits(outs[0][0]), bits(outs[1][0])) and np.array_equal(bits(outs[0][1]), bits(outs[1][1]))
+    out = str(tmp_path / 'exact.npz')
+    run_ranks(2, 'gpu', out, extra=args + ('--exact',))
+    got = np.load(out)
+    assert np.array_equal(bits(got['users']), bits(ref[:n_u])) and np.array_equal(bits(got['items']), bits(ref[n_u:]))
+
+
+@pytest.mark.parametrize('launch', ['plain', 'torchrun'])
+def test_bench_two_rank_rehearsal(cuda, tmp_path, launch):
     """bench.py's N > 1 code path (sharded propagation, per-rank scoring, max-over-ranks timing, one JSON line from
-    rank 0) on the one-GPU box: two ranks on cuda:0 over gloo (TGCN_BENCH_REHEARSAL=1).  The driver's real runs use
-    RCCL with one GPU per rank; everything else is the same code."""
+    rank 0) on the one-GPU box: two ranks on cuda:0 over gloo (TGCN_BENCH_REHEARSAL=1).  `plain`: `python bench.py --gpus 2`
+    with no torch.distributed environment -- bench.py starts its ranks itself, as child processes; `torchrun`: as the driver
+    launches N > 1.  The driver's real runs use RCCL with one GPU per rank; everything else is the same code."""
     import json
     import os
     import subprocess
     import sys
     from conftest import ROOT
     from test_dist_cpu import free_port
-    env = dict(os.environ, TGCN_BENCH_REHEARSAL='1', OMP_NUM_THREADS='4')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
-           '--workload', 'small', '--score-batches', '1', '--no-cpu-baseline']
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'MASTER_ADDR')}
+    env.update(TGCN_BENCH_REHEARSAL='1', OMP_NUM_THREADS='4')
+    tail = [os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--workload', 'small', '--score-batches', '1',
+            '--no-cpu-baseline']
+    if launch == 'plain':
+        cmd = [sys.executable] + tail
+    else:
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+               '--master-port', str(free_port())] + tail
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
@@ -138,6 +182,7 @@ def test_bench_two_rank_rehearsal(cuda, tmp_path):
     # two ranks, ONE device (the rehearsal): the line says so
     assert r['config']['world_size'] == 2 and r['config']['backend'] == 'gloo' and r['config']['distinct_devices'] == 1
     assert len(r['layers']['rank0']) == 4
+    _check_alone(r)
 
 
 def test_bench_sharded_path_on_one_rank_rccl(cuda):
@@ -163,6 +208,7 @@ def test_bench_sharded_path_on_one_rank_rccl(cuda):
     lay = r['layers']['rank0']
     assert [x['layer'] for x in lay] == [1, 2, 3, 'final gather'] and all(x['compute_ms'] > 0 for x in lay[:3])
     assert all(x['wait_on_gather_ms'] >= 0 for x in lay)
+    _check_alone(r)
 
 
 @pytest.mark.parametrize('d,world', [(64, 2), (64, 4), (64, 8), (128, 4), (256, 8)])

@@ -98,3 +98,30 @@ def test_row_plans_replayed_on_the_host(oracle, seed):
                 part = np.float32(part + np.float64(gr.vals[e]) * np.float64(x[gr.colidx[e]])).astype(np.float64)
             total = (total + part.astype(np.float32)).astype(np.float32)
         assert np.abs(total - ref[r]).max() <= 1e-5 * max(np.abs(ref[r]).max(), 1e-6) + 1e-7
+
+
+def test_row_groups_cover_every_short_row_once():
+    """graph.row_groups (tgcn_spmm_groups_f32's work list): every covered row at or below the threshold lies in exactly one group
+    of 1..max_rows consecutive rows; cut rows and uncovered rows in none; longest-first order is a permutation of the same groups."""
+    from textgcn_amd.graph import row_groups
+    rng = np.random.default_rng(0)
+    for trial in range(300):
+        n = int(rng.integers(1, 300))
+        lens = rng.integers(0, rng.choice([2, 5, 40, 200, 3000]), size=n)
+        rp = np.concatenate([[0], np.cumsum(lens)])
+        thr = rng.choice([None, 64, 1024])
+        rows = None if rng.random() < 0.5 else np.sort(rng.choice(n, size=int(rng.integers(0, n + 1)), replace=False))
+        mr = int(rng.choice([4, 8]))
+        g = row_groups(rp, rows, thr, mr, 64)
+        cov = np.zeros(n, dtype=int)
+        for f, c in g:
+            assert 1 <= c <= mr
+            cov[f:f + c] += 1
+        exp = np.ones(n, dtype=bool) if rows is None else np.isin(np.arange(n), rows)
+        if thr is not None:
+            exp &= lens <= thr
+        assert np.array_equal(cov, exp.astype(int)), trial
+        gl = row_groups(rp, rows, thr, mr, 64, longest_first=True)
+        assert sorted(map(tuple, gl)) == sorted(map(tuple, g))
+        ent = rp[gl[:, 0] + gl[:, 1]] - rp[gl[:, 0]] if len(gl) else np.zeros(0)
+        assert np.all(np.diff(ent) <= 0)

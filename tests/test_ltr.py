@@ -247,3 +247,6 @@ def test_pairwise_features_kernel_and_its_gradient(golden, cuda, tmp_path):
         assert normwise(a, b) <= 1e-5
     with pytest.raises(IndexError):
         m.score_pairwise(torch.zeros(2, 64, device=cuda), torch.zeros(2, 64, device=cuda), torch.tensor([0, n_u]), torch.tensor([0, 1]))
+    with pytest.raises(IndexError):      # device ids outside a training epoch: the range flag is read at once (round-3 advice)
+        m.score_pairwise(torch.zeros(2, 64, device=cuda), torch.zeros(2, 64, device=cuda), torch.tensor([0, 1], device=cuda),
+                         torch.tensor([0, -1], device=cuda))

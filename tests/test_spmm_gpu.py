@@ -307,3 +307,61 @@ def test_segmented_xcd_affine_kernel(cuda, oracle, d, blocks, tile, min_len):
     full = prop.forward(e0d, 3, segmented=True).cpu().numpy()
     exact = prop.forward(e0d, 3, exact=True).cpu().numpy()
     assert normwise(full, exact) <= 5e-6
+
+
+@pytest.mark.parametrize('d', [64, 128, 256])
+@pytest.mark.parametrize('unroll', [0, 8, 16, 32])
+def test_row_groups_bit_identical_to_one_wave_per_row(cuda, oracle, d, unroll):
+    """tgcn_spmm_groups_f32 (round 4): consecutive rows share a wave.  Rows without entries at the start, middle and end of a
+    group, runs of one-entry rows (eight rows per group), rows of exactly 63 / 64 / 65 / 128 entries (slab boundaries), a row
+    that ends on a slab's last entry, long rows beside short ones, with and without the split plan: the same bits as the
+    one-wave-per-row kernel and the oracle, for Y, the fused epilogue and the in-place form."""
+    from textgcn_amd import _capi
+    from textgcn_amd.propagate import DeviceCSR, spmm
+    rng = np.random.default_rng(1000 + d + unroll)
+    n_src = 900
+    lens = np.concatenate([
+        [0, 0, 0, 5, 0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 63, 1, 64, 65, 0, 128, 3, 61, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 7],
+        rng.integers(0, 4, 300), rng.integers(0, 40, 200), [700, 2, 0, 1500, 1, 1], rng.integers(0, 130, 150), [0, 0, 0]])
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    cols = np.concatenate([np.sort(rng.choice(n_src, size=min(l, n_src), replace=False)) if l <= n_src else
+                           np.sort(rng.integers(0, n_src, l)) for l in lens]).astype(np.int32)
+    vals = rng.standard_normal(len(cols)).astype(np.float32)
+    n = len(lens)
+    x = rng.standard_normal((n_src, d)).astype(np.float32)
+    idx = np.stack([np.repeat(np.arange(n), lens), cols.astype(np.int64)])
+    # (the oracle's COO product wants a square shape: pad)
+    size = max(n, n_src)
+    xp = np.zeros((size, d), dtype=np.float32)
+    xp[:n_src] = x
+    ref = oracle.spmm_coo(idx, vals, xp)[:n]
+    xd = torch.from_numpy(x).to(cuda)
+    acc_in = rng.standard_normal((n, d)).astype(np.float32)
+    for thr in (None, 256):
+        csr = DeviceCSR(rowptr, cols, vals, n_src, cuda, split_threshold=thr)
+        grp = csr.groups(d, exact=thr is None)
+        assert grp is not None and grp[1] > 0
+        g = grp[0].cpu().numpy()[:grp[1]]
+        assert g[:, 1].max() == (4 if d == 256 else 8)
+        exact = thr is None
+        y = torch.full((n, d), float('nan'), device=cuda)
+        spmm(csr, xd, y=y, exact=exact, unroll=unroll)
+        y1 = torch.full((n, d), float('nan'), device=cuda)
+        spmm(csr, xd, y=y1, exact=exact, variant=_capi.SPMM_WAVE_PER_ROW)
+        assert torch.equal(y.view(torch.int32), y1.view(torch.int32)), thr
+        short = lens <= (thr or (1 << 30))
+        assert np.array_equal(bits(y.cpu().numpy()[short]), bits(ref[short])), thr
+        if thr is not None:
+            assert normwise(y.cpu().numpy(), ref) <= 1e-5
+        acc = torch.from_numpy(acc_in).to(cuda)
+        out = torch.empty_like(acc)
+        spmm(csr, xd, y=None, acc_in=acc, acc_out=out, acc_div=4.0, exact=exact, unroll=unroll)
+        out1 = torch.empty_like(acc)
+        spmm(csr, xd, y=None, acc_in=acc, acc_out=out1, acc_div=4.0, exact=exact, variant=_capi.SPMM_WAVE_PER_ROW)
+        assert torch.equal(out.view(torch.int32), out1.view(torch.int32)), thr
+        want = ((acc_in + ref) / np.float32(4.0)).astype(np.float32)
+        assert np.array_equal(bits(out.cpu().numpy()[short]), bits(want[short])), thr
+        y2 = torch.empty_like(y)
+        spmm(csr, xd, y=y2, acc_in=acc, acc_out=acc, acc_div=1.0, exact=exact, unroll=unroll)     # in place + Y
+        assert torch.equal(y2.view(torch.int32), y.view(torch.int32))
+        assert np.array_equal(bits(acc.cpu().numpy()[short]), bits((acc_in + ref).astype(np.float32)[short])), thr

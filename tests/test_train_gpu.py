@@ -181,6 +181,8 @@ def test_get_loss_rejects_ids_outside_the_tables(golden, cuda):
         m.get_loss(bad.float())
     with pytest.raises(ValueError):
         m.get_loss(bad[:, :2])
+    with pytest.raises(IndexError):          # a DEVICE batch outside fit(): nobody would read the flag later, so it is read here
+        m.get_loss(bad.to(cuda))
     m.optimizer = torch.optim.Adam(m.parameters(), lr=1e-3)
     with pytest.raises(IndexError):
         m._train_epoch([bad.to(cuda)], 1)

@@ -8,7 +8,7 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int32, c_int64, c_ui
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, '_lib', 'libtgcn.so')
 
-TGCN_ABI_VERSION = 8
+TGCN_ABI_VERSION = 9
 TGCN_COMM_ID_BYTES = 128
 SPMM_AUTO, SPMM_WAVE_PER_ROW = 0, 1
 
@@ -25,7 +25,8 @@ class SegmentPlanStruct(Structure):
     _fields_ = [('n_tiles', c_int32), ('tile_entries', c_int32), ('n_seg_rows', c_int32), ('n_direct_rows', c_int32),
                 ('n_slots', c_int32), ('_pad', c_int32), ('tile_meta', c_void_p), ('ent_col', c_void_p),
                 ('ent_val', c_void_p), ('ent_flags', c_void_p), ('seg_rows', c_void_p), ('row_slot_ptr', c_void_p), ('row_slots', c_void_p),
-                ('direct_rows', c_void_p), ('workspace', c_void_p)]
+                ('direct_rows', c_void_p), ('workspace', c_void_p), ('direct_groups', c_void_p), ('n_direct_groups', c_int32),
+                ('_pad2', c_int32)]
 
 
 _SIGNATURES = {
@@ -33,6 +34,8 @@ _SIGNATURES = {
     'tgcn_last_error': (c_char_p, []),
     'tgcn_spmm_csr_f32': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p,
                                          c_void_p, c_void_p, c_float, POINTER(SplitPlanStruct), c_void_p, c_uint32, c_void_p]),
+    'tgcn_spmm_groups_f32': (ctypes.c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p,
+                                            c_void_p, c_void_p, c_float, POINTER(SplitPlanStruct), c_void_p, c_int64, c_uint32, c_void_p]),
     'tgcn_spmm_segmented_f32': (ctypes.c_int, [POINTER(SegmentPlanStruct), c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
                                                c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_float, c_uint32, c_void_p]),
     'tgcn_score_dense_f32': (ctypes.c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_int64,
@@ -120,3 +123,17 @@ def ptr(t):
 def current_stream(device):
     import torch
     return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+_RAW_STREAM = None
+
+
+def raw_stream(device):
+    """the current HIP stream of `device` as a plain integer (what a c_void_p parameter takes): torch's raw-stream getter where
+    this build has it (one C call, no Stream object), else the public way"""
+    global _RAW_STREAM
+    if _RAW_STREAM is None:
+        import torch
+        get = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+        _RAW_STREAM = get if get is not None else (lambda idx: torch.cuda.current_stream(idx).cuda_stream)
+    return _RAW_STREAM(device.index)

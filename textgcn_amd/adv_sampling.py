@@ -5,7 +5,8 @@ items; the model ranks the candidates with the current embeddings, keeps the `ma
 negatives and pairs them with up to `pos_samples` random positives of the user; the BPR loss of LightGCN is then
 taken over all (user, positive, negative) triples.  The reference does this with a batched matmul and a Python loop
 per user (advanced_sampling.py:55-69); here the candidate scores and the positives filter are one kernel
-(tgcn_score_candidates_f32), the selection is tgcn_topk_f32, and the pairing is tensor indexing.
+(tgcn_score_candidates_f32), the selection is tgcn_topk_f32, the positives are drawn on the device from the device mask CSR and
+the pairing is tensor arithmetic: get_loss never waits for the GPU.
 """
 import numpy as np
 import torch
@@ -34,7 +35,6 @@ class AdvSamplModel(LightGCN):
     def _copy_dataset_params(self, dataset):
         super()._copy_dataset_params(dataset)
         self.pos_samples = getattr(dataset, 'pos_samples', 5)
-        self._pos_rng = np.random.default_rng(getattr(dataset, 'seed', 0))
 
     @torch.no_grad()
     def hard_negatives(self, users, cand):
@@ -54,31 +54,63 @@ class AdvSamplModel(LightGCN):
                                    torch.from_numpy(self._mask_items_host).to(self.device))
         return self._mask_full_dev
 
-    def sample_positives(self, users_np):
-        """up to pos_samples distinct random train items per user (advanced_sampling.py:62-63): [B, pos_samples], -1 padded"""
-        rp, it = self._mask_rowptr_host, self._mask_items_host
-        out = np.full((len(users_np), self.pos_samples), -1, dtype=np.int64)
-        cnt = rp[users_np + 1] - rp[users_np]
-        rows = np.repeat(np.arange(len(users_np)), cnt)
-        flat = np.concatenate([it[rp[u]:rp[u + 1]] for u in users_np]) if len(users_np) else it[:0]
-        order = np.lexsort((self._pos_rng.random(len(flat)), rows))       # random order inside each user
-        rows, flat = rows[order], flat[order]
-        start = np.concatenate([[0], np.cumsum(cnt)[:-1]])
-        rank = np.arange(len(flat)) - start[rows]
-        keep = rank < self.pos_samples
-        out[rows[keep], rank[keep]] = flat[keep]
-        return out
+    def sample_positives(self, users):
+        """Up to pos_samples DISTINCT random train items per user (advanced_sampling.py:62-63, `random.sample`): int64
+        [B, pos_samples] on the device, -1 padded.  Drawn on the device from the device mask CSR with torch's device generator:
+        draw j picks uniformly among the cnt - j items not yet taken (an index into the remaining set, shifted past the
+        earlier picks in ascending order) -- a uniform sample without replacement, no host round trip, no per-user loop."""
+        rp, it = self._mask_full()
+        u = torch.as_tensor(users).to(self.device, torch.int64)
+        start = rp[u].to(torch.int64)
+        cnt = rp[u + 1].to(torch.int64) - start
+        p = self.pos_samples
+        rnd = torch.rand((u.numel(), p), device=self.device, dtype=torch.float64)
+        picks = []
+        for j in range(p):
+            span = (cnt - j).clamp(min=1)
+            x = torch.minimum((rnd[:, j] * span).to(torch.int64), span - 1)
+            if picks:
+                prev = torch.sort(torch.stack(picks, dim=1), dim=1)[0]
+                for c in range(j):
+                    x = x + (x >= prev[:, c]).to(torch.int64)
+            picks.append(x)
+        idx = torch.stack(picks, dim=1)
+        valid = torch.arange(p, device=self.device)[None, :] < cnt[:, None]
+        flat = (start[:, None] + idx).clamp(max=max(it.numel() - 1, 0))
+        return torch.where(valid, it[flat].to(torch.int64), torch.full_like(idx, -1))
 
     def get_loss(self, data):
-        """data: [B, 1 + m] rows (user, candidates...) -> BPR + L2 over positives x hard negatives (advanced_sampling.py:46-69)."""
-        data = data.to(self.device)
+        """data: [B, 1 + m] rows (user, candidates...) -> BPR + L2 over positives x hard negatives (advanced_sampling.py:46-69).
+        Nothing in here waits for the GPU: the candidate ranking, the positives and the pairing are device work, and the ragged
+        per-user triple lists stay one dense [B x P x N] block whose empty places are padding rows the loss kernels skip
+        (tgcn_bpr_pairs_f32: users[r] < 0), the means running over a device-side count of the real triples."""
+        data = torch.as_tensor(data)
+        if data.dim() != 2 or data.shape[1] < 2 or data.dtype.is_floating_point or data.dtype == torch.bool:
+            raise TypeError('get_loss expects integer rows [user, candidate items...]')
+        if data.device.type == 'cpu' and data.numel():     # what a DataLoader yields: range-checked before any kernel reads an id
+            if int(data[:, 0].min()) < 0 or int(data[:, 0].max()) >= self.n_users or int(data[:, 1:].min()) < 0 \
+                    or int(data[:, 1:].max()) >= self.n_items:
+                raise IndexError('get_loss: a user or candidate id of the batch is outside its embedding table')
+        data = data.to(self.device, torch.int64)
         users, cand = data[:, 0].contiguous(), data[:, 1:].contiguous()
-        neg = self.hard_negatives(users, cand)                                   # [B, kmax]
-        pos = torch.from_numpy(self.sample_positives(users.cpu().numpy())).to(self.device)   # [B, P]
+        neg = self.hard_negatives(users, cand)                                   # [B, kmax], -1 padded
+        pos = torch.as_tensor(self.sample_positives(users)).to(self.device, torch.int64)     # [B, P], -1 padded
         b, p, n = users.numel(), pos.shape[1], neg.shape[1]
         uu = users[:, None, None].expand(b, p, n)
         pp = pos[:, :, None].expand(b, p, n)
         nn_ = neg[:, None, :].expand(b, p, n)
         ok = (pp >= 0) & (nn_ >= 0)
-        triples = torch.stack([uu[ok], pp[ok], nn_[ok]], dim=1)                # cartesian product per user
+        if self._native_loss():
+            from collections import defaultdict
+            from .model import _BprStep
+            if not hasattr(self, '_loss_values'):
+                self._loss_values = defaultdict(float)
+            zero = torch.zeros((), dtype=torch.int64, device=self.device)
+            cols = torch.stack([torch.where(ok, uu, zero - 1).reshape(-1), torch.where(ok, pp, zero).reshape(-1),
+                                torch.where(ok, nn_, zero).reshape(-1)])           # [3, B P N]: padding rows carry user -1
+            bpr, reg = _BprStep.apply(self.embedding_user.weight, self.embedding_item.weight, self, cols.contiguous(), ok.sum())
+            self._loss_values['bpr'] += bpr.detach()
+            self._loss_values['reg'] += reg.detach()
+            return bpr + reg
+        triples = torch.stack([uu[ok], pp[ok], nn_[ok]], dim=1)                # cartesian product per user (generic path: syncs)
         return super().get_loss(triples)

@@ -40,14 +40,7 @@ constexpr int kUsersPerWG = 128;   // 4 waves x 32 users
 constexpr int kStage = 64;         // items per LDS stage (2 MFMA sub-tiles of 32)
 constexpr int kSmallI = 8192;      // below this the dense path (score -> mask -> top-k) is used
 
-#ifdef TGCN_FILTER_PROBE
-// diagnostic build only (tools/filter_probe.py compiles its own copy with -DTGCN_FILTER_PROBE; never in libtgcn.so): per
-// workgroup, shader-clock stamps around the phases of the filter kernel.  The values go to a buffer nothing else reads.
-__device__ unsigned long long g_probe[4 * 16384];
-#define TGCN_PROBE(slot) do { if (threadIdx.x == 0) g_probe[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) % 16384 * 4 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
 #define TGCN_PROBE(slot) do { } while (0)
-#endif
 
 struct FilterArgs {
     const float *__restrict__ U;
@@ -368,24 +361,20 @@ __device__ __forceinline__ void filter_pipelined(const FilterArgs &a)
                 const int t0 = (g * QB + q) * 2;  // 2*DQ test slots per unit; one of every kSlotsPerReg is used
                 c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[g & 1][q].x, b2.x, c0, 0, 0, 0);
                 c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[g & 1][q].x, b2.x, c1, 0, 0, 0);
-#if !defined(TGCN_FILTER_PROBE) || TGCN_FILTER_PROBE != 2      // probe build 2: the GEMM loop without its tests
                 if constexpr (PREV) {
                     if (t0 % kSlotsPerReg == 0) {  // folded: the loops are fully unrolled
                         const int reg = t0 / kSlotsPerReg, r = reg & 15;
                         test(reg < 16 ? p0[r] : p1[r], s_prev + (reg < 16 ? 0 : 32) + (r & 3) + 8 * (r >> 2) + 4 * h);
                     }
                 }
-#endif
                 c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[g & 1][q].y, b2.y, c0, 0, 0, 0);
                 c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[g & 1][q].y, b2.y, c1, 0, 0, 0);
-#if !defined(TGCN_FILTER_PROBE) || TGCN_FILTER_PROBE != 2
                 if constexpr (PREV) {
                     if ((t0 + 1) % kSlotsPerReg == 0) {
                         const int reg = (t0 + 1) / kSlotsPerReg, r = reg & 15;
                         test(reg < 16 ? p0[r] : p1[r], s_prev + (reg < 16 ? 0 : 32) + (r & 3) + 8 * (r >> 2) + 4 * h);
                     }
                 }
-#endif
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -437,11 +426,6 @@ __device__ __forceinline__ void filter_pipelined(const FilterArgs &a)
         unit(T{}, T{}, EvenLast{}, A0, A1, B0, B1, s_prev, s0, 0);
     }
     TGCN_PROBE(2);
-#ifdef TGCN_FILTER_PROBE
-    if (threadIdx.x == 0)   // where it ran: HW_ID (cu / sh / se) and the XCC id
-        g_probe[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) % 16384 * 4 + 3] =
-            ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
-#endif
     if (user_ok)
         a.counts[((size_t)user * a.S + split) * 2 + h] = cnt;
 }
@@ -590,41 +574,6 @@ __global__ __launch_bounds__(256) void k_tau(const float *__restrict__ Ss, int m
 // insertion chain); (4) the k winners ((value desc, item asc); ties at the k-th value are taken by ascending item) are packed
 // into lanes 0..k-1 and sorted by a 64-lane bitonic network.  A user with fewer than k unmasked candidates, an overflowed
 // log or more than kSelCap candidates is flagged for the exact fallback.
-constexpr int kSelCap = 1024;          // candidates per user held in LDS (8 KB per wave)
-constexpr int kSelVPL = kSelCap / kWave;
-
-__device__ __forceinline__ unsigned ordered_key(float v)
-{
-    const unsigned u = __float_as_uint(v);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-
-// bitonic sort of one (value, item) pair per lane, best first: (value desc, item asc)
-__device__ __forceinline__ void wave_sort_desc(float &v, int &i, int lane)
-{
-#pragma unroll
-    for (int size = 2; size <= kWave; size <<= 1) {
-#pragma unroll
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            const float ov = __shfl_xor(v, stride);
-            const int oi = __shfl_xor(i, stride);
-            const bool lower = (lane & stride) == 0;
-            const bool first_half = (lane & size) == 0;       // this block sorts best-first; the other half worst-first
-            const bool keep_better = lower == first_half;
-            const bool other_better = better(ov, oi, v, i);
-            if (other_better == keep_better) {
-                v = ov;
-                i = oi;
-            }
-        }
-    }
-}
-
-// the k best of VPL (key, index) pairs per lane (key 0 = dropped / padding), sorted into lanes 0..k-1
-template <int VPL>
-__device__ __forceinline__ void select_core(const unsigned (&key)[VPL], const int (&idx)[VPL], int k, int lane, float &out_v,
-                                            int &out_i, float2 *__restrict__ pack);
-
 template <int VPL>
 __device__ __forceinline__ void select_from_lds(const float2 *__restrict__ cand, int n, int k, int lane, float &out_v, int &out_i,
                                                 float2 *__restrict__ pack)
@@ -639,72 +588,6 @@ __device__ __forceinline__ void select_from_lds(const float2 *__restrict__ cand,
         key[s] = idx[s] == INT_MAX ? 0u : ordered_key(t.x);      // dropped / padding: below every real score (key >= 1)
     }
     select_core<VPL>(key, idx, k, lane, out_v, out_i, pack);
-}
-
-template <int VPL>
-__device__ __forceinline__ void select_core(const unsigned (&key)[VPL], const int (&idx)[VPL], int k, int lane, float &out_v,
-                                            int &out_i, float2 *__restrict__ pack)
-{
-    // T = k-th largest key: the largest T with |{key >= T}| >= k
-    unsigned T = 0;
-    for (int bit = 31; bit >= 0; --bit) {
-        const unsigned c = T | (1u << bit);
-        int cnt = 0;
-#pragma unroll
-        for (int s = 0; s < VPL; ++s)
-            cnt += __popcll(__ballot(key[s] >= c));
-        if (cnt >= k)
-            T = c;
-    }
-    int above = 0;
-#pragma unroll
-    for (int s = 0; s < VPL; ++s)
-        above += __popcll(__ballot(key[s] > T));
-    // ties at T: the k - above smallest item ids among them.  I = the (k - above)-th smallest tied id (same search, on ids)
-    const int need = k - above;
-    unsigned I = 0xFFFFFFFFu;   // take every tie unless there are more than needed
-    int ties = 0;
-#pragma unroll
-    for (int s = 0; s < VPL; ++s)
-        ties += __popcll(__ballot(key[s] == T));
-    if (ties > need) {
-        // largest J with |{tied, ~id >= J}| >= need  <=>  smallest ids first (ids are non-negative: ~id order reverses them)
-        unsigned J = 0;
-        for (int bit = 31; bit >= 0; --bit) {
-            const unsigned c = J | (1u << bit);
-            int cnt = 0;
-#pragma unroll
-            for (int s = 0; s < VPL; ++s)
-                cnt += __popcll(__ballot(key[s] == T && ~(unsigned)idx[s] >= c));
-            if (cnt >= need)
-                J = c;
-        }
-        I = ~J;   // ids <= I are taken
-    }
-    // pack the k winners into LDS slots 0..k-1 (any order), then one per lane
-    int base = 0;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-#pragma unroll
-    for (int s = 0; s < VPL; ++s) {
-        const bool take = key[s] > T || (key[s] == T && (unsigned)idx[s] <= I);
-        const unsigned long long m = __ballot(take);
-        if (take)
-            pack[base + __popcll(m & lt)] = make_float2(__uint_as_float(key[s]), __int_as_float(idx[s]));
-        base += __popcll(m);
-    }
-    __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0): this wave's LDS writes before its reads
-    __builtin_amdgcn_wave_barrier();
-    float v = -INFINITY;
-    int i = INT_MAX;
-    if (lane < k) {
-        const float2 t = pack[lane];
-        const unsigned kk = __float_as_uint(t.x);
-        v = __uint_as_float((kk & 0x80000000u) ? (kk & 0x7FFFFFFFu) : ~kk);   // inverse of ordered_key
-        i = __float_as_int(t.y);
-    }
-    wave_sort_desc(v, i, lane);
-    out_v = v;
-    out_i = i;
 }
 
 // ---- a second, tight threshold from the LOGGED approximate scores (wide rows: tgcn_score_prefilter.hip logs them) ----------
@@ -1381,12 +1264,6 @@ int launch_filter(const FilterArgs &a, hipStream_t s)
 
 using namespace tgcn;
 
-#ifdef TGCN_FILTER_PROBE
-extern "C" int tgcn_probe_read(void *host, int64_t bytes)
-{
-    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_probe), (size_t)bytes) == hipSuccess ? 0 : -2;
-}
-#endif
 
 extern "C" int64_t tgcn_score_topk_workspace_bytes(int32_t B, int32_t I, int32_t d, int32_t k)
 {
@@ -1493,6 +1370,7 @@ int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const fl
     fa.logs = reinterpret_cast<float2 *>(ws + p.off_logs);
     fa.counts = reinterpret_cast<int *>(ws + p.off_counts);
     fa.B = B, fa.I = I, fa.d = d, fa.S = p.S, fa.items_per_split = p.items_per_split, fa.cap2 = p.cap2;
+    bool selected = false;
     if (prefilter) {   // pass bits from the bf16 GEMM, then candidates -> fp32 chains -> flat (score, item) lists
         unsigned *mask = reinterpret_cast<unsigned *>(ws + p.off_mask);
         if (tau_stride != 1 && (rc = launch_user_bound(U, user_ids, B, d, ubound, s)) != TGCN_OK)
@@ -1536,7 +1414,10 @@ int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const fl
         if ((rc = launch_prefilter(U, user_ids, B, ipack, I, d, tau_ptr, tau_stride, ubound, mask, p.Wh, (I + ips_pre - 1) / ips_pre,
                                    ips_pre, wide, s)) != TGCN_OK)
             return rc;
-        rc = launch_rescore(U, user_ids, B, It, d, tau_ptr, tau_stride, mask, p.Wh, (I + kStage - 1) / kStage, fa.logs, totals, p.S * 2 * p.cap2, s);
+        // the fp32 chains and the exact selection in ONE launch: the kept pairs never leave the wave's LDS (round 4)
+        rc = launch_rescore_select(U, user_ids, B, It, d, tau_ptr, tau_stride, mask, p.Wh, (I + kStage - 1) / kStage, totals, mask_rowptr,
+                                   mask_items, k, round4, out_val, out_idx, flagged, s);
+        selected = true;
         }
     } else if (d <= 128) {
         const dim3 grid((B + kUsersPerWG - 1) / kUsersPerWG, p.S);
@@ -1563,7 +1444,9 @@ int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const fl
     // 3. exact selection from the logs; 4. exact rescoring of flagged users
     SelectArgs sa{fa.logs, fa.counts, mask_rowptr, mask_items, out_val, out_idx, flagged, B, p.S, p.cap2, k, round4, totals,
                   (prefilter && d > 128 ? p.n_seg : 2 * p.S) * p.cap2};
-    if (sa.totals)
+    if (selected)
+        ;      // (narrow prefiltered rows: k_rescore selected already)
+    else if (sa.totals)
         hipLaunchKernelGGL(k_select_flat, dim3((B + 3) / 4), dim3(256), 0, s, sa);
     else
         hipLaunchKernelGGL(k_select, dim3((B + 3) / 4), dim3(256), 0, s, sa);

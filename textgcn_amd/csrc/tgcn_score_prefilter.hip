@@ -225,6 +225,48 @@ __device__ __forceinline__ void wait_vmcnt()
 // address (it cannot tell the ring's buffers apart), i.e. right behind the request -- no prefetch left.  Hidden from that pass,
 // the requests are ordered by hand (wait_vmcnt<N> + the stage barrier).  An uncounted VMEM operation can only make a
 // compiler-placed vmcnt wait longer, never shorter: returns are in issue order.
+// THE INVARIANT OF THE COUNTED WAITS (both filters).  A wave issues PIECES requests per stage, LEAD stages ahead of the stage that
+// multiplies them; at the end of stage s the pieces of stage s + 1 must be in LDS.  s_waitcnt vmcnt(N) returns once at most N
+// of the wave's vector-memory operations are outstanding, and loads -- LDS-DMA requests are loads -- complete in issue order
+// AMONG THEMSELVES (gfx9: one counter for loads and stores; nothing is assumed about stores against loads).  If a piece of
+// stage s + 1 were still outstanding, every request issued after it would be too: the (LEAD - 1) x PIECES requests of stages
+// s + 2 .. s + LEAD -- that alone is more than N = (LEAD - 1) x PIECES.  So the wait covers the awaited pieces WHEREVER the
+// stage's stores (pass words, log appends, compiler spills) sit among the requests and however they retire: an outstanding store
+// only uses up allowance, it makes the wait stricter, never laxer.  What must hold is
+//     N  <=  number of this wave's REQUESTS that are younger than the awaited pieces
+// and kAllowed below IS that number, derived from the same two constants the request sites use (tools/check_dma.py builds the
+// library with -DTGCN_CHECK_DMA: every awaited piece is then compared with its source bytes before the stage is multiplied).
+template <int PIECES, int LEAD>
+struct DmaRingWait {
+    static_assert(LEAD >= 1 && PIECES >= 1, "ring shape");
+    static constexpr int kYoungerRequests = (LEAD - 1) * PIECES;   // requests of stages s + 2 .. s + LEAD, all issued after stage s + 1's
+    static constexpr int kAllowed = kYoungerRequests;
+    static_assert(kAllowed < 64, "vmcnt is a 6-bit field");
+    __device__ static __forceinline__ void wait() { wait_vmcnt<kAllowed>(); }
+};
+
+#ifdef TGCN_CHECK_DMA
+// Checked build only (never in libtgcn.so; tools/check_dma.py): counts the 16-byte pieces a consumer found stale.  Before a ring
+// buffer is requested into, the requesting lanes overwrite their pieces' places with a poison pattern (and wait for those LDS
+// writes), so the previous stage's bytes can never pass for the new ones; after the counted wait, before the stage barrier, every
+// lane compares its pieces of the awaited stage with their source bytes, read again by an ordinary load.
+__device__ unsigned long long g_dma_stale_pieces;
+__device__ unsigned long long g_dma_checked_pieces;
+__device__ __forceinline__ void dma_poison(unsigned lds_addr)
+{
+    const u32x4 poison = {0xDEADBEEFu, 0xDEADBEEFu, 0xDEADBEEFu, 0xDEADBEEFu};
+    *reinterpret_cast<__attribute__((address_space(3))) u32x4 *>(lds_addr) = poison;
+}
+__device__ __forceinline__ void dma_verify(const void *src, unsigned lds_addr)
+{
+    const u32x4 want = *reinterpret_cast<const u32x4 *>(src);
+    const u32x4 got = *reinterpret_cast<const __attribute__((address_space(3))) u32x4 *>(lds_addr);
+    atomicAdd(&g_dma_checked_pieces, 1ull);
+    if (want.x != got.x || want.y != got.y || want.z != got.z || want.w != got.w)
+        atomicAdd(&g_dma_stale_pieces, 1ull);
+}
+#endif
+
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"      // "clobber list contains reserved registers: m0" -- it is written here
 __device__ __forceinline__ void lds_dma16(const void *src, unsigned lds_base)
@@ -232,21 +274,6 @@ __device__ __forceinline__ void lds_dma16(const void *src, unsigned lds_base)
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_base), "v"(src) : "memory", "m0");
 }
 #pragma clang diagnostic pop
-
-// development switches of the narrow filter (tools/wide_ablate.py builds private copies with one ingredient of the loop compiled
-// out to price it; the shipped library has all of them on)
-#ifndef TGCN_PRE_TESTS
-#define TGCN_PRE_TESTS 1       // 0: no threshold tests (the pass words stay 0)
-#endif
-#ifndef TGCN_PRE_STAGE
-#define TGCN_PRE_STAGE 1       // 0: no stage requests / LDS stores inside the loop (the first stage is multiplied over and over)
-#endif
-#ifndef TGCN_PRE_LDSREAD
-#define TGCN_PRE_LDSREAD 1     // 0: the item fragments are read once per launch
-#endif
-#ifndef TGCN_PRE_MFMA
-#define TGCN_PRE_MFMA 1        // 0: no MFMAs
-#endif
 
 // ---- the bf16 filter ------------------------------------------------------------------------------------------------------
 struct PreArgs {
@@ -348,14 +375,32 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
     // stage and every wave has passed that stage's barrier.  Issued at the stage's start, waited for at its end (vmcnt(0) + barrier).
     // With the rows staged through registers the stage traffic cost a quarter of the launch (tools/wide_ablate.py pre_nostage: 155 ->
     // 116 us at 16 384 users).
+    constexpr int kLead = 2;      // stages between a request and the stage that multiplies it (the ring has kLead + 1 buffers)
+    using RingWait = DmaRingWait<NP, kLead>;
     auto dma_stage = [&](int nb, int row0) {
         const size_t base = (size_t)row0 * RB;
         const unsigned lds0 = (unsigned)(uintptr_t)(smem + nb * SB);
+#ifdef TGCN_CHECK_DMA
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+            dma_poison(lds0 + (unsigned)(i * T + (int)threadIdx.x) * 16u);
+        __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): the poison is in LDS before the first request is issued
+#endif
 #pragma unroll
         for (int i = 0; i < NP; ++i)
             lds_dma16(a.ipack + min(base + (size_t)(i * T + (int)threadIdx.x) * 16, a.pack_bytes - 16),
                       uniform((int)(lds0 + (unsigned)(i * T + w * kWave) * 16u)));
     };
+#ifdef TGCN_CHECK_DMA
+    auto verify_stage = [&](int nb, int row0) {      // this lane's pieces of the stage in ring buffer nb against their source bytes
+        const size_t base = (size_t)row0 * RB;
+        const unsigned lds0 = (unsigned)(uintptr_t)(smem + nb * SB);
+#pragma unroll
+        for (int i = 0; i < NP; ++i)
+            dma_verify(a.ipack + min(base + (size_t)(i * T + (int)threadIdx.x) * 16, a.pack_bytes - 16),
+                       lds0 + (unsigned)(i * T + (int)threadIdx.x) * 16u);
+    };
+#endif
     auto store_stage = [&](unsigned char *dst, const u32x4 (&v)[NP]) {
 #pragma unroll
         for (int i = 0; i < NP; ++i)
@@ -392,9 +437,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
     if (i_beg >= i_end)
         return;
     store_stage(smem, nxt);
-#if TGCN_PRE_STAGE
     dma_stage(1, i_beg + ST);      // (the user tile is out of the buffers: its fragments are in registers)
-#endif
     __syncthreads();
     // tau has arrived before the loop: a first use inside it makes hipcc's wait-count pass put s_waitcnt vmcnt(0) in front of
     // EVERY test (the loop-carried state merges the pending tau load with the stage prefetch), which serialises the prefetch
@@ -439,10 +482,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
             store_words(mrow + ((t >> 6) - (UPS - 1)));
         }
     };
-#if !TGCN_PRE_LDSREAD
-    bf16x8 abl_fa0[KS + 1], abl_fa1[KS + 1];
-    bool abl_loaded = false;
-#endif
     auto unit = [&](auto prev_tag, int t0, int un, f32x16 &c0, f32x16 &c1, const f32x16 &q0, const f32x16 &q1, int t_prev) {
         constexpr bool PREV = decltype(prev_tag)::value;
         constexpr int STEPS = KS + 1;                  // k-steps incl. the bound's
@@ -453,25 +492,17 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
             c0[r] = 0.0f, c1[r] = 0.0f;
         // all operand fragments of the unit are requested first (their LDS latency is paid once per unit, under the first tests,
         // not once per k-step), then per k-step: the previous unit's tests of that step, the MFMA pair
-#if TGCN_PRE_LDSREAD
         bf16x8 fa0[STEPS], fa1[STEPS];
-#else
-        bf16x8 (&fa0)[STEPS] = abl_fa0, (&fa1)[STEPS] = abl_fa1;
-        if (!abl_loaded)
-#endif
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
             const int off = s < KS ? 32 * s + 16 * h : 32 * KS;        // the bound's step: both halves read the pad chunk
             fa0[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pi + off));
             fa1[s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pi + 32 * RB + off));
         }
-#if !TGCN_PRE_LDSREAD
-        abl_loaded = true;
-#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < STEPS; ++s) {
-            if constexpr (PREV && TGCN_PRE_TESTS) {
+            if constexpr (PREV) {
 #pragma unroll
                 for (int t = (32 * s) / STEPS; t < (32 * (s + 1)) / STEPS; ++t) {
                     const float val = t < 16 ? q0[t & 15] : q1[t & 15];
@@ -479,12 +510,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
                 }
             }
             const bf16x8 bb = s < KS ? bfr[s < KS ? s : 0] : bfx;
-#if TGCN_PRE_MFMA
             c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa0[s], bb, c0, 0, 0, 0);
             c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa1[s], bb, c1, 0, 0, 0);
-#else
-            asm volatile("" ::"v"(fa0[s]), "v"(fa1[s]), "v"(bb));
-#endif
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (PREV) {
@@ -526,9 +553,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
     // previous stage's words to store -- is its own instance of the body.
     auto stage = [&](auto first_tag, int s0) {
         constexpr bool FIRST = decltype(first_tag)::value;
-#if TGCN_PRE_STAGE
-        dma_stage(buf >= 1 ? buf - 1 : 2, s0 + 2 * ST);     // ring position (buf + 2) % 3: multiplied last in the previous stage
-#endif
+        dma_stage(buf >= 1 ? buf - 1 : 2, s0 + kLead * ST);     // ring position (buf + 2) % 3: multiplied last in the previous stage
 #pragma unroll
         for (int un = 0; un < UPS; un += 2) {
             const int t0 = s0 + un * kStage;     // first item of this 64-item unit
@@ -546,20 +571,20 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
             unit(Yes{}, t0 + kStage, un + 1, B0, B1, A0, A1, t0);
             t_last = t0 + kStage, last_is_a = false;
         }
-        // The next stage's pieces have landed once at most NP vector-memory operations are in flight: loads complete in issue
-        // order, so whatever loads are still out are the NP youngest -- the pieces requested at THIS stage's start, two stages
-        // ahead.  The stage's own word stores count too (gfx9 keeps one counter) but need no ordering against the loads: they only
-        // use up allowance, and by now the pieces requested a whole stage ago are in, so the wait passes without the stores' round
-        // trip (with vmcnt(0) the last store's was paid every stage).  Register spills would be counted the same harmless way.  The
+        // The next stage's pieces have landed once at most RingWait::kAllowed (= NP: the pieces requested at THIS stage's start, two
+        // stages ahead) vector-memory operations are in flight -- the invariant at DmaRingWait, which asks nothing of where the
+        // stage's word stores sit among the requests (with vmcnt(0) the last store's round trip was paid every stage).  The
         // split's last stage requests nothing real and drains everything before the workgroup's LDS is released.
         if (s0 + ST >= i_end)
             wait_vmcnt<0>();
         else
-            wait_vmcnt<NP>();
-        __syncthreads();
-#if TGCN_PRE_STAGE
-        buf = buf == 2 ? 0 : buf + 1;
+            RingWait::wait();
+#ifdef TGCN_CHECK_DMA
+        if (s0 + ST < i_end)
+            verify_stage(buf == 2 ? 0 : buf + 1, s0 + ST);
 #endif
+        __syncthreads();
+        buf = buf == 2 ? 0 : buf + 1;
     };
     stage(Yes{}, i_beg);
     for (int s0 = i_beg + ST; s0 < i_end; s0 += ST)
@@ -602,35 +627,11 @@ inline unsigned wide_grid(int n_tiles, int splits)
     return (unsigned)(((groups + 7) / 8) * 8 * 32);
 }
 
-// development switches (tools/wide_ablate.py builds private copies with one of them off to price the loop's ingredients; the
-// shipped library has all of them on)
-#ifndef TGCN_WIDE_DMA
-#define TGCN_WIDE_DMA 1        // 0: no stage requests inside the loop (the ring keeps its first stages: timing only)
-#endif
-#ifndef TGCN_WIDE_TESTS
-#define TGCN_WIDE_TESTS 1      // 0: no tests / appends / sample stores
-#endif
-#ifndef TGCN_WIDE_MFMA
-#define TGCN_WIDE_MFMA 1       // 0: no MFMAs (fragment reads stay)
-#endif
-#ifndef TGCN_WIDE_PF
-#define TGCN_WIDE_PF 2         // (measured: 2 / 3 / 4 / 6 k-steps of lead -> 8.6 k / 9.0 k / 9.7 k / 17 k cycles per unit: deeper is slower)
-#endif
-#ifndef TGCN_WIDE_STAGGER
-#define TGCN_WIDE_STAGGER 1    // s_sleep units (64 cycles) waves 4-7 wait after every stage barrier, so that the two waves of a SIMD do not
-#endif                         // reach their fragment waits and their MFMAs together (0 / 1 / 3 / 8: 8.44 k / 8.18 k / 8.25 k / 8.42 k cycles per unit)
-#ifndef TGCN_WIDE_LDSREAD
-#define TGCN_WIDE_LDSREAD 1    // 0: the item fragments are read once per stage instead of once per k-step
-#endif
-
-#ifdef TGCN_WIDE_STAMP
-// private diagnostic build (tools/wide_ablate.py stamp): per wave, shader-clock cycles of the loop and of its waits; the shipped
-// library carries none of this
-__device__ unsigned long long g_wstamp[1 << 16][8];
-#define WSTAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
-#else
-#define WSTAMP(var)
-#endif
+// Two constants of the wide loop, each the best of a measured sweep (profiles/r03_experiments.md §3; the ablation builds that
+// priced the loop's ingredients were private copies of the round-3 source and are not part of this translation unit):
+constexpr int kWideFragLead = 2;    // k-steps the LDS fragment reads run ahead of their MFMAs (2 / 3 / 4 / 6 -> 8.6 k / 9.0 k / 9.7 k / 17 k cycles per unit)
+constexpr int kWideStagger = 1;     // s_sleep units (64 cycles) waves 4-7 wait after every stage barrier, so that the two waves of a SIMD do
+                                    // not reach their fragment waits and their MFMAs together (0 / 1 / 3 / 8: 8.44 k / 8.18 k / 8.25 k / 8.42 k)
 
 // k-steps per LDS stage: three stage buffers of 64 rows (one multiplied, two in flight) beside the exchange buffer in 160 KB
 template <int KS>
@@ -665,7 +666,6 @@ __global__ __launch_bounds__(512) void k_score_prefilter_wide(const PreWideArgs 
     // loaded round trip is longer than a stage.
     __shared__ __attribute__((aligned(16))) unsigned char smem[3][SBUF];
     __shared__ __attribute__((aligned(16))) float xbuf[4][2][16 * kWave];   // [user group][sending half][register][lane]
-    WSTAMP(st_kernel);
     const int lane = lane_id();
     const int w = uniform(threadIdx.x >> 6);
     const int ug = w & 3, hk = w >> 2;                 // waves ug and ug + 4 land on one SIMD (dispatch order 0 -> 2 -> 1 -> 3)
@@ -709,12 +709,32 @@ __global__ __launch_bounds__(512) void k_score_prefilter_wide(const PreWideArgs 
     const int last_row = (int)(a.pack_bytes / RBG) - 1;            // rows of the pack
     const unsigned row_pitch = (unsigned)wa.row_stride * RBG;
     const int last_t = last_row / wa.row_stride;
+    constexpr int kLead = 2;      // stages between a request and the stage that multiplies it (three ring buffers)
+    using RingWait = DmaRingWait<NPW, kLead>;
     auto request_piece = [&](int i, int buf, int t0, int ch) {
         const int pc = min(w + 8 * i, NPIECE - 1);
         const unsigned col = (pcol[i] >> 30) ? (unsigned)(pcol[i] & 0xFFFFFF) : (unsigned)(pcol[i] + ch * (32 * CK));
         const size_t off = (size_t)(unsigned)min(t0 + prow[i], last_t) * row_pitch + col;
+#ifdef TGCN_CHECK_DMA
+        if (w + 8 * i < NPIECE) {      // (a clamped duplicate of the last piece is another wave's to poison and check)
+            dma_poison((unsigned)(uintptr_t)(smem[buf] + pc * 1024) + (unsigned)lane * 16u);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+        }
+#endif
         lds_dma16(a.ipack + off, uniform((int)(unsigned)(uintptr_t)(smem[buf] + pc * 1024)));
     };
+#ifdef TGCN_CHECK_DMA
+    auto verify_stage = [&](int buf, int t0, int ch) {
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+            if (w + 8 * i >= NPIECE)
+                continue;
+            const unsigned col = (pcol[i] >> 30) ? (unsigned)(pcol[i] & 0xFFFFFF) : (unsigned)(pcol[i] + ch * (32 * CK));
+            const size_t off = (size_t)(unsigned)min(t0 + prow[i], last_t) * row_pitch + col;
+            dma_verify(a.ipack + off, (unsigned)(uintptr_t)(smem[buf] + (w + 8 * i) * 1024) + (unsigned)lane * 16u);
+        }
+    };
+#endif
     auto request = [&](int buf, int t0, int ch) {
 #pragma unroll
         for (int i = 0; i < NPW; ++i)
@@ -764,7 +784,7 @@ __global__ __launch_bounds__(512) void k_score_prefilter_wide(const PreWideArgs 
     // matrix pipe works, in front of the stage they would leave it idle for both waves of the SIMD at once.
     float fin[16];
     int fin_t = -1;                 // first item of the tile in `fin` (-1: none yet)
-    constexpr int PF = TGCN_WIDE_PF < HK ? TGCN_WIDE_PF : HK;      // k-steps of lead of the LDS fragment reads
+    constexpr int PF = kWideFragLead < HK ? kWideFragLead : HK;      // k-steps of lead of the LDS fragment reads
     constexpr int TS = HK > NPW ? HK - NPW : 0;      // k-steps of a unit's first stage that carry the tests (0: after the stage)
     auto consume = [&](int r0, int r1) {       // registers r0 .. r1 - 1 of the finished tile
         if constexpr (SAMPLE) {
@@ -801,22 +821,16 @@ __global__ __launch_bounds__(512) void k_score_prefilter_wide(const PreWideArgs 
             }
         }
     };
-#ifdef TGCN_WIDE_STAMP
-    unsigned long long st_wait = 0, st_bar = 0;
-    const unsigned long long st_begin = __builtin_amdgcn_s_memtime(), st_rbegin = __builtin_amdgcn_s_memrealtime();
-#endif
     for (int t0 = i_beg; t0 < i_end; t0 += kStage) {
         f32x16 c0, c1;
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
-#if TGCN_WIDE_STAGGER
             if (hk)
-                __builtin_amdgcn_s_sleep(TGCN_WIDE_STAGGER);      // (64 cycles each) take the pair out of lockstep
-#endif
+                __builtin_amdgcn_s_sleep(kWideStagger);      // (64 cycles each) take the pair out of lockstep
             const unsigned char *pi = smem[buf] + r32 * RBL + hk * (HK * 32) + 16 * h;
             // the stage after the next goes into the buffer the previous stage was read from (every wave is past that stage's
             // barrier); past the split: copies nobody reads
-            const int c2 = (ch + 2) % NCH, t2 = t0 + ((ch + 2) / NCH) * kStage, b2 = buf == 0 ? 2 : buf - 1;
+            const int c2 = (ch + kLead) % NCH, t2 = t0 + ((ch + kLead) / NCH) * kStage, b2 = buf == 0 ? 2 : buf - 1;
             // fragments PF k-steps ahead of their MFMAs, and no further (scheduling barriers): left to itself the compiler hoists
             // the whole chunk's LDS reads and spills the users' fragments.  (Stamps at two k-steps: ~2.5 k of a unit's 8.5 k cycles
             // per wave in s_waitcnt lgkmcnt -- eight waves' reads and the ring's DMA writes queue at the LDS.)
@@ -830,21 +844,10 @@ __global__ __launch_bounds__(512) void k_score_prefilter_wide(const PreWideArgs 
 #pragma unroll
             for (int s = 0; s < HK; ++s) {
                 if (s + PF < HK) {
-                    if (TGCN_WIDE_LDSREAD) {
-                        f0[s + PF] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pi + 32 * (s + PF)));
-                        f1[s + PF] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pi + 32 * RBL + 32 * (s + PF)));
-                    } else {
-                        f0[s + PF] = f0[s % PF], f1[s + PF] = f1[s % PF];
-                    }
+                    f0[s + PF] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pi + 32 * (s + PF)));
+                    f1[s + PF] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(pi + 32 * RBL + 32 * (s + PF)));
                 }
-                if (!TGCN_WIDE_MFMA) {
-                    if (ch == 0 && s == 0)
-                        for (int r = 0; r < 16; ++r)
-                            c0[r] = 0.f, c1[r] = 0.f;
-                    // (two vector adds that consume what the MFMA pair would: the fragments must still arrive)
-                    c0[s & 15] += __uint_as_float(__builtin_bit_cast(uint4, f0[s]).x ^ __builtin_bit_cast(uint4, bfr[ch * HK + s]).x);
-                    c1[s & 15] += __uint_as_float(__builtin_bit_cast(uint4, f1[s]).x);
-                } else if (ch == 0 && s == 0) {       // a unit's first k-step starts its sums from zero (no register clearing)
+                if (ch == 0 && s == 0) {       // a unit's first k-step starts its sums from zero (no register clearing)
                     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                     c0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f0[s], bfr[ch * HK + s], zero, 0, 0, 0);
                     c1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f1[s], bfr[ch * HK + s], zero, 0, 0, 0);
@@ -858,12 +861,12 @@ __global__ __launch_bounds__(512) void k_score_prefilter_wide(const PreWideArgs 
                 // the stage and the counted wait below never has to cover a request just issued
                 if (ch == 0 && TS > 0 && s < TS && fin_t >= 0)
                     consume((16 * s) / TS, (16 * (s + 1)) / TS);
-                if (TGCN_WIDE_DMA && s >= HK - min(NPW, HK))
+                if (s >= HK - min(NPW, HK))
                     request_piece(s - (HK - min(NPW, HK)), b2, t2, c2);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
-            for (int i = min(NPW, HK); TGCN_WIDE_DMA && i < NPW; ++i)      // (stages with fewer k-steps per wave than pieces)
+            for (int i = min(NPW, HK); i < NPW; ++i)      // (stages with fewer k-steps per wave than pieces)
                 request_piece(i, b2, t2, c2);
             if (ch == 0 && TS == 0 && fin_t >= 0)
                 consume(0, 16);
@@ -886,17 +889,15 @@ __global__ __launch_bounds__(512) void k_score_prefilter_wide(const PreWideArgs 
                         *reinterpret_cast<float4 *>(xout + g * 4 * kWave) = make_float4(c0[4 * g], c0[4 * g + 1], c0[4 * g + 2], c0[4 * g + 3]);
                 }
             }
-            // the NEXT stage's pieces of this wave have landed when all but the NPW requests just issued are done (requests,
-            // loads and the log stores retire in order; log stores issued since then only make this wait for more); the barrier
-            // then covers the other waves' pieces and their reads of `buf`
-            WSTAMP(ts0);
-            wait_vmcnt<NPW>();
-            WSTAMP(ts1);
-            __syncthreads();
-            WSTAMP(ts2);
-#ifdef TGCN_WIDE_STAMP
-            st_wait += ts1 - ts0, st_bar += ts2 - ts1;
+            // the NEXT stage's pieces of this wave have landed once at most RingWait::kAllowed (= NPW: the requests of stage + 2 just
+            // issued) operations are outstanding -- the invariant at DmaRingWait: it does not depend on where the log stores sit
+            // among the requests (with TS == 0 they are issued AFTER them) nor on how stores retire against loads; the barrier then
+            // covers the other waves' pieces and their reads of `buf`
+            RingWait::wait();
+#ifdef TGCN_CHECK_DMA
+            verify_stage(buf == 2 ? 0 : buf + 1, t0 + ((ch + 1) / NCH) * kStage, (ch + 1) % NCH);
 #endif
+            __syncthreads();
             buf = buf == 2 ? 0 : buf + 1;
         }
         // this wave's tile: own half + the partner's (the next write of xbuf lies behind the next unit's first barrier)
@@ -911,16 +912,6 @@ __global__ __launch_bounds__(512) void k_score_prefilter_wide(const PreWideArgs 
         fin_t = t0 + 32 * hk;          // first item of the tile
     }
     consume(0, 16);                    // the split's last tile
-#ifdef TGCN_WIDE_STAMP
-    if (!SAMPLE && lane == 0) {
-        const unsigned slot = (blockIdx.x * 8 + w) & 0xFFFF;
-        g_wstamp[slot][0] = __builtin_amdgcn_s_memtime() - st_begin;
-        g_wstamp[slot][1] = __builtin_amdgcn_s_memrealtime() - st_rbegin;
-        g_wstamp[slot][2] = st_wait, g_wstamp[slot][3] = st_bar;
-        g_wstamp[slot][4] = st_begin - st_kernel;       // prologue
-        g_wstamp[slot][5] = (i_end - i_beg + kStage - 1) / kStage;
-    }
-#endif
     wait_vmcnt<0>();          // requests still in flight write into this workgroup's LDS: they must land before it is released
     if (user_ok && !SAMPLE)
         wa.counts[seg] = n_log;
@@ -1304,9 +1295,16 @@ struct RescoreArgs {
     const int *__restrict__ surv;    // FROM_LIST: [B][surv_cap] candidate ids of k_refine, surv_n[b] of them (instead of the mask)
     const int *__restrict__ surv_n;
     int surv_cap;
-    float2 *__restrict__ lists;     // [B][list_cap]
+    float2 *__restrict__ lists;     // [B][list_cap]  (SELECT: unused -- the kept pairs never leave the kernel)
     int *__restrict__ totals;       // [B]
     int B, d, list_cap;
+    // SELECT (narrow rows): the exact selection of the user's top k runs in the same wave, on the kept pairs in LDS
+    const int *__restrict__ mask_rowptr;   // may be NULL
+    const int *__restrict__ mask_items;
+    float *__restrict__ out_val;
+    int64_t *__restrict__ out_idx;
+    int *__restrict__ flagged;             // [1 + B]: count, then the users left to the exact fallback
+    int k, do_round;
 };
 
 constexpr int kUserCap = 1536;      // candidates of a user held in LDS
@@ -1315,13 +1313,24 @@ constexpr int kMaxPreD = 1024;      // widest row of the prefiltered path
 constexpr int kKB = 32;             // floats of a row per LDS tile
 constexpr int kTileRow = kKB + 1;   // padded: lane = row reads are conflict-free
 constexpr int kChunkWords = 32;     // mask words per lane per chunk
+constexpr int kMaskCacheSel = 512;  // train items per user cached in LDS by the fused selection (as k_select_flat's kMaskCache)
 
-template <bool ALIGNED4, bool FROM_LIST>     // rows are multiples of 16 bytes (d % 4 == 0): one float4 per (row, piece), else four scalars
+// SELECT (round 4; the narrow rows' call): what used to be the next launch -- k_select_flat, one wave per user as well -- is the tail
+// of this one.  The kept (score, item) pairs stay in LDS: the item ids go back INTO the candidate array (kept pair number p
+// overwrites ids[p]; p never runs ahead of the candidates already chained, and everything later reads ids further on), the scores
+// into a 4 KB array; then the train items are dropped, the k-th largest is found by the bitwise search of select_core and the
+// winners are sorted and written -- no flat list in global memory, no totals round trip, one launch less per call
+// (36 of 304 us at 16 384 users).  A user with no candidates, too many, or fewer than k unmasked ones goes to the exact fallback.
+template <bool ALIGNED4, bool FROM_LIST, bool SELECT = false>     // ALIGNED4: rows are multiples of 16 bytes (d % 4 == 0): one float4 per (row, piece), else four scalars
 __global__ __launch_bounds__(256) void k_rescore(const RescoreArgs a)
 {
+    static_assert(!(SELECT && FROM_LIST), "the fused selection is the narrow rows' (d <= 128)");
+    constexpr int kSuLen = SELECT ? 128 : kMaxPreD;
     __shared__ int ids_all[4][kUserCap];
     __shared__ float tiles[4][kWave * kTileRow];
-    __shared__ __attribute__((aligned(16))) float su_all[4][kMaxPreD];   // the user's row
+    __shared__ __attribute__((aligned(16))) float su_all[4][kSuLen];   // the user's row
+    __shared__ float kscore_all[4][SELECT ? kSelCap : 1];
+    static_assert(kWave * kTileRow * sizeof(float) >= kMaskCacheSel * sizeof(int) + kWave * sizeof(float2), "select scratch inside the tile");
     const int lane = lane_id();
     const int w = threadIdx.x >> 6;
     const int b = blockIdx.x * 4 + w;
@@ -1329,7 +1338,22 @@ __global__ __launch_bounds__(256) void k_rescore(const RescoreArgs a)
         return;
     int *ids = ids_all[w];
     float *tile = tiles[w];
-    float *su = su_all[w];   // read back as LDS broadcasts: left to the compiler, u_k of the chains is a vector load from global
+    float *su = su_all[w];
+    float *kscore = kscore_all[w];
+    auto give_up = [&](int total) {      // the user goes to the exact fallback (k_brute_part)
+        if (lane == 0) {
+            a.totals[b] = total;
+            if constexpr (SELECT)
+                a.flagged[1 + atomicAdd(a.flagged, 1)] = b;
+        }
+    };
+    int mb = 0, me = 0;
+    if constexpr (SELECT) {
+        if (a.mask_rowptr) {
+            mb = a.mask_rowptr[b];
+            me = a.mask_rowptr[b + 1];
+        }
+    }   // read back as LDS broadcasts: left to the compiler, u_k of the chains is a vector load from global
                              // memory per fmaf (the address is not proven uniform), 5 us per 64-entry step
     {
         const float *__restrict__ urow = a.U + (size_t)(a.user_ids ? a.user_ids[b] : (int64_t)b) * a.d;
@@ -1343,8 +1367,7 @@ __global__ __launch_bounds__(256) void k_rescore(const RescoreArgs a)
     if constexpr (FROM_LIST) {
         n = a.surv_n[b];
         if (n > kUserCap) {
-            if (lane == 0)
-                a.totals[b] = kOverflow;
+            give_up(kOverflow);
             return;
         }
         for (int j = lane; j < n; j += kWave)
@@ -1384,8 +1407,7 @@ __global__ __launch_bounds__(256) void k_rescore(const RescoreArgs a)
         }
         const int chunk_n = __builtin_amdgcn_readlane(incl, kWave - 1);
         if (n + chunk_n > kUserCap) {    // too many candidates (tau = -inf, non-finite norms, a degenerate threshold ...)
-            if (lane == 0)
-                a.totals[b] = kOverflow;
+            give_up(kOverflow);
             return;
         }
         int off = n + incl - mine;
@@ -1406,8 +1428,7 @@ __global__ __launch_bounds__(256) void k_rescore(const RescoreArgs a)
         n += chunk_n;
     }
     if (n == 0) {
-        if (lane == 0)
-            a.totals[b] = 0;
+        give_up(0);
         return;
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -1465,8 +1486,18 @@ __global__ __launch_bounds__(256) void k_rescore(const RescoreArgs a)
             const bool keep = t0 + lane < n && s > tau;
             const unsigned long long m = __ballot(keep);
             const int pos = kept + __popcll(m & ((1ull << lane) - 1ull));
-            if (keep && pos < a.list_cap)
-                lg[pos] = make_float2(s, __int_as_float(ids[t0 + lane]));
+            if constexpr (SELECT) {
+                const int id = ids[min(t0 + lane, n - 1)];     // every lane's read of the step's ids BEFORE any write below
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                __builtin_amdgcn_wave_barrier();
+                if (keep && pos < kSelCap) {                   // pos <= t0 + lane: at or behind the candidate it came from
+                    ids[pos] = id;
+                    kscore[pos] = s;
+                }
+            } else {
+                if (keep && pos < a.list_cap)
+                    lg[pos] = make_float2(s, __int_as_float(ids[t0 + lane]));
+            }
             kept += __popcll(m);
         }
     };
@@ -1491,20 +1522,69 @@ __global__ __launch_bounds__(256) void k_rescore(const RescoreArgs a)
         issue(step + 6, v2);
         process(step + 3, v3);
     }
-    if (lane == 0)
-        a.totals[b] = kept;
+    if constexpr (!SELECT) {
+        if (lane == 0)
+            a.totals[b] = kept;
+        return;
+    } else {
+        // (4) the exact selection (k_select_flat's, on the LDS list): train items out, k-th largest, winners sorted
+        if (kept == 0 || kept > kSelCap) {
+            give_up(kept);
+            return;
+        }
+        if (lane == 0)
+            a.totals[b] = kept;
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();     // the last step's reads of the tile and its list writes are done
+        int *smask = reinterpret_cast<int *>(tile);                              // the tile is free: mask cache + pack buffer
+        float2 *spack = reinterpret_cast<float2 *>(tile + kMaskCacheSel);
+        const bool cached = (me - mb) <= kMaskCacheSel;
+        if (cached)
+            for (int j = lane; j < me - mb; j += kWave)
+                smask[j] = a.mask_items[mb + j];
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        bool ok = true;
+        float out_v = -INFINITY;
+        int out_i = INT_MAX;
+        auto run = [&](auto vpl_tag) {
+            constexpr int VPL = decltype(vpl_tag)::value;
+            unsigned key[VPL];
+            int idx[VPL];
+            int n_valid = 0;
+#pragma unroll
+            for (int sgm = 0; sgm < VPL; ++sgm) {
+                const int j = min(lane + kWave * sgm, kept - 1);
+                const int si = ids[j];
+                const float sv = kscore[j];
+                bool on = lane + kWave * sgm < kept;
+                if (on && (cached ? sorted_contains(smask, 0, me - mb, si) : sorted_contains(a.mask_items, mb, me, si)))
+                    on = false;     // a train item (base_model.py:257-258 sets them to -inf)
+                idx[sgm] = on ? si : INT_MAX;
+                key[sgm] = on ? ordered_key(sv) : 0u;
+                n_valid += __popcll(__ballot(on));
+            }
+            ok = n_valid >= a.k;
+            if (ok)
+                select_core<VPL>(key, idx, a.k, lane, out_v, out_i, spack);
+        };
+        if (kept <= 4 * kWave)
+            run(std::integral_constant<int, 4>{});
+        else if (kept <= 8 * kWave)
+            run(std::integral_constant<int, 8>{});
+        else
+            run(std::integral_constant<int, kSelVPL>{});
+        if (!ok && lane == 0)
+            a.flagged[1 + atomicAdd(a.flagged, 1)] = b;
+        if (ok && lane < a.k) {
+            a.out_val[(size_t)b * a.k + lane] = a.do_round ? round4(out_v) : out_v;
+            a.out_idx[(size_t)b * a.k + lane] = out_i;
+        }
+    }
 }
 
 }  // namespace
 
-#ifdef TGCN_WIDE_STAMP
-}  // namespace tgcn
-extern "C" int tgcn_wide_stamp_read(void *host, long long bytes)
-{
-    return hipMemcpyFromSymbol(host, HIP_SYMBOL(tgcn::g_wstamp), (size_t)bytes) == hipSuccess ? 0 : -2;
-}
-namespace tgcn {
-#endif
 
 bool prefilter_supports(int d) { return d <= 128 || (d <= kMaxPreD && d % 8 == 0); }
 
@@ -1676,26 +1756,41 @@ int launch_sample_wide(const float *U, const int64_t *user_ids, int B, const voi
     return check_launch("k_score_prefilter_wide(sample)");
 }
 
-int launch_rescore(const float *U, const int64_t *user_ids, int B, const float *It, int d, const float *tau, int tau_stride,
-                   const unsigned *mask, int Wh, int n_units, void *lists, int *totals, int list_cap, hipStream_t s)
+int launch_rescore_select(const float *U, const int64_t *user_ids, int B, const float *It, int d, const float *tau, int tau_stride,
+                          const unsigned *mask, int Wh, int n_units, int *totals, const int *mask_rowptr, const int *mask_items, int k,
+                          int do_round, float *out_val, int64_t *out_idx, int *flagged, hipStream_t s)
 {
-    RescoreArgs a{U, user_ids, It, tau, tau_stride, mask, Wh, n_units, nullptr, nullptr, 0, static_cast<float2 *>(lists), totals, B, d,
-                  list_cap};
+    if (d > 128)
+        return fail_arg("launch_rescore_select: narrow rows only");
+    RescoreArgs a{U, user_ids, It, tau, tau_stride, mask, Wh, n_units, nullptr, nullptr, 0, nullptr, totals, B, d, 0,
+                  mask_rowptr, mask_items, out_val, out_idx, flagged, k, do_round};
     if ((d & 3) == 0)
-        hipLaunchKernelGGL((k_rescore<true, false>), dim3((B + 3) / 4), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((k_rescore<true, false, true>), dim3((B + 3) / 4), dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL((k_rescore<false, false>), dim3((B + 3) / 4), dim3(256), 0, s, a);
-    return check_launch("k_rescore");
+        hipLaunchKernelGGL((k_rescore<false, false, true>), dim3((B + 3) / 4), dim3(256), 0, s, a);
+    return check_launch("k_rescore(select)");
 }
 
-// the same from k_refine's id lists (wide rows; d % 8 == 0 there)
 int launch_rescore_list(const float *U, const int64_t *user_ids, int B, const float *It, int d, const float *tau, int tau_stride,
                         const int *surv, const int *surv_n, int surv_cap, void *lists, int *totals, int list_cap, hipStream_t s)
 {
     RescoreArgs a{U, user_ids, It, tau, tau_stride, nullptr, 0, 0, surv, surv_n, surv_cap, static_cast<float2 *>(lists), totals, B, d,
-                  list_cap};
+                  list_cap, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
     hipLaunchKernelGGL((k_rescore<true, true>), dim3((B + 3) / 4), dim3(256), 0, s, a);
     return check_launch("k_rescore(list)");
 }
 
 }  // namespace tgcn
+
+#ifdef TGCN_CHECK_DMA
+// checked build only: (stale, checked) 16-byte pieces since the library was loaded; synchronises the device
+extern "C" int tgcn_debug_dma_counts(unsigned long long *stale_host, unsigned long long *checked_host)
+{
+    if (hipDeviceSynchronize() != hipSuccess)
+        return TGCN_ERR_HIP;
+    if (hipMemcpyFromSymbol(stale_host, HIP_SYMBOL(tgcn::g_dma_stale_pieces), sizeof(unsigned long long)) != hipSuccess ||
+        hipMemcpyFromSymbol(checked_host, HIP_SYMBOL(tgcn::g_dma_checked_pieces), sizeof(unsigned long long)) != hipSuccess)
+        return TGCN_ERR_HIP;
+    return TGCN_OK;
+}
+#endif

@@ -99,6 +99,35 @@ __device__ __forceinline__ void epilogue(const SpmmArgs &a, size_t off, const fl
     }
 }
 
+// The same epilogue with the row's acc_in already in registers: the load is issued at the START of the row's work (only
+// this wave writes the row, so acc_in aliasing acc_out is harmless) and has long landed when the chain ends -- one
+// dependent round trip less per row than loading it here.
+template <int VEC>
+__device__ __forceinline__ void preload_acc(const SpmmArgs &a, size_t off, float (&t)[VEC])
+{
+#pragma unroll
+    for (int k = 0; k < VEC; ++k)
+        t[k] = 0.0f;
+    if (a.acc_out)
+        load_vec<VEC>(a.acc_in + off, t);
+}
+
+template <int VEC>
+__device__ __forceinline__ void epilogue_pre(const SpmmArgs &a, size_t off, const float (&y)[VEC], float (&t)[VEC])
+{
+    if (a.Y)
+        store_vec<VEC>(a.Y + off, y);
+    if (a.acc_out) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            t[k] = t[k] + y[k];
+            if (a.acc_div != 1.0f)
+                t[k] = t[k] / a.acc_div;  // IEEE division: the reference divides (torch.mean), base_model.py:157
+        }
+        store_vec<VEC>(a.acc_out + off, t);
+    }
+}
+
 // One wave walks entries [beg, end) (wave-uniform bounds) of one row; lane owns columns
 // [lane*VEC, lane*VEC+VEC).  acc continues the fmaf chain.
 template <int VEC, int UNROLL>
@@ -176,6 +205,9 @@ __global__ __launch_bounds__(256) void k_spmm_wave(const SpmmArgs a)
     if (wave - a.n_chunks >= a.row_waves)
         return;
     const int row = a.row_order ? a.row_order[wave - a.n_chunks] : wave - a.n_chunks;
+    const size_t off = (size_t)row * a.d + lane * VEC;
+    float t[VEC];
+    preload_acc<VEC>(a, off, t);  // before the rowptr -> (col, val) -> gather chain
     const int beg = a.rowptr[row];
     const int end = a.rowptr[row + 1];
     if (end - beg > a.threshold)
@@ -185,7 +217,7 @@ __global__ __launch_bounds__(256) void k_spmm_wave(const SpmmArgs a)
     for (int k = 0; k < VEC; ++k)
         acc[k] = 0.0f;
     accumulate_wave<VEC, UNROLL>(a, beg, end, lane, acc);
-    epilogue<VEC>(a, (size_t)row * a.d + lane * VEC, acc);
+    epilogue_pre<VEC>(a, off, acc, t);
 }
 
 // ---- narrow tables (d in {8, 16, 32}) ---------------------------------------------------------------------------------------
@@ -342,12 +374,15 @@ __global__ __launch_bounds__(256) void k_spmm_seg(const SpmmArgs a, const SegArg
         if (w >= g.n_direct)
             return;
         const int row = g.direct_rows[w];
+        const size_t off = (size_t)row * a.d + lane * VEC;
+        float t[VEC];
+        preload_acc<VEC>(a, off, t);
         float acc[VEC];
 #pragma unroll
         for (int k = 0; k < VEC; ++k)
             acc[k] = 0.0f;
         accumulate_wave<VEC, (VEC == 4 ? 8 : 16)>(a, a.rowptr[row], a.rowptr[row + 1], lane, acc);
-        epilogue<VEC>(a, (size_t)row * a.d + lane * VEC, acc);
+        epilogue_pre<VEC>(a, off, acc, t);
         return;
     }
     const int2 meta = g.tile_meta[wave];
@@ -491,12 +526,247 @@ __global__ __launch_bounds__(256) void k_spmm_reduce_direct(const SpmmArgs a, co
     if (w >= n_direct)
         return;
     const int row = direct_rows[w];
+    const size_t off = (size_t)row * a.d + lane * VEC;
+    float t[VEC];
+    preload_acc<VEC>(a, off, t);
     float acc[VEC];
 #pragma unroll
     for (int k = 0; k < VEC; ++k)
         acc[k] = 0.0f;
     accumulate_wave<VEC, (VEC == 4 ? 8 : 16)>(a, a.rowptr[row], a.rowptr[row + 1], lane, acc);
-    epilogue<VEC>(a, (size_t)row * a.d + lane * VEC, acc);
+    epilogue_pre<VEC>(a, off, acc, t);
+}
+
+// ---- row groups: one wave owns up to R CONSECUTIVE rows (tgcn_spmm_groups_f32) ---------------------------------------------
+// A wave that owns one short row pays four dependent round trips (rowptr -> (col, val) -> one batch of gathers -> store) for a
+// dozen gathers, and its gather pipeline drains at the row's end.  The entries of consecutive rows are one contiguous range of
+// colidx / vals: a wave that owns rows [first, first + n) loads their n + 1 row pointers with one instruction, issues the n
+// acc_in rows at once, and walks the range 64 entries at a time with UNROLL row gathers in flight ACROSS row ends.  An entry
+// that ends a row (found by comparing its offset + 1 with the n row ends, held in SGPRs; one ballot per 64 entries) parks the
+// running sum in the wave's LDS rows -- lane-private slots, no barrier -- and restarts the chain from +0, so every row is still
+// ONE sequential fmaf chain in column order: the same bits as one wave per row.  The Y / acc epilogues of the group's rows are
+// issued together at the end.  Groups are built on the host (graph.row_groups): consecutive rows up to ~64 entries or R rows,
+// never across a row the split plan cuts; handed out longest first where the launch's tail matters.
+template <int VEC>
+struct GroupShape {
+    static constexpr int R = VEC == 4 ? 4 : 8;      // rows per group: R * VEC registers of acc_in, R * 256 * VEC bytes of LDS per wave
+};
+
+template <int VEC>
+__device__ __forceinline__ void lds_store_vec(float *p, const float (&x)[VEC])
+{
+    if constexpr (VEC == 1)
+        *p = x[0];
+    else if constexpr (VEC == 2)
+        *reinterpret_cast<float2 *>(p) = make_float2(x[0], x[1]);
+    else
+        *reinterpret_cast<float4 *>(p) = make_float4(x[0], x[1], x[2], x[3]);
+}
+
+// UNROLL gathers in flight, then the chain; bit u of `fm` set: entry j + u is the last of its row
+template <int VEC, int UNROLL, bool FULL>
+__device__ __forceinline__ void group_batch(const char *__restrict__ Xb, unsigned lane_off, float *__restrict__ yl, int c, float v, int j,
+                                            int n, unsigned fm, unsigned &rem, float (&acc)[VEC])
+{
+    constexpr unsigned kRowShift = VEC == 1 ? 8 : VEC == 2 ? 9 : 10;  // log2(4 * d)
+    constexpr int D = 64 * VEC;
+    float x[UNROLL][VEC];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+        const unsigned cj = (unsigned)__builtin_amdgcn_readlane(c, FULL ? j + u : min(j + u, n - 1));
+        load_vec<VEC>(reinterpret_cast<const float *>(Xb + ((cj << kRowShift) + lane_off)), x[u]);
+    }
+#pragma unroll
+    for (int u4 = 0; u4 < UNROLL; u4 += 4) {
+        const bool any = (fm >> u4) & 0xfu;  // scalar
+#pragma unroll
+        for (int u = u4; u < u4 + 4; ++u) {
+            if (FULL || j + u < n) {
+                const float vj = readlane_f(v, j + u);
+#pragma unroll
+                for (int k = 0; k < VEC; ++k)
+                    acc[k] = fmaf(vj, x[u][k], acc[k]);
+                if (any && (fm & (1u << u))) {  // last entry of the lowest non-empty row still open
+                    lds_store_vec<VEC>(yl + __builtin_ctz(rem) * D, acc);
+                    rem &= rem - 1;
+#pragma unroll
+                    for (int k = 0; k < VEC; ++k)
+                        acc[k] = 0.0f;
+                }
+            }
+        }
+    }
+}
+
+template <int VEC, int UNROLL>
+__device__ __forceinline__ void group_wave(const SpmmArgs &a, int first, int n, int lane, float *__restrict__ yl /* this wave's LDS rows + lane * VEC */)
+{
+    constexpr int R = GroupShape<VEC>::R;
+    constexpr int D = 64 * VEC;
+    // row pointers of the group: lane l < n holds row l's begin and end
+    const int li = min(lane, n - 1);
+    const int rp = a.rowptr[first + li];
+    const int re = a.rowptr[first + li + 1];
+    const size_t off0 = (size_t)first * D + lane * VEC;
+    float t[R][VEC];
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+#pragma unroll
+        for (int k = 0; k < VEC; ++k)
+            t[i][k] = 0.0f;
+        if (i < n)                   // uniform
+            preload_acc<VEC>(a, off0 + (size_t)i * D, t[i]);
+    }
+    {
+        float z[VEC];
+#pragma unroll
+        for (int k = 0; k < VEC; ++k)
+            z[k] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < R; ++i)  // rows without entries are never closed: their sum is +0
+            lds_store_vec<VEC>(yl + i * D, z);
+    }
+    const int beg = __builtin_amdgcn_readlane(rp, 0);
+    const int end = __builtin_amdgcn_readlane(re, n - 1);
+    int s_re[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i)
+        s_re[i] = i < n ? __builtin_amdgcn_readlane(re, i) : -1;
+    unsigned rem = (unsigned)__ballot(lane < n && re > rp);   // rows with entries, lowest = the open one
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k)
+        acc[k] = 0.0f;
+    if (end > beg) {
+        const char *__restrict__ Xb = reinterpret_cast<const char *>(a.X);
+        const unsigned lane_off = lane * VEC * 4;
+        int c = 0;
+        float v = 0.0f;
+        if (beg + lane < end) {
+            c = a.colidx[beg + lane];
+            v = a.vals[beg + lane];
+        }
+        for (int base = beg; base < end; base += kWave) {
+            const int ns = min(kWave, end - base);  // uniform
+            int c_nxt = 0;
+            float v_nxt = 0.0f;
+            if (base + kWave + lane < end) {
+                c_nxt = a.colidx[base + kWave + lane];
+                v_nxt = a.vals[base + kWave + lane];
+            }
+            const int e1 = base + lane + 1;
+            bool f = false;
+#pragma unroll
+            for (int i = 0; i < R; ++i)
+                f |= e1 == s_re[i];
+            const unsigned long long flags = __ballot(f);
+            if (ns == kWave) {
+#pragma unroll
+                for (int j = 0; j < kWave; j += UNROLL)
+                    group_batch<VEC, UNROLL, true>(Xb, lane_off, yl, c, v, j, ns, (unsigned)(flags >> j), rem, acc);
+            } else {
+                for (int j = 0; j < ns; j += UNROLL)
+                    group_batch<VEC, UNROLL, false>(Xb, lane_off, yl, c, v, j, ns, (unsigned)(flags >> j), rem, acc);
+            }
+            c = c_nxt, v = v_nxt;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+        if (i < n) {  // uniform
+            float y[VEC];
+            if constexpr (VEC == 1) {
+                y[0] = yl[i * D];
+            } else if constexpr (VEC == 2) {
+                const float2 q = *reinterpret_cast<const float2 *>(yl + i * D);
+                y[0] = q.x, y[1] = q.y;
+            } else {
+                const float4 q = *reinterpret_cast<const float4 *>(yl + i * D);
+                y[0] = q.x, y[1] = q.y, y[2] = q.z, y[3] = q.w;
+            }
+            epilogue_pre<VEC>(a, off0 + (size_t)i * D, y, t[i]);
+        }
+    }
+}
+
+template <int VEC, int UNROLL>
+__device__ __forceinline__ void single_row_wave(const SpmmArgs &a, int row, int lane)
+{
+    const size_t off = (size_t)row * a.d + lane * VEC;
+    float t[VEC];
+    preload_acc<VEC>(a, off, t);
+    float acc[VEC];
+#pragma unroll
+    for (int k = 0; k < VEC; ++k)
+        acc[k] = 0.0f;
+    accumulate_wave<VEC, UNROLL>(a, a.rowptr[row], a.rowptr[row + 1], lane, acc);
+    epilogue_pre<VEC>(a, off, acc, t);
+}
+
+template <int VEC, int UNROLL>
+__global__ __launch_bounds__(256) void k_spmm_groups(const SpmmArgs a, const int2 *__restrict__ groups, int n_groups)
+{
+    constexpr int R = GroupShape<VEC>::R;
+    __shared__ float ybuf[4][R * 64 * VEC];
+    const int lane = lane_id();
+    const int wave = uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (wave < a.n_chunks) {
+        chunk_wave<VEC, UNROLL>(a, wave, lane);
+        return;
+    }
+    const int w = wave - a.n_chunks;
+    if (w >= n_groups)
+        return;
+    const int2 g = groups[w];
+    if (g.y == 1) {  // a row long enough to be a group of its own (graph.row_groups single_len): the one-wave-per-row walk
+        single_row_wave<VEC, UNROLL>(a, g.x, lane);
+        return;
+    }
+    group_wave<VEC, UNROLL>(a, g.x, g.y, lane, ybuf[threadIdx.x >> 6] + lane * VEC);
+}
+
+// second launch of the two-launch segmented form with the direct rows in groups
+template <int VEC>
+__global__ __launch_bounds__(256) void k_spmm_reduce_groups(const SpmmArgs a, const int *__restrict__ rows,
+                                                            const int *__restrict__ row_slot_ptr,
+                                                            const int *__restrict__ row_slots, int n_red,
+                                                            const int2 *__restrict__ groups, int n_groups)
+{
+    constexpr int R = GroupShape<VEC>::R;
+    __shared__ float ybuf[4][R * 64 * VEC];
+    const int lane = lane_id();
+    const int wave = uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (wave < n_red) {
+        seg_reduce_row<VEC>(a, rows, row_slot_ptr, row_slots, wave, lane);
+        return;
+    }
+    const int w = wave - n_red;
+    if (w >= n_groups)
+        return;
+    const int2 g = groups[w];
+    if (g.y == 1) {
+        single_row_wave<VEC, (VEC == 4 ? 8 : 16)>(a, g.x, lane);
+        return;
+    }
+    group_wave<VEC, (VEC == 4 ? 8 : 16)>(a, g.x, g.y, lane, ybuf[threadIdx.x >> 6] + lane * VEC);
+}
+
+template <int VEC>
+int launch_groups(const SpmmArgs &a, const int2 *groups, int n_groups, int unroll, int grid, hipStream_t s)
+{
+    if (unroll == 0)
+        unroll = VEC == 4 ? 8 : 16;
+    switch (unroll) {
+        case 8: hipLaunchKernelGGL((k_spmm_groups<VEC, 8>), dim3(grid), dim3(256), 0, s, a, groups, n_groups); break;
+        case 32:
+            if constexpr (VEC <= 2) {
+                hipLaunchKernelGGL((k_spmm_groups<VEC, 32>), dim3(grid), dim3(256), 0, s, a, groups, n_groups);
+                break;
+            }
+            [[fallthrough]];
+        default: hipLaunchKernelGGL((k_spmm_groups<VEC, 16>), dim3(grid), dim3(256), 0, s, a, groups, n_groups); break;
+    }
+    return check_launch("k_spmm_groups");
 }
 
 // any d: wave per row, one 64-column slab at a time (re-walks the row per slab; d <= 64 is one pass)
@@ -552,6 +822,8 @@ __global__ __launch_bounds__(256) void k_spmm_long_reduce(const SpmmArgs a, cons
         return;
     const int row = long_rows[l];
     const int c0 = long_chunk_ptr[l], c1 = long_chunk_ptr[l + 1];
+    float t[VEC];
+    preload_acc<VEC>(a, (size_t)row * a.d + lane * VEC, t);
     float y[VEC];
     load_vec<VEC>(a.ws + (size_t)c0 * a.d + lane * VEC, y);
     // loads of up to 8 chunk sums are issued together; the additions stay in chunk order
@@ -567,7 +839,7 @@ __global__ __launch_bounds__(256) void k_spmm_long_reduce(const SpmmArgs a, cons
                 for (int k = 0; k < VEC; ++k)
                     y[k] = y[k] + p[u][k];
     }
-    epilogue<VEC>(a, (size_t)row * a.d + lane * VEC, y);
+    epilogue_pre<VEC>(a, (size_t)row * a.d + lane * VEC, y, t);
 }
 
 template <int VEC>
@@ -675,6 +947,61 @@ extern "C" int tgcn_spmm_csr_f32(const int32_t *rowptr, const int32_t *colidx, c
     return rc;
 }
 
+extern "C" int tgcn_spmm_groups_f32(const int32_t *rowptr, const int32_t *colidx, const float *vals, int64_t n_rows,
+                                    const float *X, int64_t n_src_rows, int32_t d, float *Y, const float *acc_in,
+                                    float *acc_out, float acc_div, const tgcn_split_plan_t *plan, const int32_t *groups,
+                                    int64_t n_groups, uint32_t flags, tgcn_stream_t stream)
+{
+    TGCN_REQUIRE(n_rows >= 0 && n_rows < INT_MAX - 256, "n_rows out of range");
+    TGCN_REQUIRE(d == 64 || d == 128 || d == 256, "row groups support d in {64, 128, 256}");
+    TGCN_REQUIRE(n_src_rows >= 0 && n_src_rows < INT_MAX, "n_src_rows out of range");
+    TGCN_REQUIRE(n_groups >= 0 && n_groups <= n_rows, "n_groups out of range");
+    if (n_rows == 0)
+        return TGCN_OK;
+    TGCN_REQUIRE(rowptr && X && colidx && vals, "rowptr / colidx / vals / X is NULL");
+    TGCN_REQUIRE(n_groups == 0 || groups, "groups is NULL");
+    TGCN_REQUIRE(Y || acc_out, "both Y and acc_out are NULL: nothing to compute");
+    TGCN_REQUIRE(!acc_out || acc_in, "acc_out given without acc_in");
+    TGCN_REQUIRE(acc_div != 0.0f, "acc_div must be non-zero");
+    TGCN_REQUIRE((uint64_t)n_src_rows * (uint64_t)d * 4u < (1ull << 32), "row groups need a gathered table below 4 GB");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    SpmmArgs a;
+    a.rowptr = rowptr, a.colidx = colidx, a.vals = vals, a.X = X, a.Y = Y;
+    a.acc_in = acc_in, a.acc_out = acc_out, a.acc_div = acc_div;
+    a.n_rows = (int)n_rows, a.d = d, a.row_waves = 0, a.row_order = nullptr;
+    a.threshold = INT_MAX, a.n_chunks = 0, a.chunk_beg = nullptr, a.chunk_end = nullptr, a.ws = nullptr;
+    const bool split = plan && plan->n_chunks > 0;
+    if (split) {
+        TGCN_REQUIRE(plan->threshold > 0, "plan->threshold must be positive");
+        TGCN_REQUIRE(plan->chunk_beg && plan->chunk_end && plan->long_rows && plan->long_chunk_ptr && plan->workspace,
+                     "split plan has NULL members");
+        TGCN_REQUIRE(plan->n_long > 0, "split plan has chunks but no long rows");
+        a.threshold = plan->threshold, a.n_chunks = plan->n_chunks;
+        a.chunk_beg = plan->chunk_beg, a.chunk_end = plan->chunk_end, a.ws = plan->workspace;
+    }
+    const int unroll = (flags >> 8) & 0xff;
+    const long long waves = (long long)a.n_chunks + n_groups;
+    const int grid = (int)((waves + 3) / 4);
+    const int2 *g2 = reinterpret_cast<const int2 *>(groups);
+    int rc = TGCN_OK;
+    if (grid > 0)
+        rc = d == 64 ? launch_groups<1>(a, g2, (int)n_groups, unroll, grid, s)
+                     : d == 128 ? launch_groups<2>(a, g2, (int)n_groups, unroll, grid, s) : launch_groups<4>(a, g2, (int)n_groups, unroll, grid, s);
+    if (rc != TGCN_OK)
+        return rc;
+    if (split) {
+        const int rgrid = (plan->n_long + 3) / 4;
+        if (d == 64)
+            hipLaunchKernelGGL((k_spmm_long_reduce<1>), dim3(rgrid), dim3(256), 0, s, a, plan->long_rows, plan->long_chunk_ptr, plan->n_long);
+        else if (d == 128)
+            hipLaunchKernelGGL((k_spmm_long_reduce<2>), dim3(rgrid), dim3(256), 0, s, a, plan->long_rows, plan->long_chunk_ptr, plan->n_long);
+        else
+            hipLaunchKernelGGL((k_spmm_long_reduce<4>), dim3(rgrid), dim3(256), 0, s, a, plan->long_rows, plan->long_chunk_ptr, plan->n_long);
+        rc = check_launch("k_spmm_long_reduce");
+    }
+    return rc;
+}
+
 extern "C" int tgcn_spmm_segmented_f32(const tgcn_segment_plan_t *plan, const int32_t *rowptr, const int32_t *colidx,
                                        const float *vals, int64_t n_rows, const float *X, int64_t n_src_rows, int32_t d,
                                        float *Y, const float *acc_in, float *acc_out, float acc_div, uint32_t flags,
@@ -693,7 +1020,7 @@ extern "C" int tgcn_spmm_segmented_f32(const tgcn_segment_plan_t *plan, const in
     TGCN_REQUIRE(plan->n_tiles >= 0 && plan->n_tiles % 4 == 0, "n_tiles must be a multiple of 4");
     TGCN_REQUIRE(plan->tile_entries > 0 && plan->tile_entries % 64 == 0, "tile_entries must be a positive multiple of 64");
     TGCN_REQUIRE((int64_t)plan->n_tiles * plan->tile_entries < INT_MAX, "segment streams too large");
-    TGCN_REQUIRE(plan->n_seg_rows >= 0 && plan->n_direct_rows >= 0 && plan->n_slots >= 0, "negative plan counts");
+    TGCN_REQUIRE(plan->n_seg_rows >= 0 && plan->n_direct_rows >= 0 && plan->n_slots >= 0 && plan->n_direct_groups >= 0, "negative plan counts");
     TGCN_REQUIRE((int64_t)plan->n_seg_rows + plan->n_direct_rows == n_rows, "plan does not cover every row once");
     TGCN_REQUIRE(plan->n_tiles == 0 || (plan->tile_meta && plan->ent_col && plan->ent_val && plan->ent_flags && plan->workspace),
                  "segment stream arrays are NULL");
@@ -725,6 +1052,19 @@ extern "C" int tgcn_spmm_segmented_f32(const tgcn_segment_plan_t *plan, const in
                                                                                     : launch_seg<4>(a, g, unroll, grid, s);
             if (rc != TGCN_OK)
                 return rc;
+        }
+        if (plan->n_direct_groups > 0) {   // the direct rows in groups of consecutive rows (graph.row_groups)
+            TGCN_REQUIRE(plan->direct_groups, "direct_groups is NULL");
+            TGCN_REQUIRE((uint64_t)n_src_rows * (uint64_t)d * 4u < (1ull << 32), "row groups need a gathered table below 4 GB");
+            const int2 *g2 = reinterpret_cast<const int2 *>(plan->direct_groups);
+            const int ggrid = (plan->n_seg_rows + plan->n_direct_groups + 3) / 4;
+            if (d == 64)
+                hipLaunchKernelGGL((k_spmm_reduce_groups<1>), dim3(ggrid), dim3(256), 0, s, a, plan->seg_rows, plan->row_slot_ptr, plan->row_slots, plan->n_seg_rows, g2, plan->n_direct_groups);
+            else if (d == 128)
+                hipLaunchKernelGGL((k_spmm_reduce_groups<2>), dim3(ggrid), dim3(256), 0, s, a, plan->seg_rows, plan->row_slot_ptr, plan->row_slots, plan->n_seg_rows, g2, plan->n_direct_groups);
+            else
+                hipLaunchKernelGGL((k_spmm_reduce_groups<4>), dim3(ggrid), dim3(256), 0, s, a, plan->seg_rows, plan->row_slot_ptr, plan->row_slots, plan->n_seg_rows, g2, plan->n_direct_groups);
+            return check_launch("k_spmm_reduce_groups");
         }
         const int rgrid = (plan->n_seg_rows + n_direct + 3) / 4;
         if (d == 64)

@@ -115,6 +115,12 @@ __global__ __launch_bounds__(256) void k_bpr_pairs(const BprArgs a)
     if (r >= a.b)
         return;
     const int n_slab = (a.d + kWave - 1) / kWave;
+    if (a.users[r] < 0) {   // a padded row (ragged per-user triple lists kept dense): no term, no gradient
+        if (lane == 0 && a.terms)
+            for (int j = 0; j < a.m; ++j)
+                a.terms[(size_t)j * a.b + r] = 0.0f;
+        return;
+    }
     const size_t ur = (size_t)a.users[r] * a.d, pr = (size_t)a.pos[r] * a.d;
     float u[kMaxSlabs], p[kMaxSlabs], gu[kMaxSlabs];
     float dot = 0.0f;
@@ -187,6 +193,11 @@ __global__ __launch_bounds__(256) void k_reg_rows(const RegArgs a)
     const int r = uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (r >= a.b)
         return;
+    if (a.users[r] < 0) {   // padded row
+        if (lane == 0 && a.terms)
+            a.terms[r] = 0.0f;
+        return;
+    }
     float sq = 0.0f;
     const float coef = a.coef * (a.upstream ? *a.upstream : 1.0f);
     for (int t = 0; t < 2 + a.m; ++t) {

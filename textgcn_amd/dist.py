@@ -171,7 +171,12 @@ class ShardedPropagator:
     """
 
     def __init__(self, graph: NormGraph, rank, world, device, group=None, split_threshold=DEFAULT_SPLIT_THRESHOLD,
-                 local_spmm=None, balance='nnz', chunks=1, collective='auto', force_collective=False):
+                 local_spmm=None, balance='nnz', chunks=1, collective='auto', force_collective=False, segment='auto'):
+        """segment: 'auto' (default) = a row chunk whose gather table -- the other node kind's part of the layer table -- is a few
+        L2 sizes runs the XCD-affine segmented kernels, by the rule a whole-graph Propagator uses (propagate.segment_blocks_auto:
+        config 2 cut in two keeps its item rows segmented; config 4's tables are far too large either way); None = never.  Rows a
+        segment plan cuts are summed piecewise (normwise 1e-6 against the one-chain result, as on one GPU), so with segments a
+        P-rank result equals the 1-rank result to rounding, not bit for bit; exact=True ignores the plans and stays bit-identical."""
         self.rank, self.world = int(rank), int(world)
         self.device = resolve_device(device)
         self.group = group
@@ -200,17 +205,25 @@ class ShardedPropagator:
             elif collective != 'torch':
                 raise ValueError("collective must be 'auto', 'torch' or 'capi'")
         # local CSR blocks, one per row chunk, column ids remapped to table rows
+        self._segment = segment if self.device.type == 'cuda' else None
         self.csr_u = self._chunk_csrs(graph, self.lay_u, 0, lambda c: self.u_pad + self.lay_i.table_rows(c - graph.n_users),
-                                      split_threshold)
-        self.csr_i = self._chunk_csrs(graph, self.lay_i, graph.n_users, self.lay_u.table_rows, split_threshold)
+                                      split_threshold, (self.u_pad, self.n_pad))
+        self.csr_i = self._chunk_csrs(graph, self.lay_i, graph.n_users, self.lay_u.table_rows, split_threshold, (0, self.u_pad))
         self.nnz_local = sum(c.nnz for c in self.csr_u) + sum(c.nnz for c in self.csr_i)
         self._buf = {}
         self._item_order = None
         self.record_events = False
         self._events = None
+        self._skip = None            # phase_times(): 'spmm' / 'gather' leaves that half of forward() out
 
     # ------------------------------------------------------------------ construction
-    def _chunk_csrs(self, graph, lay, row_origin, remap, split_threshold):
+    def segment_note(self):
+        """which of this rank's row chunks run the segmented kernels (known once a forward has built the plans)"""
+        blocks = [c.segment_blocks for c in self.csr_u + self.csr_i if c.segment_blocks]
+        on = sum(1 for b in blocks if any(b))
+        return 'none' if not on else f'{on} of {len(self.csr_u) + len(self.csr_i)} row chunks on this rank (tgcn_spmm_segmented_f32)'
+
+    def _chunk_csrs(self, graph, lay, row_origin, remap, split_threshold, col_range):
         g0 = row_origin + int(lay.bounds[self.rank])
         g1 = row_origin + int(lay.bounds[self.rank + 1])
         out = []
@@ -222,7 +235,9 @@ class ShardedPropagator:
             if len(rp) - 1 < lay.cb:   # pad rows: empty
                 rp = np.concatenate([rp, np.full(lay.cb - (len(rp) - 1), rp[-1], dtype=np.int64)])
             cols = remap(np.asarray(ci, dtype=np.int64)) if len(ci) else np.zeros(0, dtype=np.int64)
-            out.append(DeviceCSR(rp, cols, va, self.n_pad, self.device, split_threshold))
+            out.append(DeviceCSR(rp, cols, va, self.n_pad, self.device, split_threshold,
+                                 block_specs=[(0, lay.cb, col_range[0], col_range[1])] if self._segment else None,
+                                 segment=self._segment))
         return out
 
     def user_range(self, r=None):
@@ -255,7 +270,7 @@ class ShardedPropagator:
     def _all_gather(self, full, local):
         """full [P*cb, d] <- the [cb, d] blocks of every rank; `local` is the view of `full` at this rank's offset.
         Asynchronous where the backend allows; returns a handle with wait()."""
-        if not self.uses_collective:
+        if not self.uses_collective or self._skip == 'gather':
             return _Done()
         if self._capi_comm is not None:
             return self._capi_comm.all_gather(full, local)
@@ -267,6 +282,36 @@ class ShardedPropagator:
         dist.all_gather_into_tensor(host_full, host_local, group=self.group)
         full.copy_(host_full.to(full.device))
         return _Done()
+
+    def _launch(self, *a, **kw):
+        if self._skip != 'spmm':
+            self._spmm(*a, **kw)
+
+    def phase_times(self, e0_u, e0_i, n_layers, reps=3, exact=False):
+        """The two halves of forward() ALONE on this rank, same buffers, same launches: per layer k (1..K) the milliseconds of its
+        SpMM launches with every all-gather left out (`spmm_alone_ms`) and the milliseconds its all-gathers take with every SpMM
+        left out (`allgather_alone_ms`: the gathers layer k issues, waited for right behind them), HIP events on the launch
+        stream, mean of `reps` passes.  The tables hold stale rows meanwhile (timing only); the next forward() rewrites them.
+        max(sum of the two) / the measured forward = how much of the shorter half the pipeline hides."""
+        out = {}
+        keep = self.record_events
+        self.record_events = True
+        try:
+            for what, key, field in (('gather', 'spmm_alone_ms', 'compute_ms'), ('spmm', 'allgather_alone_ms', 'wait_on_gather_ms')):
+                self._skip = what
+                tot = [0.0] * (n_layers + 2)
+                for _ in range(reps):
+                    self.forward(e0_u, e0_i, n_layers, exact=exact)
+                    for rec in self.layer_times():
+                        tot[rec['layer']] += rec[field]
+                if what == 'gather':
+                    out[key] = [round(tot[k] / reps, 3) for k in range(1, n_layers + 1)]
+                else:   # the gathers layer k issues are waited for at the start of layer k + 1 (or at the end of the forward)
+                    out[key] = [round(tot[k + 1] / reps, 3) for k in range(1, n_layers + 1)]
+        finally:
+            self._skip = None
+            self.record_events = keep
+        return out
 
     @staticmethod
     def _wait(works):
@@ -341,9 +386,9 @@ class ShardedPropagator:
                     full, mine = yu_chunks[c]
                     r = rows_u[c]
                     if single:
-                        self._spmm(self.csr_u[c], x, y=b['out_u'][r] if last else mine, exact=exact)
+                        self._launch(self.csr_u[c], x, y=b['out_u'][r] if last else mine, exact=exact)
                     else:
-                        self._spmm(self.csr_u[c], x, y=None if last else mine, acc_in=e0_u[r] if k == 1 else acc_u[r],
+                        self._launch(self.csr_u[c], x, y=None if last else mine, acc_in=e0_u[r] if k == 1 else acc_u[r],
                                    acc_out=b['out_u'][r] if last else acc_u[r], acc_div=div, exact=exact)
                     if not last:   # users stay where they live after the last layer
                         works.append(self._all_gather(full, mine))
@@ -359,10 +404,10 @@ class ShardedPropagator:
                     full, mine = yi_chunks[c]
                     r = rows_i[c]
                     if single:
-                        self._spmm(self.csr_i[c], x, y=mine, exact=exact)
+                        self._launch(self.csr_i[c], x, y=mine, exact=exact)
                     else:
                         # on the last layer the item block of the *mean* is what gets gathered: write it into the table
-                        self._spmm(self.csr_i[c], x, y=None if last else mine, acc_in=e0_i[r] if k == 1 else acc_i[r],
+                        self._launch(self.csr_i[c], x, y=None if last else mine, acc_in=e0_i[r] if k == 1 else acc_i[r],
                                    acc_out=mine if last else acc_i[r], acc_div=div, exact=exact)
                     works.append(self._all_gather(full, mine))
                 self._mark(k, 'compute_end')

@@ -165,6 +165,58 @@ def split_plan_arrays(rowptr, threshold):
     }
 
 
+def row_groups(rowptr, rows=None, threshold=None, max_rows=8, target_entries=64, longest_first=False, single_len=32, phases=None):
+    """Groups of CONSECUTIVE rows for tgcn_spmm_groups_f32 (include/tgcn.h): int32 [n_groups, 2] = (first row, rows).
+
+    rows: the ascending row ids to cover (None: every row); rows with more than `threshold` entries are left out (the split
+    plan's chunk waves own them).  A group is a run of consecutive covered rows whose entries START inside one window of
+    `target_entries` consecutive stored entries, at most `max_rows` of them -- so a group holds about target_entries entries
+    (a row that starts in the window brings all of its entries along), one wave's worth of a few gather batches.  A row
+    of `single_len` entries or more is a group of its own (the kernel walks it as one wave per row: its round trips are
+    already amortised, config 2's 50-entry rows lose 5 % in shared groups).
+    longest_first: groups sorted by entry count, descending (the launch's tail is its last long group).
+    phases: optional row boundaries [r_0 < r_1 < ...]: no group crosses one, and with longest_first the groups are sorted INSIDE
+    each range [r_j, r_j+1), the ranges handed out last to first -- row blocks that share a gather table (item rows, then user
+    rows) stay together, so the waves in flight gather from ONE table."""
+    rowptr = np.asarray(rowptr, dtype=np.int64)
+    n = len(rowptr) - 1
+    lens = np.diff(rowptr)
+    if rows is None:
+        cover = np.ones(n, dtype=bool)
+    else:
+        cover = np.zeros(n, dtype=bool)
+        cover[np.asarray(rows, dtype=np.int64)] = True
+    if threshold is not None:
+        cover &= lens <= threshold
+    idx = np.nonzero(cover)[0]
+    if len(idx) == 0:
+        return np.zeros((0, 2), dtype=np.int32)
+    win = rowptr[idx] // int(target_entries)
+    new = np.ones(len(idx), dtype=bool)
+    new[1:] = (np.diff(idx) != 1) | (np.diff(win) != 0)       # a gap in the covered rows, or the next window
+    ph = None
+    if phases is not None and len(phases):
+        ph = np.searchsorted(np.asarray(phases, dtype=np.int64), idx, side='right')
+        new[1:] |= np.diff(ph) != 0
+    run = np.cumsum(new) - 1
+    pos = np.arange(len(idx)) - np.nonzero(new)[0][run]        # position inside the run
+    new |= (pos % int(max_rows)) == 0
+    if single_len:
+        single = lens[idx] >= int(single_len)
+        new |= single
+        new[1:] |= single[:-1]
+    first = idx[new]
+    cnt = np.diff(np.append(np.nonzero(new)[0], len(idx)))
+    groups = np.stack([first, cnt], axis=1)
+    if longest_first:
+        ent = rowptr[first + cnt] - rowptr[first]
+        if ph is None:
+            groups = groups[np.argsort(-ent, kind='stable')]
+        else:
+            groups = groups[np.lexsort((-ent, -ph[new]))]       # last phase first, longest first inside a phase
+    return np.ascontiguousarray(groups.astype(np.int32))
+
+
 def segment_plan_arrays(rowptr, colidx, vals, phases, tile_entries=256, n_classes=8, min_row_len=0):
     """Host arrays of a tgcn_segment_plan_t (XCD-affine column blocking, include/tgcn.h).
 

@@ -174,7 +174,8 @@ class LTRLinear(LightGCN):
     def _pair_ids(self, users, items, n_rows):
         """contiguous int64 device ids inside the tables (the kernel reads text rows by raw id): any integer dtype, any device;
         an id outside its table raises IndexError as the reference's tensor indexing would (checked on the host copy the ids
-        arrive as, or -- device ids -- clamped here and reported by fit()'s flag read, like get_loss's)."""
+        arrive as, or -- device ids -- clamped here and reported by fit()'s flag read, like get_loss's; outside a training
+        epoch the flag is read right here)."""
         out = []
         for ids, lim in ((users, self.n_users), (items, self.n_items)):
             ids = torch.as_tensor(ids)
@@ -187,7 +188,10 @@ class LTRLinear(LightGCN):
             else:
                 ids = ids.to(self.device, torch.int64)
                 bad = ((ids < 0) | (ids >= lim)).any()
-                self._bad_ids = bad if getattr(self, '_bad_ids', None) is None else (self._bad_ids | bad)
+                if getattr(self, '_in_epoch', False):   # fit(): the flag is read with the step's NaN flag (no extra sync)
+                    self._bad_ids = bad if getattr(self, '_bad_ids', None) is None else (self._bad_ids | bad)
+                elif bool(bad):                          # anywhere else nobody would read it: one flag read, then raise
+                    raise IndexError('score_pairwise: id outside its table')
                 ids = ids.clamp(0, lim - 1)
             out.append(ids.reshape(-1).contiguous())
         return out

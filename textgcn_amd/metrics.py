@@ -59,7 +59,8 @@ def true_lists_csr(y_true):
 def ranking_metrics_device(true_ptr, true_items, pred, ks, n_items):
     """The same numbers from device tensors: true_ptr int64 [n+1] / true_items int64 (CSR of the relevant lists, rows in
     the order of `pred`'s rows), pred int64 [n, kmax] ranked DISTINCT item ids per row (what a top-k returns; with distinct
-    predictions the reference's intersect1d / isin pair reduces to a membership test per position); n_items bounds the ids.
+    predictions the reference's intersect1d / isin pair reduces to a membership test per position); n_items bounds the ids, and
+    an entry outside [0, n_items) means "no item" and counts as a miss.
     float64 on the device; only the 5 x len(ks) means cross to the host."""
     import torch
     n, kmax = pred.shape
@@ -70,7 +71,9 @@ def ranking_metrics_device(true_ptr, true_items, pred, ks, n_items):
     span = int(n_items)
     rows_true = torch.repeat_interleave(torch.arange(n, device=dev), true_ptr[1:] - true_ptr[:-1], output_size=int(true_items.numel()))
     keys_true = torch.sort(rows_true * span + true_items)[0]
-    keys_pred = torch.arange(n, device=dev)[:, None] * span + pred
+    # an id outside [0, n_items) is "no item" (TGCN_NO_ITEM = 2^31 - 1 fills the list positions of a row with fewer than k
+    # rankable scores, include/tgcn.h): it must never match -- as a key it would land in ANOTHER user's range
+    keys_pred = torch.where((pred >= 0) & (pred < span), torch.arange(n, device=dev)[:, None] * span + pred, torch.full_like(pred, -1))
     if keys_true.numel():
         pos = torch.searchsorted(keys_true, keys_pred.reshape(-1)).clamp_(max=keys_true.numel() - 1)
         rel = (keys_true[pos] == keys_pred.reshape(-1)).reshape(n, kmax).to(torch.float64)

@@ -17,6 +17,7 @@ dropout keeps the CSR structure, zeroing values (K10).
 import logging
 import os
 import shutil
+import weakref
 from collections import defaultdict
 
 import numpy as np
@@ -72,6 +73,34 @@ def _backward_propagate(model, grad, vals_t):
     return x
 
 
+class _MatrixHandle:
+    """The model's own matrix as `representation` hands it to `layer_aggregation` when only `layer_combination` is overridden:
+    the engine's CSR + the call's values (edge dropout) and their transpose.  Not a tensor: an override of
+    `layer_aggregation` gets a torch sparse COO tensor instead, as in the reference."""
+
+    def __init__(self, csr, vals=None, vals_t=None):
+        self.csr, self.vals, self.vals_t = csr, vals, vals_t
+
+
+class _Spmm(torch.autograd.Function):
+    """y = A . emb for one `layer_aggregation` call (base_model.py:148) with autograd: backward = A^T . g -- the same kernel
+    on the transposed values (the model's matrix: same structure) or on the transposed CSR (a matrix the caller brought)."""
+
+    @staticmethod
+    def forward(ctx, emb, model, csr, vals, transposed):
+        ctx.model, ctx.transposed = model, transposed
+        y = torch.empty((csr.n_rows, emb.shape[1]), dtype=torch.float32, device=emb.device)
+        spmm(csr, emb.detach().contiguous(), y=y, exact=model.exact, vals=vals)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad):
+        csr_t, vals_t = ctx.transposed()
+        g = torch.empty((csr_t.n_rows, grad.shape[1]), dtype=torch.float32, device=grad.device)
+        spmm(csr_t, grad.contiguous(), y=g, exact=ctx.model.exact, vals=vals_t)
+        return g, None, None, None, None
+
+
 class _BprStep(torch.autograd.Function):
     """get_loss (base_model.py:181-210) as ONE autograd node on the native path: K-layer propagation (tgcn_spmm_*), BPR
     pair terms (tgcn_bpr_pairs_f32), L2 terms (tgcn_reg_rows_f32); backward = gradient scatter of the pairs into a zeroed
@@ -79,7 +108,10 @@ class _BprStep(torch.autograd.Function):
     tensor, and autograd's upstream factor reaches the kernels as a device scalar (no host round trip)."""
 
     @staticmethod
-    def forward(ctx, wu, wi, model, cols):
+    def forward(ctx, wu, wi, model, cols, n_real=None):
+        """cols [2 + m, b] int64 (users, positives, negatives...).  n_real: None, or a DEVICE scalar = the number of rows whose
+        user id is not negative -- rows with a negative user id are padding (the kernels skip them) and the means run over the
+        n_real real rows (AdvSamplModel keeps its ragged triple lists dense on the device this way)."""
         lib = _capi.lib()
         dev = model.device
         stream = _capi.current_stream(dev)
@@ -96,8 +128,15 @@ class _BprStep(torch.autograd.Function):
         reg_terms = torch.empty((b,), dtype=torch.float32, device=dev)
         _capi.check(lib.tgcn_reg_rows_f32(_capi.ptr(e0[:n_u]), _capi.ptr(e0[n_u:]), _capi.ptr(users), _capi.ptr(pos), _capi.ptr(negs),
                                           b, m, d, 0.0, None, _capi.ptr(reg_terms), None, None, stream), 'tgcn_reg_rows_f32')
-        bpr = terms.sum() / float(b * m)
-        reg = reg_terms.sum() * (model.reg_lambda / (2.0 * b))
+        if n_real is None:
+            bpr = terms.sum() / float(b * m)
+            reg = reg_terms.sum() * (model.reg_lambda / (2.0 * b))
+            ctx.rescale = None
+        else:
+            n_real = n_real.to(torch.float32).clamp(min=1.0)
+            bpr = terms.sum() / (n_real * float(m))
+            reg = reg_terms.sum() * (model.reg_lambda / 2.0) / n_real
+            ctx.rescale = float(b) / n_real          # the kernels divide their gradients by b (x m): corrected through *upstream
         ctx.model, ctx.out, ctx.vals_t, ctx.cols, ctx.e0 = model, out, drop[1], cols, e0
         return bpr, reg
 
@@ -110,6 +149,8 @@ class _BprStep(torch.autograd.Function):
         b, m = cols.shape[1], cols.shape[0] - 2
         g_bpr = g_bpr.to(torch.float32).contiguous()
         g_reg = g_reg.to(torch.float32).contiguous()
+        if ctx.rescale is not None:
+            g_bpr, g_reg = (g_bpr * ctx.rescale).contiguous(), (g_reg * ctx.rescale).contiguous()
         grad = torch.zeros_like(e0)
         scale = 1.0 if (model._single or K == 0) else 1.0 / float(K + 1)     # the layer mean's factor, folded into the scatter
         _capi.check(lib.tgcn_bpr_pairs_f32(_capi.ptr(out[:n_u]), _capi.ptr(out[n_u:]), _capi.ptr(cols[0]), _capi.ptr(cols[1]),
@@ -120,7 +161,7 @@ class _BprStep(torch.autograd.Function):
                                           _capi.ptr(cols[2:]), b, m, d, model.reg_lambda / b, _capi.ptr(g_reg), None,
                                           _capi.ptr(de0[:n_u]), _capi.ptr(de0[n_u:]), stream), 'tgcn_reg_rows_f32')
         ctx.out = None
-        return de0[:n_u], de0[n_u:], None, None
+        return de0[:n_u], de0[n_u:], None, None, None
 
 
 class LightGCN(nn.Module):
@@ -177,7 +218,9 @@ class LightGCN(nn.Module):
     def _copy_dataset_params(self, dataset):
         self.n_users = dataset.n_users
         self.n_items = dataset.n_items
-        self.norm_matrix = dataset.norm_matrix if not hasattr(dataset, 'graph') else None   # reference container (lazy in ours)
+        # the reference's container (base_model.py:57): a torch sparse COO tensor.  A dataset of ours builds it lazily
+        # (interactions.py), so it is only fetched when somebody asks for it (`norm_matrix` property below)
+        self._norm_matrix = dataset.norm_matrix if not hasattr(dataset, 'graph') else None
         self._dataset = dataset
         self.true_test_lil = dataset.true_test_lil
         self.train_user_dict = dataset.train_user_dict
@@ -303,24 +346,152 @@ class LightGCN(nn.Module):
 
     # ------------------------------------------------------------------ forward (base_model.py:93-106)
     @property
+    def norm_matrix(self):
+        """base_model.py:57: the normalised Laplacian as a torch sparse COO tensor (the reference's container).  The HIP path
+        reads its own CSR of the same matrix; this tensor exists for callers and overrides that want the reference's object.
+        Built on first use from the dataset's tensor or from the graph, on the model's device; `layer_aggregation` recognises
+        it and uses the engine's CSR without converting anything."""
+        if self._norm_matrix is None:
+            ds_nm = getattr(self._dataset, 'norm_matrix', None)
+            if ds_nm is not None:
+                self._norm_matrix = ds_nm
+            else:
+                idx, val = self.graph.to_coo()
+                self._norm_matrix = torch.sparse_coo_tensor(torch.from_numpy(idx), torch.from_numpy(np.array(val)),
+                                                            (self.graph.n, self.graph.n), is_coalesced=True)
+        return self._norm_matrix
+
+    @norm_matrix.setter
+    def norm_matrix(self, value):
+        self._norm_matrix = value
+
+    def _overridden(self, name):
+        """True when `name` is not LightGCN's own member any more: replaced on the instance (the reference rebinds members that
+        way, ltr_models.py:177-179) or overridden by a subclass (rejected_models.py:27-39).  `--single`'s own rebinding of
+        layer_combination (base_model.py:51-52) is not an override."""
+        own = self.__dict__.get(name)
+        if own is not None:
+            if name == 'layer_combination' and getattr(own, '__func__', None) is LightGCN.layer_combination_single \
+                    and getattr(own, '__self__', None) is self:
+                return type(self).layer_combination_single is not LightGCN.layer_combination_single
+            return True
+        return getattr(type(self), name) is not getattr(LightGCN, name)
+
+    @property
     def representation(self):
+        """base_model.py:93-106.  With LightGCN's own layer_aggregation and layer_combination the K products and the layer
+        mean run fused (one engine call, one autograd node).  When either member is overridden -- on a subclass or on the
+        instance -- the reference's loop runs THROUGH the overrides: layer_aggregation(norm_matrix, E^k) K times, then
+        layer_combination([E^0..E^K]); an overridden layer_aggregation receives a torch sparse COO tensor (the dropped matrix
+        in training), as the reference's would."""
         e0 = self._e0()
         if self.training and self.dropout > 0:
             vals, vals_t = self._dropout_values()
         else:
             vals = vals_t = None   # A is symmetric: A^T = A
+        agg_custom, comb_custom = self._overridden('layer_aggregation'), self._overridden('layer_combination')
+        if agg_custom or comb_custom:
+            if agg_custom:
+                matrix = self.norm_matrix if vals is None else self._dropped_coo(vals, vals_t)
+                if matrix.device != self.device:
+                    matrix = self._norm_matrix = self._register_matrix(matrix.to(self.device), _MatrixHandle(self._engine.csr))
+            else:
+                matrix = _MatrixHandle(self._engine.csr, vals, vals_t)
+            current = e0
+            cache = [current]
+            for _ in range(self.n_layers):
+                current = self.layer_aggregation(matrix, current)
+                cache.append(current)
+            return torch.split(self.layer_combination(cache), [self.n_users, self.n_items])
         if torch.is_grad_enabled() and e0.requires_grad:
             out = _Propagate.apply(e0, self, vals, vals_t)
         else:
             out = self._engine.forward(e0.detach(), self.n_layers, single=self._single, exact=self.exact, vals=vals)
         return torch.split(out, [self.n_users, self.n_items])
 
+    def _coo_indices(self):
+        if getattr(self, '_coo_idx_dev', None) is None:
+            self._coo_idx_dev = torch.from_numpy(self.graph.to_coo()[0]).to(self.device)
+        return self._coo_idx_dev
+
+    def _dropped_coo(self, vals, vals_t):
+        """base_model.py:77-86 as a tensor, for an overridden layer_aggregation: the kept entries of this step's mask (their
+        values already divided by 1 - p), coalesced order.  Registered, so that a `super().layer_aggregation(...)` inside the
+        override runs on the engine's CSR with the same values instead of converting the tensor."""
+        keep = vals.vals != 0          # stored values are products of positive factors: a zero is a dropped entry
+        idx = self._coo_indices()
+        n = self.graph.n
+        m = torch.sparse_coo_tensor(idx[:, keep], vals.vals[keep], (n, n), is_coalesced=True)
+        return self._register_matrix(m, _MatrixHandle(self._engine.csr, vals, vals_t))
+
+    def _register_matrix(self, tensor, resolved):
+        cache = self.__dict__.setdefault('_matrix_cache', {})
+        for key in [k for k, (ref, _) in cache.items() if ref() is None]:
+            del cache[key]
+        while len(cache) >= 8:
+            del cache[next(iter(cache))]
+        cache[id(tensor)] = (weakref.ref(tensor), resolved)
+        return tensor
+
+    def _resolve_matrix(self, norm_matrix):
+        """what `layer_aggregation` multiplies by: (DeviceCSR, per-call values or None, callable -> (transposed CSR, values))."""
+        if isinstance(norm_matrix, _MatrixHandle):
+            h = norm_matrix
+            return h.csr, h.vals, (lambda: (h.csr, h.vals_t))
+        if isinstance(norm_matrix, DeviceCSR):
+            if norm_matrix is self._engine.csr:
+                return norm_matrix, None, (lambda: (norm_matrix, None))
+            return norm_matrix, None, self._transposer(norm_matrix)
+        if isinstance(norm_matrix, torch.Tensor) and norm_matrix.layout in (torch.sparse_coo, torch.sparse_csr):
+            if norm_matrix is self._norm_matrix:       # the model's own matrix: the engine's CSR is built from it
+                return self._engine.csr, None, (lambda: (self._engine.csr, None))
+            hit = self.__dict__.get('_matrix_cache', {}).get(id(norm_matrix))
+            if hit is not None and hit[0]() is norm_matrix:
+                r = hit[1]
+                return self._resolve_matrix(r) if isinstance(r, (_MatrixHandle, DeviceCSR)) else r
+            if norm_matrix.dim() != 2 or norm_matrix.dtype != torch.float32:
+                raise TypeError(f'layer_aggregation: norm_matrix must be a 2-D float32 sparse tensor, got {tuple(norm_matrix.shape)} '
+                                f'{norm_matrix.dtype}')
+            coo = (norm_matrix.detach() if norm_matrix.layout == torch.sparse_coo else norm_matrix.detach().to_sparse_coo()).coalesce()
+            idx = coo.indices().cpu().numpy()
+            val = coo.values().cpu().numpy()
+            n_rows, n_src = int(norm_matrix.shape[0]), int(norm_matrix.shape[1])
+            rowptr = np.zeros(n_rows + 1, dtype=np.int64)
+            np.cumsum(np.bincount(idx[0], minlength=n_rows), out=rowptr[1:])
+            csr = DeviceCSR(rowptr, idx[1], val, n_src, self.device, self._split_threshold)
+            self._register_matrix(norm_matrix, csr)
+            return csr, None, self._transposer(csr)
+        raise TypeError('layer_aggregation: norm_matrix must be a torch sparse tensor (COO or CSR, float32) or a DeviceCSR, got '
+                        f'{type(norm_matrix).__name__}')
+
+    def _transposer(self, csr):
+        """lazily built CSR of the transpose of a matrix the caller brought (only a backward pass needs it)"""
+        def make():
+            t = getattr(csr, '_transposed', None)
+            if t is None:
+                import scipy.sparse as sp
+                m = sp.csr_matrix((csr.vals.cpu().numpy()[:csr.nnz], csr.colidx.cpu().numpy()[:csr.nnz].astype(np.int64),
+                                   csr.rowptr.cpu().numpy().astype(np.int64)), shape=(csr.n_rows, csr.n_src_rows))
+                mt = m.transpose().tocsr()
+                mt.sort_indices()
+                t = csr._transposed = DeviceCSR(mt.indptr.astype(np.int64), mt.indices, mt.data.astype(np.float32), csr.n_rows,
+                                                self.device, self._split_threshold)
+            return t, None
+        return make
+
     def layer_aggregation(self, norm_matrix, emb_matrix):
-        """base_model.py:141-148.  `norm_matrix` is accepted for signature compatibility; the product always uses
-        the model's CSR (the same matrix) unless a NormGraph / DeviceCSR is passed explicitly."""
-        csr = norm_matrix if isinstance(norm_matrix, DeviceCSR) else self._engine.csr
-        y = torch.empty_like(emb_matrix)
-        spmm(csr, emb_matrix.contiguous(), y=y, exact=self.exact)
+        """base_model.py:141-148: `torch.sparse.mm(norm_matrix, emb_matrix)` on the HIP path, with the matrix the CALLER passes:
+        a torch sparse tensor (COO as the reference builds it, or CSR; converted to a device CSR once and remembered by
+        identity -- the model's own `norm_matrix` and the dropped matrix `representation` hands out need no conversion), or a
+        DeviceCSR.  Anything else is a TypeError.  Differentiable in emb_matrix."""
+        csr, vals, transposed = self._resolve_matrix(norm_matrix)
+        if not isinstance(emb_matrix, torch.Tensor) or emb_matrix.dim() != 2 or emb_matrix.shape[0] != csr.n_src_rows:
+            raise ValueError(f'layer_aggregation: emb_matrix must be [{csr.n_src_rows}, d], got '
+                             f'{tuple(getattr(emb_matrix, "shape", ()))}')
+        if torch.is_grad_enabled() and emb_matrix.requires_grad:
+            return _Spmm.apply(emb_matrix, self, csr, vals, transposed)
+        y = torch.empty((csr.n_rows, emb_matrix.shape[1]), dtype=torch.float32, device=emb_matrix.device)
+        spmm(csr, emb_matrix.detach().contiguous(), y=y, exact=self.exact, vals=vals)
         return y
 
     def layer_combination(self, vectors):
@@ -378,7 +549,10 @@ class LightGCN(nn.Module):
         d64 = data.to(self.device, torch.int64)
         lim = lim.to(self.device)
         bad = ((d64 < 0) | (d64 >= lim)).any()
-        self._bad_ids = bad if getattr(self, '_bad_ids', None) is None else (self._bad_ids | bad)
+        if getattr(self, '_in_epoch', False):
+            self._bad_ids = bad if getattr(self, '_bad_ids', None) is None else (self._bad_ids | bad)
+        elif bool(bad):        # get_loss called outside fit(): nobody would read the flag later
+            raise IndexError('get_loss: a user or item id of the batch is outside its embedding table')
         return torch.minimum(d64.clamp_min(0), lim - 1).t().contiguous()
 
     def _native_loss(self):
@@ -387,6 +561,7 @@ class LightGCN(nn.Module):
         cls = type(self)
         plain = all(name not in self.__dict__ and getattr(cls, name) is getattr(LightGCN, name)
                     for name in ('score_pairwise', 'bpr_loss', 'reg_loss', 'representation'))
+        plain = plain and not self._overridden('layer_aggregation') and not self._overridden('layer_combination')
         return (plain and self.device.type == 'cuda' and self.emb_size <= 512 and torch.is_grad_enabled()
                 and self.embedding_user.weight.requires_grad and self.embedding_item.weight.requires_grad)
 
@@ -416,6 +591,13 @@ class LightGCN(nn.Module):
         self._loss_values = defaultdict(float)
         pending = None                     # deferred mode: the previous step's flags (device scalars)
         self._bad_ids = None
+        self._in_epoch = True              # device-id range flags raised inside the epoch are read with the NaN flag below
+        try:
+            self._run_epoch(batches, epoch, pending)
+        finally:
+            self._in_epoch = False
+
+    def _run_epoch(self, batches, epoch, pending):
 
         def stop_if(flags):
             nan, bad = flags
@@ -484,18 +666,19 @@ class LightGCN(nn.Module):
         return results
 
     def _chunk_masks(self, users, step):
-        """[(ids int64 [b], mask rowptr int32 [b + 1], mask items int32)] on the device for the consecutive `step`-user chunks of
-        `users`, cut out of the device mask CSR.  The whole call costs ONE host-to-device copy (the ids): the row pointers are
-        a device cumsum of counts read from the device CSR, a contiguous id range takes its items as a view, any other list by
-        one device gather; the host only does O(len(users)) numpy arithmetic on its copy of the row pointers (for the sizes)
-        and never waits for the GPU."""
+        """GENERATOR of (ids int64 [b], mask rowptr int32 [b + 1], mask items int32) on the device for the consecutive `step`-user
+        chunks of `users`, cut out of the device mask CSR.  The whole call costs ONE host-to-device copy (the ids), made up front
+        with the two row-pointer gathers; each chunk's own tensors -- a device cumsum for its row pointers, and for a
+        non-contiguous id list one device gather of its items -- are built when the chunk is asked for, i.e. under the
+        previous chunks' kernels, so only one chunk's gather is alive at a time and the first scoring call is issued before the
+        second chunk's mask exists.  The host only does O(len(users)) numpy arithmetic on its copy of the row pointers (for the
+        sizes) and never waits for the GPU."""
         rp = self._mask_rowptr_host
         rp_dev, items_dev = self._mask()
         ids_all = torch.from_numpy(np.ascontiguousarray(users)).to(self.device)
         start_all = rp_dev[ids_all]
         cnt_all = rp_dev[ids_all + 1] - start_all
         cnt_host = rp[users + 1] - rp[users]
-        out = []
         for j in range(0, len(users), step):
             batch = users[j:j + step]
             ids, cnt = ids_all[j:j + step], cnt_all[j:j + step]
@@ -509,15 +692,14 @@ class LightGCN(nn.Module):
             else:
                 shift = torch.repeat_interleave(start_all[j:j + step] - rowptr[:-1].to(torch.int64), cnt, output_size=total)
                 items = items_dev[shift + torch.arange(total, device=self.device)]
-            out.append((ids, rowptr, items))
-        return out
+            yield ids, rowptr, items
 
     def _batch_mask(self, batch_users, ids=None):
         """(mask rowptr, mask items) of one batch (see _chunk_masks)"""
         batch_users = np.asarray(batch_users, dtype=np.int64)
         if len(batch_users) == 0:
             return torch.zeros(1, dtype=torch.int32, device=self.device), torch.zeros(1, dtype=torch.int32, device=self.device)
-        _, rowptr, items = self._chunk_masks(batch_users, len(batch_users))[0]
+        _, rowptr, items = next(self._chunk_masks(batch_users, len(batch_users)))
         return rowptr, items
 
     @torch.no_grad()
@@ -579,7 +761,14 @@ class LightGCN(nn.Module):
     def _save_predictions(self, users, predictions, scores):
         """predictions.tsv in the reference's format (base_model.py:268-273): original ids, python-list cells."""
         import pandas as pd
-        pred_unmapped = [[self.item_mapping_dict[i] for i in row] for row in predictions]
+        # a row with fewer than k rankable (non-NaN) scores ends in (-inf, TGCN_NO_ITEM) fillers (include/tgcn.h): not items --
+        # they are left out of the row's lists (the reference's torch.topk would rank the NaN scores first there; its
+        # NaN-free loss assertion, base_model.py:123, keeps such tables out of a real run)
+        n_items = self.n_items
+        keep = [[0 <= i < n_items for i in row] for row in predictions]
+        pred_unmapped = [[self.item_mapping_dict[i] for i, k in zip(row, kp) if k] for row, kp in zip(predictions, keep)]
+        if scores:
+            scores = [[v for v, k in zip(row, kp) if k] for row, kp in zip(scores, keep)]
         users_unmapped = [self.user_mapping_dict[u] for u in users.tolist()]
         path = os.path.join(self.save_path, 'predictions.tsv')
         pd.DataFrame({'user_id': users_unmapped, 'y_pred': pred_unmapped, 'scores': scores}).to_csv(path, sep='\t', index=False)

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _capi
-from .graph import NormGraph, segment_plan_arrays, split_plan_arrays
+from .graph import NormGraph, row_groups, segment_plan_arrays, split_plan_arrays
 
 DEFAULT_SPLIT_THRESHOLD = 1024
 L2_SHARE_BYTES = 3 << 20        # of an XCD's 4 MB L2 that a gathered table can count on next to the streaming traffic
@@ -18,6 +18,8 @@ SEGMENT_CLASSES = 8             # one column-block class per XCD
 SEGMENT_TILE_ENTRIES = 256      # entries per tile wave.  One launch for tiles + direct rows: 512..1024 within 1 %, 256 -8 %, 2048 -30 %;
                                 # two launches (below): 192..256 best (0.555-0.557 ms per config-2 forward against 0.592), 128 / 320 +2 %
 SEGMENT_MIN_ROW_LEN = 48        # shorter rows stay direct: < 6 entries per block do not pay for a workspace slot (0 / 16: +7 %; 32..64 within 1 %)
+GROUP_TARGET_ENTRIES = 64       # stored entries per row group (one wave): four batches of 16 gathers
+GROUP_SINGLE_LEN = 32           # rows of this many entries or more are a group of their own
 SEGMENT_TWO_PHASE = True        # tiles alone (the XCDs' L2s hold only their block of the gathered table), then the piece reduce and the
                                 # direct rows side by side in a second launch (tgcn_spmm_segmented_f32 flags bit 16): config 2 -6 %, same bits
 
@@ -80,7 +82,10 @@ class DeviceCSR:
         # share of the launch: (longest work item) x (waves the chip runs at once) vs total entries.  On huge graphs
         # (config 4: 0.04) it only scatters the CSR reads (measured 5 % slower), so rows keep their natural order.
         longest = min(int(lens.max()) if len(lens) else 0, split_threshold or (1 << 30))
-        if order_rows and self.nnz and longest * 8192 > 0.1 * self.nnz:
+        self._rowptr_host = rowptr
+        self._groups = {}
+        self._longest_first = bool(order_rows and self.nnz and longest * 8192 > 0.1 * self.nnz)
+        if self._longest_first:
             order = np.argsort(-lens, kind='stable')
             if block_specs:
                 # one phase per row block that shares a gather table (item rows, then user rows), longest first inside
@@ -104,6 +109,7 @@ class DeviceCSR:
         self.segment_tile = SEGMENT_TILE_ENTRIES
         self.segment_min_row_len = SEGMENT_MIN_ROW_LEN
         self._segment_plans = {}
+        self.use_groups = True        # False: one wave per row everywhere (tools / A-B timing; same bits)
 
     @property
     def n_chunks(self):
@@ -121,6 +127,21 @@ class DeviceCSR:
                                        p['long_chunk_ptr'].data_ptr(), ws.data_ptr())
             self._plan_struct[d] = (st, ws)
         return ctypes.byref(self._plan_struct[d][0])
+
+    def groups(self, d, exact=False):
+        """device int32 [n_groups, 2] row groups for tgcn_spmm_groups_f32 at width d (None: width / table size not supported).
+        exact: no split plan -- every row, however long, is in a group (one chain per row)."""
+        if d not in (64, 128, 256) or self.n_src_rows * d * 4 >= (1 << 32) or self.n_rows == 0:
+            return None
+        thr = None if (exact or self._plan_host is None) else self._plan_host['threshold']
+        key = (4 if d == 256 else 8, thr)
+        if key not in self._groups:
+            phases = sorted({sp[0] for sp in self._block_specs} - {0}) if self._block_specs else None
+            g = row_groups(self._rowptr_host, None, thr, key[0], GROUP_TARGET_ENTRIES, longest_first=self._longest_first,
+                           single_len=GROUP_SINGLE_LEN, phases=phases)
+            self._groups[key] = torch.from_numpy(g).to(self.device) if len(g) else torch.zeros((1, 2), dtype=torch.int32, device=self.device)
+            self._groups[key, 'n'] = len(g)
+        return self._groups[key], self._groups[key, 'n']
 
     def configure_segments(self, blocks_per_spec, tile_entries=SEGMENT_TILE_ENTRIES, min_row_len=SEGMENT_MIN_ROW_LEN):
         """Set the XCD-affine segmentation by hand: blocks_per_spec[i] column blocks (a multiple of 8) for
@@ -156,21 +177,37 @@ class DeviceCSR:
                           for (r0, r1, c0, c1), nb in zip(self._block_specs, blocks) if nb]
                 h = segment_plan_arrays(rowptr, colidx, self.vals.cpu().numpy(), phases, self.segment_tile,
                                         min_row_len=self.segment_min_row_len)
+                n_dg = 0
+                if self.n_src_rows * d * 4 < (1 << 32) and len(h['direct_rows']):
+                    # natural row order, as the one-wave-per-row form hands the direct rows out (the tiles' pieces are reduced
+                    # beside them: nothing here is a tail)
+                    h['direct_groups'] = row_groups(rowptr, h['direct_rows'], None, 4 if d == 256 else 8, GROUP_TARGET_ENTRIES,
+                                                    single_len=GROUP_SINGLE_LEN, phases=[sp[0] for sp in self._block_specs if sp[0]])
+                    n_dg = len(h['direct_groups'])
+                    if n_dg == len(h['direct_rows']):      # every direct row a group of its own (config 2: 50-entry user rows):
+                        n_dg = 0                           # the one-wave-per-row launch does the same work without the group list
+                        del h['direct_groups']
                 dv = {k: torch.from_numpy(v).to(self.device) for k, v in h.items() if isinstance(v, np.ndarray)}
                 ws = torch.empty((max(h['n_slots'], 1), d), dtype=torch.float32, device=self.device)
                 st = _capi.SegmentPlanStruct(len(h['tile_meta']), h['tile_entries'], len(h['seg_rows']), len(h['direct_rows']),
                                              h['n_slots'], 0, dv['tile_meta'].data_ptr(), dv['ent_col'].data_ptr(),
                                              dv['ent_val'].data_ptr(), dv['ent_flags'].data_ptr(), dv['seg_rows'].data_ptr(),
                                              dv['row_slot_ptr'].data_ptr(), dv['row_slots'].data_ptr(),
-                                             dv['direct_rows'].data_ptr(), ws.data_ptr())
+                                             dv['direct_rows'].data_ptr(), ws.data_ptr(),
+                                             dv['direct_groups'].data_ptr() if n_dg else None, n_dg, 0)
                 entry = (st, ws, dv, h)
             self._segment_plans[d] = (entry, blocks)
         entry, blocks = self._segment_plans[d]
         self.segment_blocks = blocks
         if entry is None:
             return None
-        if vals is None:
+        if vals is None and (self.use_groups or not entry[0].n_direct_groups):
             return ctypes.byref(entry[0])
+        if vals is None:       # A/B switch: the plan without its direct-row groups
+            tmp = _capi.SegmentPlanStruct.from_buffer_copy(entry[0])
+            tmp.n_direct_groups = 0
+            self._segment_keep = (tmp, None)
+            return ctypes.byref(tmp)
         # per-call values (edge dropout, transposed values): the plan's streams get their own gathered copy, made once per
         # EdgeValues object (K forward + K backward launches share it)
         st, dv = entry[0], entry[2]
@@ -182,6 +219,8 @@ class DeviceCSR:
             ev = vals.index_select(0, dv['ent_src'])
         tmp = _capi.SegmentPlanStruct.from_buffer_copy(st)
         tmp.ent_val = ev.data_ptr()
+        if not self.use_groups:
+            tmp.n_direct_groups = 0
         self._segment_keep = (tmp, ev)     # alive until the next call on this CSR (the launch is stream-ordered after the gather)
         return ctypes.byref(tmp)
 
@@ -238,6 +277,14 @@ def spmm(csr, x, y=None, acc_in=None, acc_out=None, acc_div=1.0, exact=False, va
         _capi.check(rc, 'tgcn_spmm_segmented_f32')
         return y if y is not None else acc_out
     plan = None if exact else csr.plan(d)
+    grp = csr.groups(d, exact) if (variant == _capi.SPMM_AUTO and csr.use_groups) else None
+    if grp is not None:
+        rc = _capi.lib().tgcn_spmm_groups_f32(
+            _capi.ptr(csr.rowptr), _capi.ptr(csr.colidx), _capi.ptr(vals), csr.n_rows, _capi.ptr(x), csr.n_src_rows, d,
+            _capi.ptr(y), _capi.ptr(acc_in), _capi.ptr(acc_out), float(acc_div), plan, _capi.ptr(grp[0]), grp[1],
+            (unroll & 0xff) << 8, _capi.current_stream(dev))
+        _capi.check(rc, 'tgcn_spmm_groups_f32')
+        return y if y is not None else acc_out
     rc = _capi.lib().tgcn_spmm_csr_f32(
         _capi.ptr(csr.rowptr), _capi.ptr(csr.colidx), _capi.ptr(vals), csr.n_rows, _capi.ptr(x), csr.n_src_rows, d,
         _capi.ptr(y), _capi.ptr(acc_in), _capi.ptr(acc_out), float(acc_div), plan, _capi.ptr(csr.row_order),

@@ -97,6 +97,24 @@ def retired_positions(idx):
 
 
 _WORKSPACE = {}
+_PLAN_BYTES = {}    # (B, I, d, k) -> tgcn_score_topk_workspace_bytes
+_PACK_BYTES = {}    # (I, d) -> tgcn_item_pack_bytes
+_LAST_CALL = {}     # (device, slot) -> (B, I, d, k, prefilter) of the last score_topk call that used the slot's workspace
+
+
+def last_call(dev, slot=0):
+    """(B, I, d, k, prefilter) of the last score_topk call on (dev, slot), or None: what call_stats / fallback_count can be asked about"""
+    return _LAST_CALL.get((_capi.resolve_device(dev), slot))
+
+
+def _check_last_call(dev, slot, b, n_items, d, k, prefilter=None):
+    got = _LAST_CALL.get((dev, slot))
+    if got is None:
+        raise RuntimeError('no score_topk call has used this slot')
+    want = (int(b), int(n_items), int(d), int(min(k, MAX_K_PER_PASS)))
+    if got[:4] != want or (prefilter is not None and bool(prefilter) != got[4]):
+        raise ValueError(f'the last score_topk call on slot {slot} was (B, I, d, k, prefilter) = {got}, not {want + (prefilter,)}: its '
+                         'workspace offsets belong to that shape (a partial tail chunk?)')
 
 
 def _workspace(dev, nbytes, slot=0):
@@ -114,9 +132,8 @@ def fallback_count(dev, b, n_items, d, k, slot=0):
     """Users of the last score_topk call on (dev, slot) that took the exact fallback (diagnostic; synchronises)."""
     import ctypes
     dev = _capi.resolve_device(dev)
-    ws = _WORKSPACE.get((dev, slot)) if (dev, slot) in _WORKSPACE else None
-    if ws is None:
-        raise RuntimeError('no score_topk call has used this slot')
+    _check_last_call(dev, slot, b, n_items, d, k)
+    ws = _WORKSPACE[(dev, slot)]
     out = ctypes.c_int32(0)
     rc = _capi.lib().tgcn_score_topk_fallback_count(_capi.ptr(ws), b, n_items, d, int(min(k, MAX_K_PER_PASS)), ctypes.byref(out),
                                                     _capi.current_stream(dev))
@@ -129,9 +146,8 @@ def call_stats(dev, b, n_items, d, k, prefilter, slot=0):
     dict(fallback_users, kept_pairs, rescored_pairs, logged_pairs)."""
     import ctypes
     dev = _capi.resolve_device(dev)
-    ws = _WORKSPACE.get((dev, slot))
-    if ws is None:
-        raise RuntimeError('no score_topk call has used this slot')
+    _check_last_call(dev, slot, b, n_items, d, k, prefilter)
+    ws = _WORKSPACE[(dev, slot)]
     out = (ctypes.c_int64 * 4)()
     rc = _capi.lib().tgcn_score_topk_stats(_capi.ptr(ws), b, n_items, d, int(min(k, MAX_K_PER_PASS)), 1 if prefilter else 0, out,
                                            _capi.current_stream(dev))
@@ -175,6 +191,7 @@ def score_topk(users_emb, items_emb, k, user_ids=None, mask_rowptr=None, mask_it
     `prefilter`: find the candidates with the bf16 pass and rescore them in fp32 (tgcn_score_topk_prefilter_f32) -- the same
     result bit for bit; `item_pack` = item_pack(items_emb) when the table is shared by many calls."""
     dev = _dev(users_emb)
+    k = int(k)
     _f32c(users_emb, 'users_emb'), _f32c(items_emb, 'items_emb')
     if users_emb.shape[1] != items_emb.shape[1]:
         raise ValueError('users_emb / items_emb differ in width')
@@ -211,22 +228,38 @@ def score_topk(users_emb, items_emb, k, user_ids=None, mask_rowptr=None, mask_it
     val = torch.empty((b, k), dtype=torch.float32, device=dev)
     idx = torch.empty((b, k), dtype=torch.int64, device=dev)
     lib = _capi.lib()
-    need = lib.tgcn_score_topk_workspace_bytes(b, n_items, d, int(k))
-    ws = _workspace(dev, max(need, 256), slot)
+    # the call's plan depends on its shape alone: asked of the library once per (B, I, d, k), as is the pack's size per (I, d)
+    shape = (b, n_items, d, k)
+    need = _PLAN_BYTES.get(shape)
+    if need is None:
+        need = _PLAN_BYTES[shape] = max(int(lib.tgcn_score_topk_workspace_bytes(b, n_items, d, int(k))), 256)
+    ws = _WORKSPACE.get((dev, slot))
+    if ws is None or ws.numel() < need:
+        ws = _workspace(dev, need, slot)
+    _LAST_CALL[(dev, slot)] = (b, n_items, d, k, bool(prefilter))
+    # raw integers for the pointer arguments (argtypes are bound once, at load): no ctypes object per argument
+    mrp = 0 if mask_rowptr is None else mask_rowptr.data_ptr()
+    mit = 0 if mask_items is None else mask_items.data_ptr()
+    uid = 0 if user_ids is None else user_ids.data_ptr()
+    stream = _capi.raw_stream(dev)
     if prefilter:
-        if item_pack is not None and (item_pack.dtype != torch.uint8 or item_pack.numel() != lib.tgcn_item_pack_bytes(n_items, d)
-                                      or item_pack.device != dev or not item_pack.is_contiguous()):
-            raise TypeError('item_pack must be the uint8 tensor of item_pack(items_emb) on the same device')
-        rc = lib.tgcn_score_topk_prefilter_f32(_capi.ptr(users_emb), _capi.ptr(user_ids), b, _capi.ptr(items_emb), n_items, d,
-                                               _capi.ptr(mask_rowptr), _capi.ptr(mask_items), int(k), 1 if round4 else 0,
-                                               _capi.ptr(item_pack), _capi.ptr(val), _capi.ptr(idx), _capi.ptr(ws), ws.numel(),
-                                               _capi.current_stream(dev))
-        _capi.check(rc, 'tgcn_score_topk_prefilter_f32')
+        pk = 0
+        if item_pack is not None:
+            pb = _PACK_BYTES.get((n_items, d))
+            if pb is None:
+                pb = _PACK_BYTES[(n_items, d)] = int(lib.tgcn_item_pack_bytes(n_items, d))
+            if item_pack.dtype != torch.uint8 or item_pack.numel() != pb or item_pack.device != dev or not item_pack.is_contiguous():
+                raise TypeError('item_pack must be the uint8 tensor of item_pack(items_emb) on the same device')
+            pk = item_pack.data_ptr()
+        rc = lib.tgcn_score_topk_prefilter_f32(users_emb.data_ptr(), uid, b, items_emb.data_ptr(), n_items, d, mrp, mit, k,
+                                               1 if round4 else 0, pk, val.data_ptr(), idx.data_ptr(), ws.data_ptr(), ws.numel(), stream)
+        if rc:
+            _capi.check(rc, 'tgcn_score_topk_prefilter_f32')
         return val, idx
-    rc = lib.tgcn_score_topk_f32(_capi.ptr(users_emb), _capi.ptr(user_ids), b, _capi.ptr(items_emb), n_items, d,
-                                 _capi.ptr(mask_rowptr), _capi.ptr(mask_items), int(k), 1 if round4 else 0, _capi.ptr(val),
-                                 _capi.ptr(idx), _capi.ptr(ws), ws.numel(), _capi.current_stream(dev))
-    _capi.check(rc, 'tgcn_score_topk_f32')
+    rc = lib.tgcn_score_topk_f32(users_emb.data_ptr(), uid, b, items_emb.data_ptr(), n_items, d, mrp, mit, k, 1 if round4 else 0,
+                                 val.data_ptr(), idx.data_ptr(), ws.data_ptr(), ws.numel(), stream)
+    if rc:
+        _capi.check(rc, 'tgcn_score_topk_f32')
     return val, idx
 
 

@@ -31,7 +31,7 @@ def main():
     import bench
     from textgcn_amd.dist import ShardedPropagator
     t0 = time.time()
-    graph, e0, path = bench.shared_workload(args.workload, rank, dist.barrier)
+    graph, e0, path = bench.shared_workload(args.workload, rank, int(os.environ.get('LOCAL_RANK', rank)), dist.barrier)
     t_share = time.time() - t0
     sp = ShardedPropagator(graph, rank, world, 'cpu', local_spmm=lambda *a, **k: None, split_threshold=1024, chunks=args.chunks)
     eu, ei = sp.local_e0(e0)
