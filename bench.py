@@ -228,13 +228,14 @@ def random_row_rate(n_rows, d, dev, entries=1 << 23):
                     order_rows=False)
     x = torch.randn((n_rows, d), device=dev)
     y = torch.empty((n_out, d), device=dev)
+    from textgcn_amd._capi import SPMM_WAVE_PER_ROW      # (its own kernel name: a profile never mistakes the probe for a layer)
     for _ in range(2):
-        spmm(csr, x, y=y, exact=True)
+        spmm(csr, x, y=y, exact=True, variant=SPMM_WAVE_PER_ROW)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()
     reps = 5
     for _ in range(reps):
-        spmm(csr, x, y=y, exact=True)
+        spmm(csr, x, y=y, exact=True, variant=SPMM_WAVE_PER_ROW)
     ev1.record()
     ev1.synchronize()
     return len(cols) * 4.0 * d / (ev0.elapsed_time(ev1) / 1e3 / reps)
@@ -948,6 +949,46 @@ def run_sharded(args, world, rank, local_rank, dev, dev_index, rehearsal):
             mrp, mit = graph.train_mask()
             result['scoring'] = scoring_record(ue.contiguous(), ie.contiguous(), users_all, mrp, mit, n_i, d, dev, args, barrier, world=world,
                                                reduce_max_sum=reduce_max_sum, cpu=False, large=False)
+        if args.shard == 'rows' and not args.no_user_partition:
+            # the same forward under the USER partition (users never leave their rank; item rows are per-rank partial sums joined by
+            # one all-reduce of the item table per layer): timed the same way, checked against the row partition's output (equal to
+            # rounding: an item row is a sum of per-rank chains); the record's `value` stays the prescribed row partition's
+            from textgcn_amd.dist import UserShardedPropagator
+            ref_u, ref_tab = sp.forward(eu, ei, K, exact=args.exact, copy=True)
+            ref_i = sp.items_in_order(ref_tab)
+            del ref_tab
+            up = UserShardedPropagator(graph, rank, world, dev, split_threshold=thr, chunks=chunks, force_collective=args.force_sharded)
+            ueu, uei = up.local_e0(e0)
+
+            def step_users():
+                up.forward(ueu, uei, K, exact=args.exact)
+            tu_dev, tu_wall = time_steps(step_users, args.steps, args.warmup, barrier)
+            tu = reduce_max_sum([max(tu_wall, tu_dev)])[0][0]
+            got_u, got_i = up.forward(ueu, uei, K, exact=args.exact)
+            # the two partitions cut the users at the same nnz-balanced bounds: this rank's users are the same rows
+            n_mine = up.u1 - up.u0
+            err_i = float((got_i - ref_i).abs().max() / ref_i.abs().max())
+            err_u = float((got_u[:n_mine] - ref_u[:n_mine]).abs().max() / ref_u[:n_mine].abs().max()) if n_mine else 0.0
+            errs = reduce_max_sum([err_u, err_i])[0]
+            up.record_events = True
+            step_users()
+            lt = up.layer_times()
+            up.record_events = False
+            every = [None] * world
+            dist.all_gather_object(every, lt)
+            result['user_partition'] = {
+                'what': 'users partitioned (nnz-balanced), item table replicated: user rows local, item rows = per-rank partial sums joined '
+                        'by ONE all-reduce of [I, d] per layer (dist.UserShardedPropagator); equal to the row partition to rounding',
+                'value': args.steps * K * graph.nnz / tu, 'unit': 'edges/s', 'ms_per_step': tu / args.steps * 1e3,
+                'bytes_exchanged_per_layer_per_rank': int(2 * (world - 1) / max(world, 1) * n_i * d * 4),
+                'row_partition_bytes_received_per_layer_per_rank': int((world - 1) / max(world, 1) * graph.n * d * 4),
+                'vs_row_partition': {'normwise_max_err_users': errs[0], 'normwise_max_err_items': errs[1], 'bar': 1e-4,
+                                     'ok': bool(max(errs) <= 1e-4)},
+                'layers_max_over_ranks': [{'layer': m['layer'], 'compute_ms': round(max(r[j]['compute_ms'] for r in every), 3),
+                                           'wait_on_reduce_ms': round(max(r[j]['wait_on_reduce_ms'] for r in every), 3)}
+                                          for j, m in enumerate(lt)]}
+            del up, ueu, uei, ref_u, ref_i, got_u, got_i
+            torch.cuda.empty_cache()
         if rank == 0:
             print(json.dumps(result), flush=True)
     finally:
@@ -982,6 +1023,9 @@ def main():
     ap.add_argument('--shard', default='rows', choices=['rows', 'features'],
                     help="N > 1: 'rows' = 1-D row partition with per-layer RCCL all-gathers (the north-star design, default); "
                          "'features' = every rank holds all rows and d/N columns: no per-layer exchange, one all-gather at the end")
+    ap.add_argument('--no-user-partition', action='store_true',
+                    help='N > 1, --shard rows: do not ALSO time the user partition (users local, one all-reduce of the item table per '
+                         'layer: dist.UserShardedPropagator) in the same run')
     ap.add_argument('--feature-partition', action='store_true',
                     help='N > 1, --shard rows: ALSO time the forward under the feature (column) partition in the same run (a second '
                          'full-graph propagator per rank; off by default)')

@@ -52,7 +52,7 @@ def main():
     ap.add_argument('--collective', default='torch')
     ap.add_argument('--sample', type=int, default=0, help='save only this many seeded sample rows of each table (large graphs)')
     ap.add_argument('--graph-seed', type=int, default=1)
-    ap.add_argument('--shard', choices=['rows', 'features'], default='rows')
+    ap.add_argument('--shard', choices=['rows', 'features', 'users'], default='rows')
     ap.add_argument('--device-per-rank', action='store_true', help='--mode nccl on a multi-GPU box: rank r uses cuda:r')
     ap.add_argument('--split-threshold', type=int, default=64)
     ap.add_argument('--exact', action='store_true')
@@ -79,6 +79,21 @@ def main():
         full = cp.assemble(cp.forward(cp.local_e0(e0), args.layers, single=args.single))
         if args.rank == 0:
             np.savez(args.out, users=full[:args.n_users].cpu().numpy(), items=full[args.n_users:].cpu().numpy())
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    if args.shard == 'users':         # user partition: local user rows, partial item sums, one all-reduce of the item table per layer
+        from textgcn_amd.dist import UserShardedPropagator
+        if args.mode == 'cpu':
+            up = UserShardedPropagator(g, args.rank, args.world, 'cpu', local_spmm=oracle_spmm, split_threshold=None, chunks=args.chunks)
+        else:
+            up = UserShardedPropagator(g, args.rank, args.world, 'cuda:0' if args.mode != 'nccl' else 'cuda', split_threshold=args.split_threshold,
+                                       chunks=args.chunks, force_collective=(args.mode == 'nccl'))
+        eu, ei = up.local_e0(e0)
+        users_local, items = up.forward(eu, ei, args.layers, single=args.single, exact=(args.mode == 'cpu' or args.exact))
+        users_full = up.gather_users(users_local)
+        if args.rank == 0:
+            np.savez(args.out, users=users_full.cpu().numpy(), items=items.cpu().numpy(), user_bounds=up.bounds, nnz_local=up.nnz_local)
         dist.barrier()
         dist.destroy_process_group()
         return

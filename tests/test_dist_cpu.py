@@ -130,3 +130,42 @@ def test_forward_results_are_views_until_the_next_forward_and_copy_detaches_them
             want, _ = oracle.propagate(*g.to_coo(), e_a.numpy(), layers)
             got_i = sp.items_in_order(keep_i).numpy()
             assert np.array_equal(bits(keep_u[:203].numpy()), bits(want[:203])) and np.array_equal(bits(got_i), bits(want[203:]))
+
+
+@pytest.mark.parametrize('world,n_users,n_items,nnz,d,chunks,single', [
+    (2, 203, 97, 2500, 64, 1, False), (3, 203, 97, 2500, 64, 3, False), (2, 203, 97, 2500, 64, 2, True),
+    (3, 2, 5, 6, 16, 2, False),         # fewer users than ranks: a rank without users
+    (4, 61, 7, 200, 32, 4, False),      # world 4, a chunk per item or two
+    (2, 1, 1, 1, 100, 1, False),
+])
+def test_user_partition_matches_oracle_gloo(oracle, tmp_path, world, n_users, n_items, nnz, d, chunks, single):
+    """The user partition (dist.UserShardedPropagator): users local, item rows as per-rank partial sums joined by ONE all-reduce of
+    the item table per layer (gloo, asynchronous, in chunks under the user half-step).  An item row is a sum of per-rank chains, so
+    the result equals the oracle to rounding (normwise 1e-6; the path's bar is 1e-4) -- and with ONE rank, or where every item's
+    users live on one rank, bit for bit."""
+    from conftest import normwise
+    out = str(tmp_path / 'r0.npz')
+    run_ranks(world, 'cpu', out, extra=('--shard', 'users', '--chunks', str(chunks), '--n-users', str(n_users), '--n-items', str(n_items),
+                                        '--nnz', str(nnz), '--d', str(d), '--layers', '2') + (('--single',) if single else ()))
+    got = np.load(out)
+    ru, ri = reference(oracle, n_users=n_users, n_items=n_items, nnz=nnz, d=d, layers=2, single=single)
+    assert got['users'].shape == ru.shape and got['items'].shape == ri.shape
+    assert normwise(got['users'], ru) <= 1e-6 and normwise(got['items'], ri) <= 1e-6
+    assert got['user_bounds'][0] == 0 and got['user_bounds'][-1] == n_users and len(got['user_bounds']) == world + 1
+
+
+def test_user_partition_one_rank_is_bit_identical(oracle):
+    """world = 1: the partial sums ARE the rows -- the oracle's bits, every chunk count"""
+    from dist_worker import oracle_spmm
+    from textgcn_amd import synth
+    from textgcn_amd.dist import UserShardedPropagator
+    from textgcn_amd.graph import NormGraph
+    u, i = synth.interactions(203, 97, 2500, seed=1)
+    g = NormGraph.from_pairs(u, i, 203, 97)
+    e0 = synth.embeddings(g.n, 64, seed=2)
+    want, _ = oracle.propagate(*g.to_coo(), e0.numpy(), 3)
+    for chunks in (1, 4):
+        up = UserShardedPropagator(g, 0, 1, 'cpu', local_spmm=oracle_spmm, split_threshold=None, chunks=chunks)
+        assert up.nnz_local == g.nnz
+        uu, ii = up.forward(*up.local_e0(e0), 3, exact=True)
+        assert np.array_equal(bits(uu.numpy()), bits(want[:203])) and np.array_equal(bits(ii.numpy()), bits(want[203:]))

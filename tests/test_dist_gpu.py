@@ -101,6 +101,25 @@ def test_bench_two_gpus_rccl(tmp_path):
     assert r['n_gpus'] == 2 and r['scaling'] == 'strong' and r['config']['world_size'] == 2 and r['config']['distinct_devices'] == 2
     assert r['config']['backend'] == 'nccl' and len(r['layers']['max_over_ranks']) == 4
     _check_alone(r)
+    assert r['user_partition']['vs_row_partition']['ok'] and r['user_partition']['value'] > 0
+
+
+@pytest.mark.parametrize('mode,world,chunks', [('gpu', 2, 1), ('gpu', 3, 2), ('nccl', 1, 2)])
+def test_user_partition_hip_forward(cuda, tmp_path, mode, world, chunks):
+    """dist.UserShardedPropagator with the HIP kernels: two / three gloo ranks on the one GPU (item rows = sums of per-rank partial
+    chains: the one-GPU result to rounding, normwise 1e-6) and the RCCL all-reduce itself on a 1-rank communicator (then every
+    partial sum is the row: bit-identical)."""
+    from conftest import normwise
+    out = str(tmp_path / 'r0.npz')
+    n_u, n_i, nnz = 2030, 970, 40000
+    run_ranks(world, mode, out, extra=('--n-users', str(n_u), '--n-items', str(n_i), '--nnz', str(nnz), '--shard', 'users',
+                                       '--chunks', str(chunks)))
+    got = np.load(out)
+    ref = _single_gpu_reference(cuda, n_u, n_i, nnz)
+    if world == 1:
+        assert np.array_equal(bits(got['users']), bits(ref[:n_u])) and np.array_equal(bits(got['items']), bits(ref[n_u:]))
+    else:
+        assert normwise(got['users'], ref[:n_u]) <= 1e-6 and normwise(got['items'], ref[n_u:]) <= 1e-6
 
 
 @pytest.mark.parametrize('world,balance,chunks', [(2, 'nnz', 1), (3, 'nnz', 2), (3, 'rows', 1)])
@@ -183,6 +202,8 @@ def test_bench_two_rank_rehearsal(cuda, tmp_path, launch):
     assert r['config']['world_size'] == 2 and r['config']['backend'] == 'gloo' and r['config']['distinct_devices'] == 1
     assert len(r['layers']['rank0']) == 4
     _check_alone(r)
+    up = r['user_partition']
+    assert up['value'] > 0 and up['vs_row_partition']['ok'] and len(up['layers_max_over_ranks']) == 3
 
 
 def test_bench_sharded_path_on_one_rank_rccl(cuda):

@@ -603,3 +603,43 @@ def test_rows_with_fewer_scores_than_k_do_not_become_positions(cuda):
         for row in range(b):
             n = int(n_scores[row])
             assert torch.equal(fi[row, :n], idx[row, :n]) and torch.equal(fv[row, :n].view(torch.int32), v[row, :n].view(torch.int32))
+
+
+@pytest.mark.parametrize('d', [64, 128, 40])
+def test_prefilter_huge_norms_and_threshold_signs(cuda, d):
+    """Rows at the edges of the fp32 range through both fused entry points (written in round 4 for a form of the narrow filter that
+    read its verdict from the accumulator's sign -- measured no faster and not kept, profiles/r04_experiments.md -- and kept as data
+    the bound must survive): items and users of norm 2^59, 2^61, 2^100, with inf / NaN elements, zero rows, users whose every
+    score is negative (tau < 0), users with tiny scores (|tau| ~ 2^-40), a user with every item masked but 25 (tau = -inf): both
+    entry points must return the dense path's lists, bit for bit."""
+    rng = np.random.default_rng(77 + d)
+    b, i, k = 300, 9000, 40
+    u = (rng.standard_normal((b, d)) * 0.1).astype(np.float32)
+    it = (rng.standard_normal((i, d)) * 0.1).astype(np.float32)
+    it[5] *= np.float32(2.0 ** 59)
+    it[6] *= np.float32(2.0 ** 62)
+    it[7] *= np.float32(2.0 ** 100)
+    it[8, 1] = np.inf
+    it[9, d - 1] = -np.inf
+    it[10, 0] = np.nan
+    it[11] = 0.0
+    it[12] = np.float32(2.0 ** 63)
+    u[3] *= np.float32(2.0 ** 58)
+    u[4] *= np.float32(2.0 ** 61)
+    u[5, 2] = np.inf
+    u[6, 0] = np.nan
+    u[7] = 0.0
+    u[8] = -np.abs(it[100:4000]).mean(axis=0) * 3          # most scores negative
+    u[9] = u[9] * np.float32(2.0 ** -40)                   # tiny scores
+    u[10] = np.float32(2.0 ** -70)
+    u[11] *= np.float32(2.0 ** 40)
+    rp, items = _rand_mask(rng, b, i, 0, 30)
+    # user 12: all but 25 items masked (fewer than k unmasked: tau = -inf, the lists end in masked -inf entries)
+    cnt = np.diff(rp)
+    keep25 = np.sort(rng.choice(i, size=25, replace=False))
+    row12 = np.setdiff1d(np.arange(i), keep25)
+    items = np.concatenate([items[:rp[12]], row12, items[rp[13]:]])
+    cnt[12] = len(row12)
+    rp = np.concatenate([[0], np.cumsum(cnt)])
+    _fused_vs_dense(cuda, u, it, k, mask=(rp, items), round4=False)
+    _fused_vs_dense(cuda, u, it, k, mask=None, round4=True)

@@ -131,6 +131,8 @@ int launch_sample_wide(const float *U, const int64_t *user_ids, int B, const voi
                        int64_t ld, hipStream_t stream);
 int launch_rescore_list(const float *U, const int64_t *user_ids, int B, const float *It, int d, const float *tau, int tau_stride,
                         const int *surv, const int *surv_n, int surv_cap, void *lists, int *totals, int list_cap, hipStream_t stream);
+int launch_rescore(const float *U, const int64_t *user_ids, int B, const float *It, int d, const float *tau, int tau_stride,
+                   const unsigned *mask, int Wh, int n_units, void *lists, int *totals, int list_cap, hipStream_t stream);
 // the narrow rows' fp32 chains AND the exact selection of the top k in one launch (k_rescore<.., SELECT>): writes out_val / out_idx,
 // flags the users it leaves to the exact fallback
 int launch_rescore_select(const float *U, const int64_t *user_ids, int B, const float *It, int d, const float *tau, int tau_stride,

@@ -1276,6 +1276,8 @@ namespace {
 // prefilter: candidates from the bf16 pass of tgcn_score_prefilter.hip, rescored in fp32 (same results; d <= 128, or d <= 1024 with d % 8 == 0;
 // otherwise the fp32 filter runs).  item_pack: device pointer to the packed item operand (tgcn_item_pack_bf16), or NULL: packed by
 // this call.
+constexpr int kFuseSelectMaxUsers = 4096;     // calls up to this size select inside k_rescore (see its SELECT note)
+
 int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const float *It, int32_t I, int32_t d,
                     const int32_t *mask_rowptr, const int32_t *mask_items, int32_t k, int32_t round4, float *out_val,
                     int64_t *out_idx, void *workspace, int64_t workspace_bytes, tgcn_stream_t stream, bool prefilter,
@@ -1414,10 +1416,16 @@ int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const fl
         if ((rc = launch_prefilter(U, user_ids, B, ipack, I, d, tau_ptr, tau_stride, ubound, mask, p.Wh, (I + ips_pre - 1) / ips_pre,
                                    ips_pre, wide, s)) != TGCN_OK)
             return rc;
-        // the fp32 chains and the exact selection in ONE launch: the kept pairs never leave the wave's LDS (round 4)
-        rc = launch_rescore_select(U, user_ids, B, It, d, tau_ptr, tau_stride, mask, p.Wh, (I + kStage - 1) / kStage, totals, mask_rowptr,
-                                   mask_items, k, round4, out_val, out_idx, flagged, s);
-        selected = true;
+        if (B <= kFuseSelectMaxUsers) {
+            // small calls: the fp32 chains and the exact selection in ONE launch, the kept pairs never leave the wave's LDS (round 4)
+            rc = launch_rescore_select(U, user_ids, B, It, d, tau_ptr, tau_stride, mask, p.Wh, (I + kStage - 1) / kStage, totals,
+                                       mask_rowptr, mask_items, k, round4, out_val, out_idx, flagged, s);
+            selected = true;
+        } else {
+            // large calls: k_select_flat as its own launch runs 32 waves per CU where the fused kernel's LDS allows 8
+            rc = launch_rescore(U, user_ids, B, It, d, tau_ptr, tau_stride, mask, p.Wh, (I + kStage - 1) / kStage, fa.logs, totals,
+                                p.S * 2 * p.cap2, s);
+        }
         }
     } else if (d <= 128) {
         const dim3 grid((B + kUsersPerWG - 1) / kUsersPerWG, p.S);

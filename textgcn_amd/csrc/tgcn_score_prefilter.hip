@@ -1319,21 +1319,34 @@ constexpr int kMaskCacheSel = 512;  // train items per user cached in LDS by the
 // of this one.  The kept (score, item) pairs stay in LDS: the item ids go back INTO the candidate array (kept pair number p
 // overwrites ids[p]; p never runs ahead of the candidates already chained, and everything later reads ids further on), the scores
 // into a 4 KB array; then the train items are dropped, the k-th largest is found by the bitwise search of select_core and the
-// winners are sorted and written -- no flat list in global memory, no totals round trip, one launch less per call
-// (36 of 304 us at 16 384 users).  A user with no candidates, too many, or fewer than k unmasked ones goes to the exact fallback.
+// winners are sorted and written -- no flat list in global memory, no totals round trip, one launch less per call.  A user with
+// no candidates, too many, or fewer than k unmasked ones goes to the exact fallback.  For SMALL calls only (score_topk_impl: up
+// to 4096 users): this kernel's LDS holds it to 8 waves per CU, and the selection -- a latency chain of ballots and a 64-lane
+// bitonic sort -- runs four times as many waves per CU as its own launch (k_select_flat): at 16 384 users the fused launch took
+// 163 us where the pair took ~116 (rocprofv3, profiles/r04_experiments.md section 2); at 2048 the two are equal (28 us) and the
+// fused form saves a launch.
+// Waves per workgroup.  (Round 4 tried TWO for the SELECT form -- 38 KB of LDS, so that a workgroup fits on a CU beside a workgroup of
+// the bf16 filter (120 KB) and one call's chains could run under the next call's filter: no gain, 2048-user calls on four streams
+// 56 -> 58 us, profiles/r04_experiments.md section 2 -- the launches of a call each fill the chip by themselves.)
+template <bool SELECT>
+struct RescoreShape {
+    static constexpr int kWaves = 4;
+};
+
 template <bool ALIGNED4, bool FROM_LIST, bool SELECT = false>     // ALIGNED4: rows are multiples of 16 bytes (d % 4 == 0): one float4 per (row, piece), else four scalars
-__global__ __launch_bounds__(256) void k_rescore(const RescoreArgs a)
+__global__ __launch_bounds__(RescoreShape<SELECT>::kWaves * 64) void k_rescore(const RescoreArgs a)
 {
     static_assert(!(SELECT && FROM_LIST), "the fused selection is the narrow rows' (d <= 128)");
     constexpr int kSuLen = SELECT ? 128 : kMaxPreD;
-    __shared__ int ids_all[4][kUserCap];
-    __shared__ float tiles[4][kWave * kTileRow];
-    __shared__ __attribute__((aligned(16))) float su_all[4][kSuLen];   // the user's row
-    __shared__ float kscore_all[4][SELECT ? kSelCap : 1];
+    constexpr int WPB = RescoreShape<SELECT>::kWaves;
+    __shared__ int ids_all[WPB][kUserCap];
+    __shared__ float tiles[WPB][kWave * kTileRow];
+    __shared__ __attribute__((aligned(16))) float su_all[WPB][kSuLen];   // the user's row
+    __shared__ float kscore_all[WPB][SELECT ? kSelCap : 1];
     static_assert(kWave * kTileRow * sizeof(float) >= kMaskCacheSel * sizeof(int) + kWave * sizeof(float2), "select scratch inside the tile");
     const int lane = lane_id();
     const int w = threadIdx.x >> 6;
-    const int b = blockIdx.x * 4 + w;
+    const int b = blockIdx.x * WPB + w;
     if (b >= a.B)
         return;
     int *ids = ids_all[w];
@@ -1756,6 +1769,18 @@ int launch_sample_wide(const float *U, const int64_t *user_ids, int B, const voi
     return check_launch("k_score_prefilter_wide(sample)");
 }
 
+int launch_rescore(const float *U, const int64_t *user_ids, int B, const float *It, int d, const float *tau, int tau_stride,
+                   const unsigned *mask, int Wh, int n_units, void *lists, int *totals, int list_cap, hipStream_t s)
+{
+    RescoreArgs a{U, user_ids, It, tau, tau_stride, mask, Wh, n_units, nullptr, nullptr, 0, static_cast<float2 *>(lists), totals, B, d,
+                  list_cap, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+    if ((d & 3) == 0)
+        hipLaunchKernelGGL((k_rescore<true, false>), dim3((B + 3) / 4), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((k_rescore<false, false>), dim3((B + 3) / 4), dim3(256), 0, s, a);
+    return check_launch("k_rescore");
+}
+
 int launch_rescore_select(const float *U, const int64_t *user_ids, int B, const float *It, int d, const float *tau, int tau_stride,
                           const unsigned *mask, int Wh, int n_units, int *totals, const int *mask_rowptr, const int *mask_items, int k,
                           int do_round, float *out_val, int64_t *out_idx, int *flagged, hipStream_t s)
@@ -1764,10 +1789,11 @@ int launch_rescore_select(const float *U, const int64_t *user_ids, int B, const 
         return fail_arg("launch_rescore_select: narrow rows only");
     RescoreArgs a{U, user_ids, It, tau, tau_stride, mask, Wh, n_units, nullptr, nullptr, 0, nullptr, totals, B, d, 0,
                   mask_rowptr, mask_items, out_val, out_idx, flagged, k, do_round};
+    constexpr int WPB = RescoreShape<true>::kWaves;
     if ((d & 3) == 0)
-        hipLaunchKernelGGL((k_rescore<true, false, true>), dim3((B + 3) / 4), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((k_rescore<true, false, true>), dim3((B + WPB - 1) / WPB), dim3(WPB * 64), 0, s, a);
     else
-        hipLaunchKernelGGL((k_rescore<false, false, true>), dim3((B + 3) / 4), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((k_rescore<false, false, true>), dim3((B + WPB - 1) / WPB), dim3(WPB * 64), 0, s, a);
     return check_launch("k_rescore(select)");
 }
 

@@ -506,3 +506,184 @@ class ColumnShardedPropagator:
 
     def close(self):
         pass
+
+
+class UserShardedPropagator:
+    """A third partition (round 4; an OPTION beside the prescribed row partition): by USERS only, the item table replicated.
+
+    Rank p owns a contiguous nnz-balanced block of users U_p -- their rows of A and the [|U_p|, d] user tables, which never leave the
+    rank -- and holds the whole [I, d] item table.  A is bipartite, so a layer is
+        Y_u[U_p]  = A[U_p, items] . X_i                    local: the single-GPU chain of every user row, on the local item table
+        P_i       = A[items, U_p] . X_u[U_p]               the item rows restricted to the rank's own users: a PARTIAL sum
+        Y_i       = sum over ranks of P_i                  ONE all-reduce of [I, d] per layer
+    Against the row partition's per-layer all-gather of BOTH tables ((P-1)/P x (U + I) x d x 4 bytes received per rank: 1.57 GB at
+    config 4, P = 8) the exchange is an all-reduce of the ITEM table alone (2 (P-1)/P x I x d x 4 = 0.9 GB sent and received), and
+    the 1.28 GB user table -- 71 % of the rows -- is never communicated; the partial item product gathers from the rank's own user
+    block (160 MB at P = 8: Infinity-Cache resident).  The all-reduce of chunk c of the item rows runs under the partial product of
+    chunks c + 1.. and under the whole user half-step.
+    Price: an item row is the sum of P partial chains instead of one chain, added in the collective's order: the result equals the
+    one-GPU forward to rounding (normwise ~1e-7; the path's bar is 1e-4), not bit for bit, and is only as deterministic as the
+    collective (RCCL's ring / tree order is fixed for a fixed world).  The reference is single-device: nothing to match."""
+
+    def __init__(self, graph: NormGraph, rank, world, device, group=None, split_threshold=DEFAULT_SPLIT_THRESHOLD, local_spmm=None,
+                 chunks=1, force_collective=False):
+        self.rank, self.world = int(rank), int(world)
+        self.device = resolve_device(device)
+        self.group = group
+        self.n_users, self.n_items = graph.n_users, graph.n_items
+        ub, _ = graph.partition(self.world)
+        self.bounds = np.asarray(ub, dtype=np.int64)
+        u0, u1 = int(self.bounds[self.rank]), int(self.bounds[self.rank + 1])
+        self.u0, self.u1 = u0, u1
+        self.bu = max(u1 - u0, 1)           # (a rank without users keeps one empty row: the kernels want a non-empty table)
+        self._spmm = local_spmm or _hip_spmm
+        self.uses_collective = self.world > 1 or force_collective
+        self.backend = dist.get_backend(group) if self.uses_collective else 'none'
+        I = self.n_items
+        # user rows: columns are item ids (global id - U): rows of the local item table
+        rp, ci, va = graph.row_block(u0, u1)
+        rp = np.asarray(rp, dtype=np.int64)
+        if u1 == u0:
+            rp = np.zeros(2, dtype=np.int64)
+        self.csr_u = DeviceCSR(rp, np.asarray(ci, dtype=np.int64) - graph.n_users, va, max(I, 1), self.device, split_threshold)
+        # item rows restricted to the rank's users, in C row chunks; columns = local user index
+        a, b = int(graph.rowptr[graph.n_users]), int(graph.rowptr[graph.n])
+        cols = np.asarray(graph.colidx[a:b])
+        keep = (cols >= u0) & (cols < u1)
+        rows = np.repeat(np.arange(I, dtype=np.int64), np.diff(np.asarray(graph.rowptr[graph.n_users:graph.n + 1], dtype=np.int64)))[keep]
+        lcols = (cols[keep].astype(np.int64) - u0)
+        lvals = np.asarray(graph.vals[a:b])[keep]
+        cnt = np.bincount(rows, minlength=I)
+        rp_i = np.zeros(I + 1, dtype=np.int64)
+        np.cumsum(cnt, out=rp_i[1:])
+        self.chunks = max(1, min(int(chunks), max(I, 1)))
+        self.cb = -(-max(I, 1) // self.chunks)
+        self.csr_i = []
+        for c in range(self.chunks):
+            r0, r1 = min(c * self.cb, I), min((c + 1) * self.cb, I)
+            e0, e1 = int(rp_i[r0]), int(rp_i[r1])
+            self.csr_i.append(DeviceCSR(rp_i[r0:r1 + 1] - e0, lcols[e0:e1], lvals[e0:e1], self.bu, self.device, split_threshold)
+                              if r1 > r0 else None)
+        self.nnz_local = int(rp[-1]) + int(rp_i[-1])
+        self._buf = {}
+        self.record_events = False
+        self._events = None
+
+    def user_range(self):
+        return self.u0, self.u1
+
+    def local_e0(self, e0_full):
+        """(this rank's user rows [bu, d], the whole item table [I, d]) of a full [N, d] table (host or device tensor)"""
+        d = e0_full.shape[1]
+        eu = torch.zeros((self.bu, d), dtype=torch.float32, device=self.device)
+        eu[:self.u1 - self.u0] = e0_full[self.u0:self.u1].to(self.device)
+        return eu, e0_full[self.n_users:].to(self.device).contiguous()
+
+    def buffers(self, d):
+        if d not in self._buf:
+            mk = lambda n: torch.zeros((max(n, 1), d), dtype=torch.float32, device=self.device)  # noqa: E731
+            self._buf[d] = {'xu': [mk(self.bu), mk(self.bu)], 'xi': [mk(self.n_items), mk(self.n_items)], 'acc_u': mk(self.bu),
+                            'acc_i': mk(self.n_items), 'out_u': mk(self.bu), 'out_i': mk(self.n_items)}
+        return self._buf[d]
+
+    def _all_reduce(self, t):
+        if not self.uses_collective:
+            return _Done()
+        if self.backend == 'nccl' or t.device.type == 'cpu':
+            return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        host = t.detach().cpu()                  # one-GPU rehearsal (gloo, device tensors): staged through host memory
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+        t.copy_(host.to(t.device))
+        return _Done()
+
+    def _mark(self, layer, kind):
+        if self._events is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(torch.cuda.current_stream(self.device))
+            self._events.append((layer, kind, ev))
+
+    def layer_times(self):
+        """After a forward() with record_events = True: [{layer, compute_ms, wait_on_reduce_ms}] -- ms the launch stream spent in the
+        layer's SpMM launches and its item epilogue, and ms it sat waiting for the all-reduced item rows."""
+        if not self._events:
+            return []
+        torch.cuda.synchronize(self.device)
+        out = {}
+        prev = None
+        for layer, kind, ev in self._events:
+            rec = out.setdefault(layer, {'layer': layer, 'compute_ms': 0.0, 'wait_on_reduce_ms': 0.0})
+            if prev is not None and kind in ('launched', 'done'):
+                rec['compute_ms'] += prev.elapsed_time(ev)
+            elif prev is not None and kind == 'reduced':
+                rec['wait_on_reduce_ms'] += prev.elapsed_time(ev)
+            prev = ev
+        return [out[k] for k in sorted(out)]
+
+    def forward(self, e0_u, e0_i, n_layers, single=False, exact=False):
+        """e0_u [bu, d]: this rank's users; e0_i [I, d]: all items.  -> (users_local [bu, d], items [I, d] in item-id order): views
+        of reusable buffers, valid until the next forward() on this object."""
+        self._events = [] if (self.record_events and self.device.type == 'cuda') else None
+        d = e0_u.shape[1]
+        b = self.buffers(d)
+        if n_layers == 0:
+            b['out_u'].copy_(e0_u)
+            b['out_i'].copy_(e0_i)
+            return b['out_u'], b['out_i']
+        xu, xi = e0_u, e0_i
+        I = self.n_items
+        for k in range(1, n_layers + 1):
+            last = k == n_layers
+            div = float(n_layers + 1) if last else 1.0
+            yu, yi = b['xu'][k & 1], b['xi'][k & 1]
+            self._mark(k, 'start')
+            # item partials first: their all-reduce runs under the remaining chunks and under the user half-step
+            works = []
+            for c, csr in enumerate(self.csr_i):
+                if csr is None:
+                    continue
+                r = slice(c * self.cb, min((c + 1) * self.cb, I))
+                self._spmm(csr, xu, y=yi[r], exact=exact)
+                works.append(self._all_reduce(yi[r]))
+            # user half-step: the single-GPU chains, layer sum fused
+            if single:
+                self._spmm(self.csr_u, xi, y=b['out_u'] if last else yu, exact=exact)
+            else:
+                self._spmm(self.csr_u, xi, y=None if last else yu, acc_in=e0_u if k == 1 else b['acc_u'],
+                           acc_out=b['out_u'] if last else b['acc_u'], acc_div=div, exact=exact)
+            self._mark(k, 'launched')
+            for w in works:
+                w.wait()
+            self._mark(k, 'reduced')
+            # the items' layer sum, on the reduced rows (the epilogue's arithmetic: add, then one IEEE division on the last layer)
+            if single:
+                if last:
+                    b['out_i'].copy_(yi)
+            else:
+                torch.add(e0_i if k == 1 else b['acc_i'], yi, out=b['out_i'] if last else b['acc_i'])
+                if last:
+                    b['out_i'].div_(div)
+            self._mark(k, 'done')
+            xu, xi = yu, yi
+        return b['out_u'], b['out_i']
+
+    def gather_users(self, users_local):
+        """All ranks' user blocks -> [U, d] in user-id order (tests / single-process consumers)."""
+        d = users_local.shape[1]
+        bmax = int(np.diff(self.bounds).max()) if self.world > 0 else self.bu
+        bmax = max(bmax, 1)
+        mine = torch.zeros((bmax, d), dtype=torch.float32, device=users_local.device)
+        mine[:self.u1 - self.u0] = users_local[:self.u1 - self.u0]
+        full = torch.empty((self.world * bmax, d), dtype=torch.float32, device=users_local.device)
+        if not self.uses_collective:
+            full.copy_(mine)
+        elif self.backend == 'nccl' or full.device.type == 'cpu':
+            dist.all_gather_into_tensor(full, mine, group=self.group)
+        else:
+            host = torch.empty((self.world * bmax, d), dtype=torch.float32)
+            dist.all_gather_into_tensor(host, mine.cpu(), group=self.group)
+            full.copy_(host.to(full.device))
+        rows = np.concatenate([r * bmax + np.arange(int(self.bounds[r + 1] - self.bounds[r])) for r in range(self.world)])
+        return full[torch.from_numpy(rows).to(full.device)]
+
+    def close(self):
+        pass

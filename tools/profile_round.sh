@@ -2,8 +2,8 @@
 # Collect the round's profile evidence on the GPU box (run from the repo root):
 #     bash tools/profile_round.sh gpurun_out/prof
 # then, back in the build container:
-#     python tools/summarize_profiles.py --round r03 --gather-cal gpurun_out/gcal            (tools/gather_cal_round.sh: measured counter factors)
-#     python tools/summarize_profiles.py --round r03 --kt gpurun_out/prof/kt --pmc gpurun_out/prof/pmc_c2 --workload c2   (and c3, c4)
+#     python tools/summarize_profiles.py --round r04 --gather-cal gpurun_out/gcal            (tools/gather_cal_round.sh: measured counter factors)
+#     python tools/summarize_profiles.py --round r04 --kt gpurun_out/prof/kt --pmc gpurun_out/prof/pmc_c2 --workload c2   (and c3, c4)
 # One kernel-trace pass of the default bench.py run, then one PMC pass per counter set and workload (each in its own run, as
 # MI355X_MICROARCH.md prescribes).  TCC_EA0_RDREQ_DRAM_32B_sum x 32 B is the exact fabric-side read byte count (measured x0.999 on
 # known-traffic gathers); FETCH_SIZE is kept beside it (x1.996 on the same launches).
@@ -13,7 +13,7 @@ workloads=${2:-"c2 c3 c4"}
 root=$(pwd)
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$root" || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -- python bench.py --steps 20 --warmup 5 > "$out/kt.log" 2>&1 || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -- python bench.py --steps 20 --warmup 3 > "$out/kt.log" 2>&1 || exit 1
 echo "kernel trace done"
 for wl in $workloads; do
     mkdir -p "$out/pmc_$wl"

@@ -35,7 +35,11 @@ def main():
     ap.add_argument('--users', type=int, default=0, help='users per call instead of the shape\'s (same number of calls)')
     ap.add_argument('--calls', type=int, default=0)
     ap.add_argument('--modes', default='fp32,prefilter,prefilter+pack')
+    ap.add_argument('--lib', default=None, help='another build of libtgcn.so to time (A/B on one box: run the tool once per library)')
     args = ap.parse_args()
+    if args.lib:
+        from textgcn_amd import _capi
+        _capi.LIB_PATH = os.path.abspath(args.lib)
     dev = torch.device('cuda:0')
     for name in args.shapes.split(','):
         b, calls, n_items, d = SHAPES[name]
@@ -90,7 +94,7 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 t = e0.elapsed_time(e1) / 1e3 / args.reps
-                print(json.dumps({'shape': name, 'users_per_call': b, 'calls': calls, 'items': n_items, 'd': d, 'mode': mode,
+                print(json.dumps({'lib': os.path.basename(args.lib) if args.lib else 'libtgcn.so', 'shape': name, 'users_per_call': b, 'calls': calls, 'items': n_items, 'd': d, 'mode': mode,
                                   'streams': n_streams, 'us_per_call': round(t / calls * 1e6, 1),
                                   'T_pairs_per_s': round(n_users * n_items / t / 1e12, 4), 'identical_to_fp32': bool(same), 'fallback_users_last_call': fb}), flush=True)
 

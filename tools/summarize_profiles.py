@@ -177,9 +177,10 @@ def main():
     # one-wave-per-row kernel and its long-row reduce
     seg = [k for k in fs if k.startswith('k_spmm_seg<')]
     if seg:
-        spmm = seg[:1] + [k for k in fs if k.startswith(('k_spmm_reduce_direct', 'k_spmm_seg_reduce'))]
+        spmm = seg[:1] + [k for k in fs if k.startswith(('k_spmm_reduce_groups', 'k_spmm_reduce_direct', 'k_spmm_seg_reduce'))]
     else:
-        main = [k for k in fs if k.startswith('k_spmm_wave')]
+        # round 4: a layer is k_spmm_groups (+ k_spmm_long_reduce); the random-row probe runs the one-wave-per-row kernel
+        main = [k for k in fs if k.startswith('k_spmm_groups')] or [k for k in fs if k.startswith('k_spmm_wave')]
         main = sorted(main, key=lambda k: -fs[k]['FETCH_SIZE']['mean'] * fs[k]['FETCH_SIZE']['n'])[:1]
         spmm = main + [k for k in fs if k.startswith('k_spmm_long_reduce') and main]
     if spmm:
