@@ -1337,9 +1337,14 @@ template <bool ALIGNED4, bool FROM_LIST, bool SELECT = false>     // ALIGNED4: r
 __global__ __launch_bounds__(RescoreShape<SELECT>::kWaves * 64) void k_rescore(const RescoreArgs a)
 {
     static_assert(!(SELECT && FROM_LIST), "the fused selection is the narrow rows' (d <= 128)");
-    constexpr int kSuLen = SELECT ? 128 : kMaxPreD;
+    // LDS per wave decides how many waves a CU runs, and a wave here is a chain of ~10 dependent round trips: the launch's time is
+    // (waves / resident waves) x that chain.  Narrow rows (from the mask; d <= 128) keep 128 floats of the user's row and 1024
+    // candidates -- what k_select_flat takes anyway -- : 12.9 KB per wave, 12 waves per CU (the register limit) where round 3's
+    // 18.5 KB (a 1024-float row, 1536 candidates) allowed 8.
+    constexpr int kSuLen = FROM_LIST ? kMaxPreD : 128;
+    constexpr int kCap = FROM_LIST ? kUserCap : kSelCap;
     constexpr int WPB = RescoreShape<SELECT>::kWaves;
-    __shared__ int ids_all[WPB][kUserCap];
+    __shared__ int ids_all[WPB][kCap];
     __shared__ float tiles[WPB][kWave * kTileRow];
     __shared__ __attribute__((aligned(16))) float su_all[WPB][kSuLen];   // the user's row
     __shared__ float kscore_all[WPB][SELECT ? kSelCap : 1];
@@ -1379,7 +1384,7 @@ __global__ __launch_bounds__(RescoreShape<SELECT>::kWaves * 64) void k_rescore(c
     int n = 0;
     if constexpr (FROM_LIST) {
         n = a.surv_n[b];
-        if (n > kUserCap) {
+        if (n > kCap) {
             give_up(kOverflow);
             return;
         }
@@ -1419,7 +1424,7 @@ __global__ __launch_bounds__(RescoreShape<SELECT>::kWaves * 64) void k_rescore(c
                 incl += t;
         }
         const int chunk_n = __builtin_amdgcn_readlane(incl, kWave - 1);
-        if (n + chunk_n > kUserCap) {    // too many candidates (tau = -inf, non-finite norms, a degenerate threshold ...)
+        if (n + chunk_n > kCap) {    // too many candidates (tau = -inf, non-finite norms, a degenerate threshold ...)
             give_up(kOverflow);
             return;
         }
