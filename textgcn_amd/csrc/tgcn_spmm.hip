@@ -53,6 +53,43 @@ struct SpmmArgs {
     float *__restrict__ ws;
 };
 
+// Streams touched once per launch -- the CSR entries, acc_in, Y, acc_out -- carry the non-temporal hint: what the L2s and the
+// Infinity Cache should keep is the GATHERED table (config 4: the Zipf-popular item rows), not 7 GB of bytes nobody reads twice.
+// A/B on one box (profiles/r04_experiments.md section 6): config 4 layer 7.49-7.56 -> 7.32-7.41 ms, config 2 198 -> 194, config 3 232 -> 228 us.
+using f32x2_t = __attribute__((ext_vector_type(2))) float;
+using f32x4_t = __attribute__((ext_vector_type(4))) float;
+template <typename T>
+__device__ __forceinline__ T ld_stream(const T *p)
+{
+    return __builtin_nontemporal_load(p);
+}
+template <int VEC>
+__device__ __forceinline__ void load_vec_stream(const float *p, float (&x)[VEC])
+{
+    if constexpr (VEC == 1) {
+        x[0] = ld_stream(p);
+    } else if constexpr (VEC == 2) {
+        const f32x2_t t = ld_stream(reinterpret_cast<const f32x2_t *>(p));
+        x[0] = t.x, x[1] = t.y;
+    } else {
+        const f32x4_t t = ld_stream(reinterpret_cast<const f32x4_t *>(p));
+        x[0] = t.x, x[1] = t.y, x[2] = t.z, x[3] = t.w;
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void store_vec_stream(float *p, const float (&x)[VEC])
+{
+    if constexpr (VEC == 1) {
+        __builtin_nontemporal_store(x[0], p);
+    } else if constexpr (VEC == 2) {
+        const f32x2_t t = {x[0], x[1]};
+        __builtin_nontemporal_store(t, reinterpret_cast<f32x2_t *>(p));
+    } else {
+        const f32x4_t t = {x[0], x[1], x[2], x[3]};
+        __builtin_nontemporal_store(t, reinterpret_cast<f32x4_t *>(p));
+    }
+}
+
 template <int VEC>
 __device__ __forceinline__ void load_vec(const float *p, float (&x)[VEC])
 {
@@ -109,14 +146,14 @@ __device__ __forceinline__ void preload_acc(const SpmmArgs &a, size_t off, float
     for (int k = 0; k < VEC; ++k)
         t[k] = 0.0f;
     if (a.acc_out)
-        load_vec<VEC>(a.acc_in + off, t);
+        load_vec_stream<VEC>(a.acc_in + off, t);
 }
 
 template <int VEC>
 __device__ __forceinline__ void epilogue_pre(const SpmmArgs &a, size_t off, const float (&y)[VEC], float (&t)[VEC])
 {
     if (a.Y)
-        store_vec<VEC>(a.Y + off, y);
+        store_vec_stream<VEC>(a.Y + off, y);
     if (a.acc_out) {
 #pragma unroll
         for (int k = 0; k < VEC; ++k) {
@@ -124,7 +161,7 @@ __device__ __forceinline__ void epilogue_pre(const SpmmArgs &a, size_t off, cons
             if (a.acc_div != 1.0f)
                 t[k] = t[k] / a.acc_div;  // IEEE division: the reference divides (torch.mean), base_model.py:157
         }
-        store_vec<VEC>(a.acc_out + off, t);
+        store_vec_stream<VEC>(a.acc_out + off, t);
     }
 }
 
@@ -140,8 +177,8 @@ __device__ __forceinline__ void accumulate_wave(const SpmmArgs &a, int beg, int 
         int c = 0;
         float v = 0.0f;
         if (lane < n) {
-            c = a.colidx[base + lane];
-            v = a.vals[base + lane];
+            c = ld_stream(a.colidx + base + lane);
+            v = ld_stream(a.vals + base + lane);
         }
         int j = 0;
         for (; j + UNROLL <= n; j += UNROLL) {
@@ -643,16 +680,16 @@ __device__ __forceinline__ void group_wave(const SpmmArgs &a, int first, int n, 
         int c = 0;
         float v = 0.0f;
         if (beg + lane < end) {
-            c = a.colidx[beg + lane];
-            v = a.vals[beg + lane];
+            c = ld_stream(a.colidx + beg + lane);
+            v = ld_stream(a.vals + beg + lane);
         }
         for (int base = beg; base < end; base += kWave) {
             const int ns = min(kWave, end - base);  // uniform
             int c_nxt = 0;
             float v_nxt = 0.0f;
             if (base + kWave + lane < end) {
-                c_nxt = a.colidx[base + kWave + lane];
-                v_nxt = a.vals[base + kWave + lane];
+                c_nxt = ld_stream(a.colidx + base + kWave + lane);
+                v_nxt = ld_stream(a.vals + base + kWave + lane);
             }
             const int e1 = base + lane + 1;
             bool f = false;

@@ -43,7 +43,7 @@ def run_cases(args, cfg, gr, prop, e0, K, target, single):
         for c in cases:
             ms = float(np.median(times[c]))
             same_as = ('wave_per_row', False, 0, c[3])
-            rec = {'config': cfg, 'target_entries': target, 'single_len': single, 'form': c[0], 'unroll': c[2], 'segmented': 'auto' if c[3] is None else 'off',
+            rec = {'lib': os.path.basename(args.lib) if args.lib else 'libtgcn.so', 'config': cfg, 'target_entries': target, 'single_len': single, 'form': c[0], 'unroll': c[2], 'segmented': 'auto' if c[3] is None else 'off',
                    'seg_blocks': prop.csr.segment_blocks, 'ms_fwd': round(ms, 4), 'us_layer': round(ms / K * 1e3, 1),
                    'ms_min': round(float(np.min(times[c])), 4), 'gedges_per_s': round(K * gr.nnz / ms / 1e6, 2),
                    'bits_equal_to_wave_per_row': bool(torch.equal(outs[c].view(torch.int32), outs[same_as].view(torch.int32)))}
@@ -59,7 +59,11 @@ def main():
     ap.add_argument('--out', default='gpurun_out/groups_bench.jsonl')
     ap.add_argument('--targets', type=int, nargs='*', default=[64], help='entries per group (sweep)')
     ap.add_argument('--singles', type=int, nargs='*', default=[32], help='rows of this length or more stay alone (sweep)')
+    ap.add_argument('--lib', default=None, help='another build of libtgcn.so (A/B on one box: run the tool once per library)')
     args = ap.parse_args()
+    if args.lib:
+        from textgcn_amd import _capi
+        _capi.LIB_PATH = os.path.abspath(args.lib)
     dev = torch.device('cuda:0')
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     for cfg in args.configs:
