@@ -56,6 +56,7 @@ def main():
     ap.add_argument('--device-per-rank', action='store_true', help='--mode nccl on a multi-GPU box: rank r uses cuda:r')
     ap.add_argument('--split-threshold', type=int, default=64)
     ap.add_argument('--exact', action='store_true')
+    ap.add_argument('--no-segment', action='store_true', help='keep every row chunk on the row-group kernel (bit-identity against segment=None)')
     args = ap.parse_args()
 
     from textgcn_amd import synth
@@ -106,7 +107,7 @@ def main():
         assert sp.backend == 'nccl' and sp.uses_collective and (sp._capi_comm is not None) == (args.collective == 'capi')
     else:
         sp = ShardedPropagator(g, args.rank, args.world, 'cuda:0', split_threshold=args.split_threshold, balance=args.balance,
-                               chunks=args.chunks)
+                               chunks=args.chunks, segment=None if args.no_segment else 'auto')
     eu, ei = sp.local_e0(e0)
     users_local, items_full = sp.forward(eu, ei, args.layers, single=args.single, exact=(args.mode == 'cpu' or args.exact))
     if args.sample:      # large graphs: seeded sample rows of rank 0's own users and of the gathered item table

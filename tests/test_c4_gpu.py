@@ -58,8 +58,11 @@ def test_full_size_c4_properties(cuda, oracle, c4):
     out_split = prop.forward(e0d, K, exact=False)
     ref = out_exact.cpu().numpy()
     assert normwise(out_split.cpu().numpy(), ref) <= 1e-5
-    short = torch.from_numpy(np.nonzero(deg <= 1024)[0][:100000]).to(cuda)
-    # rows that were never split differ only through their (split) neighbours: still within the bar, and layer 1 of them is exact
+    # the default path also cuts the HOT item rows (>= 640 entries here) at 8 MB windows of the user table (propagate.segment_blocks_auto)
+    assert prop.csr.segment_blocks and prop.csr.segment_blocks[0] == 0 and prop.csr.segment_blocks[1][0] >= 104
+    cut_from = min(1024, prop.csr.segment_blocks[1][2])
+    short = torch.from_numpy(np.nonzero(deg < cut_from)[0][:100000]).to(cuda)
+    # rows that were never cut differ only through their (cut) neighbours: still within the bar, and layer 1 of them is exact
     y1a, y1b = torch.empty_like(e0d), torch.empty_like(e0d)
     from textgcn_amd.propagate import spmm
     spmm(prop.csr, e0d, y=y1a, exact=True)
@@ -101,7 +104,7 @@ def test_c4_two_rank_sharded_forward_equals_single_gpu(cuda, c4, tmp_path):
     out = str(tmp_path / 'r0.npz')
     # the worker draws E0 with seed 2; the graph is synth seed 0 as in the fixture
     run_ranks(2, 'gpu', out, extra=('--n-users', str(gr.n_users), '--n-items', str(gr.n_items), '--nnz', '100000000', '--graph-seed', '0',
-                                    '--balance', 'nnz', '--chunks', '4', '--sample', '2000'))
+                                    '--balance', 'nnz', '--chunks', '4', '--sample', '2000', '--no-segment'))
     got = np.load(out)
     from textgcn_amd import synth
     e0w = synth.embeddings(gr.n, d, seed=2).to(cuda)
@@ -110,3 +113,8 @@ def test_c4_two_rank_sharded_forward_equals_single_gpu(cuda, c4, tmp_path):
     ir = torch.from_numpy(got['item_rows'] + gr.n_users).to(cuda)
     assert np.array_equal(bits(got['users']), bits(ref[ur].cpu().numpy()))
     assert np.array_equal(bits(got['items']), bits(ref[ir].cpu().numpy()))
+    # and with the hot-row windows on (what bench.py runs): the same rows to rounding
+    run_ranks(2, 'gpu', out, extra=('--n-users', str(gr.n_users), '--n-items', str(gr.n_items), '--nnz', '100000000', '--graph-seed', '0',
+                                    '--balance', 'nnz', '--chunks', '4', '--sample', '2000', '--split-threshold', '1024'))
+    got = np.load(out)
+    assert normwise(got['users'], ref[ur].cpu().numpy()) <= 1e-5 and normwise(got['items'], ref[ir].cpu().numpy()) <= 1e-5

@@ -200,3 +200,21 @@ def test_segment_heuristic_picks_item_rows_of_config_2_only():
     u, i = synth.interactions(600, 300, 9000, seed=1)
     gs = NormGraph.from_pairs(u, i, 600, 300)
     assert [segment_blocks_auto(gs.rowptr, gs.colidx, sp, 64) for sp in [(0, 600, 600, 900), (600, 900, 0, 600)]] == [0, 0]
+
+
+def test_hot_row_rule_for_tables_beyond_the_infinity_cache():
+    """propagate.segment_blocks_auto, round 4: over a gather table larger than the Infinity Cache (config 4's 1.28 GB user table) only
+    the LONG rows are cut, at 8 MB windows -- (blocks, classes, min_row_len) -- and only where such rows hold enough entries; the
+    rule needs row lengths only (no column scan)."""
+    from textgcn_amd.propagate import segment_blocks_auto
+    n_cols, d = 5_000_000, 64
+    lens = np.concatenate([np.full(100, 50_000), np.full(5000, 20)])
+    rowptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    got = segment_blocks_auto(rowptr, None, (0, len(lens), 0, n_cols), d)
+    assert got == (160, 8, 640)
+    assert segment_blocks_auto(rowptr, None, (0, len(lens), 0, n_cols), 128) == (312, 8, 1248)
+    short = np.concatenate([[0], np.cumsum(np.full(200_000, 30))]).astype(np.int64)
+    assert segment_blocks_auto(short, None, (0, 200_000, 0, n_cols), d) == 0            # nothing long enough to cut
+    few = np.concatenate([[0], np.cumsum(np.concatenate([np.full(3, 1000), np.full(400_000, 30)]))]).astype(np.int64)
+    assert segment_blocks_auto(few, None, (0, 400_003, 0, n_cols), d) == 0              # long rows exist but hold < 10 % of the entries
+    assert segment_blocks_auto(rowptr, None, (0, len(lens), 0, 600_000), d) == 0        # 154 MB table: inside the Infinity Cache

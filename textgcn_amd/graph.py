@@ -220,8 +220,8 @@ def row_groups(rowptr, rows=None, threshold=None, max_rows=8, target_entries=64,
 def segment_plan_arrays(rowptr, colidx, vals, phases, tile_entries=256, n_classes=8, min_row_len=0):
     """Host arrays of a tgcn_segment_plan_t (XCD-affine column blocking, include/tgcn.h).
 
-    phases: list of (row_begin, row_end, col_lo, col_hi, n_blocks[, n_classes]) -- row ranges whose entries fall in one column
-    range, cut into n_blocks column blocks (a multiple of the phase's n_classes: 8 = one class per XCD, 4 = two XCDs share a
+    phases: list of (row_begin, row_end, col_lo, col_hi, n_blocks[, n_classes[, min_row_len]]) -- row ranges whose entries fall in one
+    column range (the optional seventh member overrides `min_row_len` for the phase), cut into n_blocks column blocks (a multiple of the phase's n_classes: 8 = one class per XCD, 4 = two XCDs share a
     class -- for a table of which a QUARTER fits an L2: half the pieces per row).  The entries of a phase are copied into
     n_classes streams: stream x holds the entries of blocks x, x + n_classes, ... ordered by (block, row, column).
     A row's run inside one block is a segment; streams are cut into tiles of `tile_entries` entries (one wavefront
@@ -262,8 +262,9 @@ def segment_plan_arrays(rowptr, colidx, vals, phases, tile_entries=256, n_classe
         lens = np.diff(rowptr[r0:r1 + 1])
         rows = np.repeat(np.arange(n_r, dtype=np.int64), lens)
         ent_off = np.arange(a, b, dtype=np.int64)
-        if min_row_len > 0:       # short rows leave too few entries per block: they stay direct
-            keep = (lens >= min_row_len)[rows]
+        mrl = int(ph[6]) if len(ph) > 6 else min_row_len
+        if mrl > 0:               # short rows leave too few entries per block: they stay direct
+            keep = (lens >= mrl)[rows]
             cols, rows, ent_off = cols[keep], rows[keep], ent_off[keep]
             if len(cols) == 0:
                 continue

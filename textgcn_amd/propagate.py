@@ -24,6 +24,11 @@ SEGMENT_TWO_PHASE = True        # tiles alone (the XCDs' L2s hold only their blo
                                 # direct rows side by side in a second launch (tgcn_spmm_segmented_f32 flags bit 16): config 2 -6 %, same bits
 
 
+HOT_MIN_TABLE_BYTES = 256 << 20  # hot-row mode applies to gather tables beyond the Infinity Cache
+HOT_WINDOW_BYTES = 8 << 20      # hot-row mode: width of a column block of the gathered table (config 4: 104 .. 312 blocks within 1 %)
+HOT_ENTRIES_PER_BLOCK = 4       # ... a row is cut when it leaves at least this many entries per block (config 4: 500 .. 800 entries best)
+
+
 def segment_blocks_auto(rowptr, colidx, spec, d):
     """Number of XCD-affine column blocks for one (row_begin, row_end, col_lo, col_hi) row range, or 0 to keep it on
     the one-wave-per-row kernel.  Segmenting pays when the gathered table misses an XCD's L2 but an eighth of it fits,
@@ -33,9 +38,25 @@ def segment_blocks_auto(rowptr, colidx, spec, d):
     r0, r1, c0, c1 = spec
     row_bytes = 4 * d
     table = (c1 - c0) * row_bytes
-    if d not in (64, 128, 256) or table <= L2_SHARE_BYTES or table > SEGMENT_CLASSES * (L2_SHARE_BYTES + (L2_SHARE_BYTES >> 2)):
+    if d not in (64, 128, 256) or table <= L2_SHARE_BYTES:
         return 0
     a, b = int(rowptr[r0]), int(rowptr[r1])
+    if table > SEGMENT_CLASSES * (L2_SHARE_BYTES + (L2_SHARE_BYTES >> 2)):
+        if table <= HOT_MIN_TABLE_BYTES:      # between the two rules nothing measured pays (config 3: +-2 % whatever the blocks)
+            return 0
+        # HOT-ROW mode (round 4; config 4's item rows over the 1.28 GB user table).  No eighth of such a table fits an L2 -- but the
+        # long rows of a Zipf graph are many: 22 k item rows of >= 640 entries hold 38 % of config 4's item-row entries, and inside a
+        # window of ~32 k users those rows reference each user row ~5 times.  Cutting ONLY them at windows of 8 MB (pieces summed in
+        # column order, as every segmented row) makes those re-references hits instead of 256-byte row fetches from HBM: 22.8 ->
+        # 21.6 ms per config-4 forward (profiles/r04_experiments.md section 7).  Short rows stay one chain: a piece per window
+        # would cost them more than their gathers.
+        nb = min(1024, ((-(-table // HOT_WINDOW_BYTES) + 7) // 8) * 8)
+        mrl = HOT_ENTRIES_PER_BLOCK * nb
+        lens = np.diff(np.asarray(rowptr[r0:r1 + 1], dtype=np.int64))
+        hot_entries = int(lens[lens >= mrl].sum())
+        if hot_entries < max(1 << 20, 0.1 * (b - a)):
+            return 0
+        return (int(nb), SEGMENT_CLASSES, int(mrl))
     if b - a < (1 << 20) or (b - a) / max(r1 - r0, 1) < 8 * SEGMENT_CLASSES:
         return 0
     counts = np.bincount(np.asarray(colidx[a:b], dtype=np.int64) - c0, minlength=c1 - c0)
