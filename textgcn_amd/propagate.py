@@ -30,8 +30,9 @@ HOT_ENTRIES_PER_BLOCK = 4       # ... a row is cut when it leaves at least this 
 
 
 def segment_blocks_auto(rowptr, colidx, spec, d):
-    """Number of XCD-affine column blocks for one (row_begin, row_end, col_lo, col_hi) row range, or 0 to keep it on
-    the one-wave-per-row kernel.  Segmenting pays when the gathered table misses an XCD's L2 but an eighth of it fits,
+    """Column blocks for one (row_begin, row_end, col_lo, col_hi) row range: 0 = keep it on the row-group kernel; n = n XCD-affine
+    blocks (one class per XCD) for every row of at least SEGMENT_MIN_ROW_LEN entries; (n, classes, min_row_len) = the hot-row mode
+    of tables beyond the Infinity Cache (only rows of at least min_row_len entries are cut; see below).  Segmenting pays when the gathered table misses an XCD's L2 but an eighth of it fits,
     the hottest rows do not already serve most gathers from L2 (Zipf-popular items do), and a row leaves enough
     entries per block to amortise the extra workspace round trip (measured on BASELINE config 2: item rows, mean 100
     entries, +16 %; user rows, mean 50 entries over a Zipf table, -30 %)."""
