@@ -857,7 +857,8 @@ def run_sharded(args, world, rank, local_rank, dev, dev_index, rehearsal):
         t = reduce_max_sum([max(t_wall, t_dev)])[0][0]
         d_local = sp.dl if args.shard == 'features' else d
         roofline = spmm_roofline(nnz_local, n_rows_local, n_src, d_local, K, t_dev, args.steps, None, 'no PMC pass for this mode', dev,
-                                 gather=False, kernel='one SpMM layer on this rank = 2 x chunks launches of k_spmm_groups (+ k_spmm_long_reduce)')
+                                 gather=False, kernel='one SpMM layer on this rank = one launch pair per row chunk (2 x chunks): k_spmm_groups + k_spmm_long_reduce, or '
+                                        'k_spmm_seg + k_spmm_reduce_groups for the chunks config.xcd_segments counts')
         roofline['note'] = 'per rank: this rank\'s row blocks, launch time includes waiting for the all-gathered tables'
         result = {
             'metric': f'propagated edges/sec ({K}-layer SpMM, d={d})', 'value': args.steps * K * graph.nnz / t, 'unit': 'edges/s',
