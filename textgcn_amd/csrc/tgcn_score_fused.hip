@@ -1147,14 +1147,23 @@ Plan make_plan(int B, int I, int d, int k)
     if (prefilter_supports(d))
         o += align256((size_t)((B + 255) / 256) * 256 * 2 * p.Wh * sizeof(unsigned));   // rows of the bf16 filter's padded users
     // the wide bf16 filter (K split between two waves per SIMD) logs into 4 segments per (user, split) -- (tile, row half) of the
-    // lane that finished the pair -- and k_refine reads one segment per lane: at most 16 splits.  As few splits as fill the chip
-    // ONCE (one 512-thread workgroup per CU: 256 workgroups): a workgroup's prologue -- its users' fragments, ~35 us by the cycle
-    // stamps -- is then paid once per call, not once per generation of workgroups (8192 users: 64 tiles x 4 splits).
+    // lane that finished the pair -- and k_refine reads one segment per lane: at most 16 splits.  One 512-thread workgroup per CU
+    // (256 at a time); a workgroup pays a prologue (its users' fragments, ~35 us by the cycle stamps = ~9 units of 64 items) and
+    // then its split's units, so a call costs generations x (prologue + units / splits).  8192 users: 64 tiles x 4 splits fill the
+    // chip once; 12 288 users: 96 x 2 would leave a quarter of the CUs idle and 96 x 3 a second generation of 32 -- 96 x 8 = three
+    // full generations is 20 % shorter (profiles/r04_c5_call_sweep.jsonl).
     {
         const int tiles = (B + 127) / 128;
         const int units = (I + kStage - 1) / kStage;
-        int sw = max(1, min(16, 256 / max(tiles, 1)));
-        sw = max(1, min(sw, units / 8));                       // at least 8 units per split
+        constexpr int kPrologueUnits = 9;
+        int sw = 1;
+        long best = -1;
+        for (int c = 1; c <= 16 && c <= max(1, units / 8); ++c) {         // at least 8 units per split
+            const long gens = ((long)tiles * c + 255) / 256;
+            const long cost = gens * (kPrologueUnits + (units + c - 1) / c);
+            if (best < 0 || cost < best)
+                best = cost, sw = c;
+        }
         p.ips_w = ((units + sw - 1) / sw) * kStage;
         p.S_w = (I + p.ips_w - 1) / p.ips_w;
         p.cap2_w = max(p.cap2, (64 * 64) / (4 * p.S_w));       // 4096 log entries per user in all (~550 are used at K = 960)

@@ -80,6 +80,8 @@ class LTRLinear(LightGCN):
     """reference: TextGCN/ltr_models.py:38-210 (LTRBase + LTRLinear)."""
 
     ltr_predict_chunk = 8192    # users per folded scoring call (their [B, K] operand is built per call)
+    predict_streams = 2         # the wide filter owns its CUs: a third call in flight only queues (config 5: 33.1 ms against 34.9-36.4
+                                # with four, profiles/r04_c5_call_sweep.jsonl)
 
     def __init__(self, params, dataset):
         super().__init__(params, dataset)
