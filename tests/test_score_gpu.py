@@ -510,11 +510,13 @@ def test_prefilter_wide_rows_identical(cuda):
     _fused_vs_dense(cuda, u, it2.astype(np.float32), k, mask=_rand_mask(rng, b, i, 0, 60), round4=False)
 
 
-@pytest.mark.parametrize('b,i,d', [(33000, 8200, 264), (700, 16500, 960), (4100, 9000, 512)])
+@pytest.mark.parametrize('b,i,d', [(33000, 8200, 264), (700, 16500, 960), (4100, 9000, 512), (6200, 16500, 264), (12300, 8200, 264)])
 def test_prefilter_wide_split_counts(cuda, b, i, d):
-    """The wide filter takes as few item splits as fill the chip once (tgcn_score_fused.hip make_plan): 1 split for hundreds of user
-    tiles, 16 for a handful, with the per-segment log capacity scaled to match (4 segments per split and user, 4096 log entries per
-    user in all).  Both ends of that range, and an odd tile count, against the fp32 path bit for bit."""
+    """The wide filter's item splits come from generations x (prologue + units per split) (tgcn_score_fused.hip make_plan): 1-2 splits
+    for hundreds of user tiles, 16 for a handful, with the per-segment log capacity scaled to match (4 segments per split and user,
+    4096 log entries per user in all); its (split, tile) pairs are dealt to the XCDs in groups of 32 that may straddle two splits.
+    Both ends of that range, an odd tile count, and tile counts that are no multiple of 32 (49, 97: the last group of a split is
+    shared with the next split's first tiles) against the fp32 path bit for bit."""
     from textgcn_amd import scoring
     rng = np.random.default_rng(b + d)
     u = torch.from_numpy((rng.standard_normal((b, d)) * 0.1).astype(np.float32)).to(cuda)
