@@ -337,12 +337,17 @@ def test_scoring_at_config5_folded_width(cuda, oracle):
     assert np.array_equal(bits(v.cpu().numpy()[rows]), bits(rv))
 
 
-@pytest.mark.parametrize('b,i,d', [(300, 200_000, 64), (48, 1_000_000, 64), (48, 1_700_000, 64), (64, 140_000, 256)])
+@pytest.mark.parametrize('b,i,d', [(300, 200_000, 64), (48, 1_000_000, 64), (48, 1_700_000, 64), (40, 2_000_000, 64), (33, 2_200_000, 64),
+                                   (40, 2_150_000, 128), (64, 140_000, 256), (4200, 140_001, 128), (4130, 131_073, 50), (260, 131_137, 64)])
 def test_fused_topk_very_large_catalogue(cuda, b, i, d):
-    """Large catalogues (config 4 has 2 M items).  Narrow rows keep the in-kernel sample while a user's bitmap row fits LDS (every 8th
-    item up to 0.8 M items, every 16th up to 1.5 M: 200 000 and 1 000 000); beyond that, and for wide rows beyond 131 072 items, the
-    threshold comes from the mask + workgroup-per-row top-k on a stride-32 sample instead of k_tau, and the fallback bookkeeping is
-    cleared by a memset (1 700 000; 140 000 x 256).  Same contract everywhere: equal to the dense path."""
+    """Large catalogues (config 4 has 2 M items).  Narrow rows keep the in-kernel sample (two values per user and block of 128 sampled
+    items reach k_tau) at the density whose bitmap row fits k_sample_bits' LDS: every 8th item up to 1.0 M items, every 16th up to
+    2.1 M (200 000; 1 000 000 on the boundary; 1 700 000; config 4's 2 000 000), every 32nd beyond (2 200 000; 2 150 000 x 128).  Wide
+    rows beyond 131 072 items take the threshold from the mask + workgroup-per-row top-k on a stride-32 sample of all scores instead
+    of k_tau, and the fallback bookkeeping is cleared by a memset (140 000 x 256).  From 131 072 items on the narrow filter also keeps
+    its stage summary and k_rescore reads the flagged stages' words only: both stage sizes (d <= 64: 256 items, d <= 128: 128), both
+    consumers (calls up to 4096 users select inside k_rescore; 4200 / 4130 users take the separate selection), catalogues ending inside
+    a stage and inside a 64-item unit.  Same contract everywhere: equal to the dense path."""
     rng = np.random.default_rng(77)
     k = 40
     u = (rng.standard_normal((b, d)) * 0.1).astype(np.float32)

@@ -122,8 +122,17 @@ int launch_sample_pack_top(const float *U, const int64_t *user_ids, int B, const
 int launch_user_bound(const float *U, const int64_t *user_ids, int B, int d, float *ubound /* [B][2] */, hipStream_t stream);
 size_t item_pack_bytes(int I, int d);      // 0: no bf16 candidate pass for this width
 int launch_item_pack(const float *It, int I, int d, void *pack, hipStream_t stream);
+// The narrow bf16 filter's stage summary (large catalogues): one bit per LDS stage and (user, row half) -- some pass-bit word of the
+// stage is non-zero -- as [B padded to 256][2][n_splits][sw] words; k_rescore then reads the flagged stages' words only.
+struct PassSummary {
+    unsigned *words = nullptr;      // NULL: none kept (the consumer scans every pass-bit word)
+    int sw = 0;                     // summary words per (user, row half, split) = ceil(stages per split / 32)
+    int n_splits = 0, items_per_split = 0, stage_items = 0;
+};
+int prefilter_stage_items(int d);   // items per LDS stage of launch_prefilter's kernel for this width
 int launch_prefilter(const float *U, const int64_t *user_ids, int B, const void *ipack, int I, int d, const float *tau, int tau_stride,
-                     const float *ubound, unsigned *mask, int Wh, int S, int items_per_split, bool wide, hipStream_t stream);
+                     const float *ubound, unsigned *mask, int Wh, int S, int items_per_split, bool wide, const PassSummary &summ,
+                     hipStream_t stream);
 int pack_row_bytes(int d);                 // bytes of a packed item row; its 16-byte factor chunk is the last one
 int launch_prefilter_wide(const float *U, const int64_t *user_ids, int B, const void *ipack, int I, int d, const float *tau, int tau_stride,
                           const float *ubound, void *logs, int *counts, int S, int items_per_split, int cap2, hipStream_t stream);
@@ -132,12 +141,13 @@ int launch_sample_wide(const float *U, const int64_t *user_ids, int B, const voi
 int launch_rescore_list(const float *U, const int64_t *user_ids, int B, const float *It, int d, const float *tau, int tau_stride,
                         const int *surv, const int *surv_n, int surv_cap, void *lists, int *totals, int list_cap, hipStream_t stream);
 int launch_rescore(const float *U, const int64_t *user_ids, int B, const float *It, int d, const float *tau, int tau_stride,
-                   const unsigned *mask, int Wh, int n_units, void *lists, int *totals, int list_cap, hipStream_t stream);
+                   const unsigned *mask, int Wh, int n_units, const PassSummary &summ, void *lists, int *totals, int list_cap,
+                   hipStream_t stream);
 // the narrow rows' fp32 chains AND the exact selection of the top k in one launch (k_rescore<.., SELECT>): writes out_val / out_idx,
 // flags the users it leaves to the exact fallback
 int launch_rescore_select(const float *U, const int64_t *user_ids, int B, const float *It, int d, const float *tau, int tau_stride,
-                          const unsigned *mask, int Wh, int n_units, int *totals, const int *mask_rowptr, const int *mask_items, int k,
-                          int do_round, float *out_val, int64_t *out_idx, int *flagged, hipStream_t stream);
+                          const unsigned *mask, int Wh, int n_units, const PassSummary &summ, int *totals, const int *mask_rowptr,
+                          const int *mask_items, int k, int do_round, float *out_val, int64_t *out_idx, int *flagged, hipStream_t stream);
 int launch_topk(const float *S, int64_t lds, int B, int I, int k, int do_round, float *out_val, int64_t *out_idx,
                 hipStream_t stream);
 int launch_mask(float *S, int64_t lds, int B, int I, const int *mask_rowptr, const int *mask_items, int item_div,

@@ -37,6 +37,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int kSampleStride = 32;  // items per sampled item (16 where the denser sample pays: make_plan)
 constexpr double kBarRisk = 3e-6;  // per user: the chance that the bar tau_u lands above the user's k-th best score (-> exact fallback)
 constexpr int kUsersPerWG = 128;   // 4 waves x 32 users
+constexpr int kSummaryMinWords = 2048;   // pass-bit words per (user, row half) from which the bf16 filter keeps its stage summary (131 072 items)
 constexpr int kStage = 64;         // items per LDS stage (2 MFMA sub-tiles of 32)
 constexpr int kSmallI = 8192;      // below this the dense path (score -> mask -> top-k) is used
 
@@ -1050,6 +1051,8 @@ struct Plan {
     int S_w, ips_w, cap2_w;                 // wide bf16 filter: its own (at most 16) item splits -- 4 log segments of cap2_w per split and user
     int Wh;                                 // mask words per (user, row half): the 64-item units of the catalogue, padded to 4
     size_t off_mask;
+    size_t off_summ;                        // the narrow bf16 filter's stage summary (PassSummary), summ_words per (user, row half); 0: none
+    int summ_words;
     size_t off_sample, off_tauv, off_taui, off_tau, off_ubound, off_ipack, off_logs, off_counts, off_parts, off_flags, off_done, off_totals, off_surv, off_surv_n, off_stats, total;
     int n_seg;                              // log segments per user (2 S; the wide bf16 filter: 4 S_w)
     int flag_cap;
@@ -1086,15 +1089,18 @@ int bar_rank(int k, int stride)
 // runs on the bf16 pipe and keeps its scores to itself (the TOP forms: two values per user and 128-sample block reach k_tau), so a
 // denser sample costs MFMAs, not traffic.  The prefiltered entry point reads the sampled rows from the pack (k_sample_pack_top,
 // 19 us per 16 384 x 6250 x 64): every 8th item; the fp32 entry point converts them itself (k_sample_bf16, twice the time): every
-// 16th.  At K = 960 the sample is a tenth of the filter and k_refine's second bar decides what is rescored: every 32nd item, all
-// scores to k_tau, as before; so do catalogues whose bitmap row would not fit k_sample_bits' LDS (above 0.8 / 1.5 M items) and
-// catalogues too small for the blocks to resolve the rank (below ~35 000 items at k = 40).
+// 16th.  Catalogues whose bitmap row would not fit k_sample_bits' LDS at that density (above 1.0 / 2.1 M items) take every 16th /
+// 32nd / 64th item, still in the TOP form: with ALL sample scores written and ranked by k_mask + k_topk (round 3's form for them) a
+// 2048-user call on config 4's 2 M items spent 118 + 6 + 178 us of its 1063 on the bar -- the sample pass was a 512 MB store
+// (profiles/r04_experiments.md section 9).  At K = 960 the sample is a tenth of the filter and k_refine's second bar decides what
+// is rescored: every 32nd item, all scores to k_tau, as before; so do catalogues too small for the blocks to resolve the rank
+// (below ~35 000 items at k = 40) and beyond 8 M items.
 void set_sample(Plan &p, int I, int d, int k, bool from_pack)
 {
     // the densest TOP form whose blocks still resolve the rank: k_tau sees two values per block of 128 sampled items, and with fewer
     // than ~2 rank blocks several of a user's `rank` best share a block (the bar then sits ranks lower than asked for -- at 9 blocks
     // and rank 22 it would fall off the end: tau = -inf, every user to the exact fallback)
-    for (int dense = from_pack ? 8 : 16; dense <= 16; dense *= 2) {
+    for (int dense = from_pack ? 8 : 16; dense <= 64; dense *= 2) {
         const int m = (I + dense - 1) / dense, n_blk = (m + 127) / 128, rank = bar_rank(k, dense);
         if (sample_top_supports(d, m) && n_blk >= 2 * rank) {
             p.top = true, p.stride = dense, p.rank = rank, p.m = m, p.m_rank = 2 * n_blk;
@@ -1146,6 +1152,12 @@ Plan make_plan(int B, int I, int d, int k)
     p.off_mask = o;
     if (prefilter_supports(d))
         o += align256((size_t)((B + 255) / 256) * 256 * 2 * p.Wh * sizeof(unsigned));   // rows of the bf16 filter's padded users
+    // ... and, for large catalogues, their stage summary (PassSummary): at most ceil(stages / 32) + one word per split, per row half
+    p.off_summ = o, p.summ_words = 0;
+    if (d <= 128 && prefilter_supports(d) && p.Wh >= kSummaryMinWords) {
+        p.summ_words = (p.Wh * kStage / prefilter_stage_items(d) + 31) / 32 + 40;
+        o += align256((size_t)((B + 255) / 256) * 256 * 2 * p.summ_words * sizeof(unsigned));
+    }
     // the wide bf16 filter (K split between two waves per SIMD) logs into 4 segments per (user, split) -- (tile, row half) of the
     // lane that finished the pair -- and k_refine reads one segment per lane: at most 16 splits.  One 512-thread workgroup per CU
     // (256 at a time); a workgroup pays a prologue (its users' fragments, ~35 us by the cycle stamps = ~9 units of 64 items) and
@@ -1422,17 +1434,28 @@ int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const fl
         } else if (d > 64 && I <= (1 << 18)) {
             ips_pre = 1024;      // (768 / 1280 / 2048 with the packed operand: 54 / 53 / 56 us against 46)
         }
-        if ((rc = launch_prefilter(U, user_ids, B, ipack, I, d, tau_ptr, tau_stride, ubound, mask, p.Wh, (I + ips_pre - 1) / ips_pre,
-                                   ips_pre, wide, s)) != TGCN_OK)
+        // large catalogues (one-store-per-stage form): the filter also keeps one bit per stage, and the chains' kernel reads the flagged
+        // stages' words instead of scanning the user's whole row (2 M items: 250 KB per user for ~200 set bits)
+        PassSummary summ;
+        const int n_splits_pre = (I + ips_pre - 1) / ips_pre;
+        if (wide && p.summ_words > 0) {
+            summ.stage_items = prefilter_stage_items(d);
+            summ.items_per_split = ips_pre, summ.n_splits = n_splits_pre;
+            summ.sw = (ips_pre / summ.stage_items + 31) / 32;
+            if (summ.n_splits * summ.sw <= p.summ_words)        // (always: make_plan's bound is stages / 32 + one word per split)
+                summ.words = reinterpret_cast<unsigned *>(ws + p.off_summ);
+        }
+        if ((rc = launch_prefilter(U, user_ids, B, ipack, I, d, tau_ptr, tau_stride, ubound, mask, p.Wh, n_splits_pre, ips_pre, wide, summ,
+                                   s)) != TGCN_OK)
             return rc;
         if (B <= kFuseSelectMaxUsers) {
             // small calls: the fp32 chains and the exact selection in ONE launch, the kept pairs never leave the wave's LDS (round 4)
-            rc = launch_rescore_select(U, user_ids, B, It, d, tau_ptr, tau_stride, mask, p.Wh, (I + kStage - 1) / kStage, totals,
+            rc = launch_rescore_select(U, user_ids, B, It, d, tau_ptr, tau_stride, mask, p.Wh, (I + kStage - 1) / kStage, summ, totals,
                                        mask_rowptr, mask_items, k, round4, out_val, out_idx, flagged, s);
             selected = true;
         } else {
             // large calls: k_select_flat as its own launch runs 32 waves per CU where the fused kernel's LDS allows 8
-            rc = launch_rescore(U, user_ids, B, It, d, tau_ptr, tau_stride, mask, p.Wh, (I + kStage - 1) / kStage, fa.logs, totals,
+            rc = launch_rescore(U, user_ids, B, It, d, tau_ptr, tau_stride, mask, p.Wh, (I + kStage - 1) / kStage, summ, fa.logs, totals,
                                 p.S * 2 * p.cap2, s);
         }
         }

@@ -288,6 +288,12 @@ struct PreArgs {
     int Wh;
     int B, I, d, items_per_split;
     int n_tiles, n_splits;          // user tiles of 256 x item splits; the grid is linear: 8 ceil(n_tiles n_splits / 8) workgroups
+    // WIDE form, large catalogues: one bit per stage and (user, row half) -- "some word of the stage is non-zero" --
+    // [B padded][2][n_splits][summ_sw] words, bit ls & 31 of word ls >> 5 for the split's stage ls; NULL: not kept.
+    // k_rescore then reads 1 / (32 x words per stage) of the pass-bit area and the words of the flagged stages only (config 4: a
+    // user's row is 250 KB of words holding ~200 set bits -- the scan was most of k_rescore's 175 us there).
+    unsigned *__restrict__ summ;
+    int summ_sw;
 };
 
 // KS = 16-wide k-steps per dot product (d <= 16 KS).  Items on MFMA rows (A operand, LDS stages of ST rows of bf16), the wave's
@@ -471,6 +477,24 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
             t.v[i] = wv[i];
         *reinterpret_cast<Words *>(dst) = t;
     };
+    // the stage summary (WIDE, a.summ != NULL): the running word of 32 stages, stored when its last stage is noted (the condition
+    // is wave-uniform: a scalar branch) and once more at the split's end
+    unsigned sm = 0u;
+    unsigned *__restrict__ srow = nullptr;
+    if constexpr (WIDE) {
+        if (a.summ)
+            srow = a.summ + (((size_t)user * 2 + h) * a.n_splits + split) * a.summ_sw;
+    }
+    auto note_stage = [&](int ls, int n_words, bool last) {      // wv[0 .. n_words) are the final words of the split's stage ls
+        unsigned any = 0u;
+#pragma unroll
+        for (int i = 0; i < UPS; ++i)
+            any |= i < n_words ? wv[i] : 0u;
+        const unsigned bit = any != 0u ? 1u << (ls & 31) : 0u;
+        sm = (ls & 31) == 0 ? bit : (sm | bit);
+        if (srow && (last || (ls & 31) == 31))
+            srow[ls >> 5] = sm;
+    };
     auto flush_words = [&](int t) {                        // the split ended on unit t: the words of its unfinished stage
         const int k = ((t - i_beg) >> 6) % UPS;
         if (k != UPS - 1) {
@@ -537,6 +561,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
             for (int i = 0; i < UPS; ++i)
                 wv[i] = i == kk ? (user_ok ? bits : 0u) : wv[i];
             flush_words(t_prev);
+            note_stage((t_prev - i_beg) / ST, kk + 1, true);      // (words past kk are the previous stage's)
         } else {
             mrow[t_prev >> 6] = user_ok ? bits : 0u;
         }
@@ -563,8 +588,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
                 unit(No{}, t0, un, A0, A1, B0, B1, 0);
             else
                 unit(Yes{}, t0, un, A0, A1, B0, B1, t0 - kStage);
-            if (WIDE && !FIRST && un == 0)     // the previous stage's words are complete: one store per lane
+            if (WIDE && !FIRST && un == 0) {   // the previous stage's words are complete: one store per lane
                 store_words(mrow + (t0 >> 6) - UPS);
+                note_stage((s0 - i_beg) / ST - 1, UPS, false);
+            }
             t_last = t0, last_is_a = true;
             if (t0 + kStage >= i_end)
                 break;
@@ -947,7 +974,7 @@ struct SampleArgs {
     int bits_words;
 };
 
-constexpr int kSampleBitsMaxWords = 3072;     // LDS row of k_sample_bits (4 waves x 12 KB): 768 blocks = 98 304 sampled items
+constexpr int kSampleBitsMaxWords = 4096;     // LDS row of k_sample_bits (4 waves x 16 KB = the 64 KB a launch may ask for): 1024 blocks = 131 072 sampled items
 
 __global__ __launch_bounds__(256) void k_sample_bits(const int *__restrict__ mask_rowptr, const int *__restrict__ mask_items,
                                                      unsigned *__restrict__ bits, int B, int words, int stride, int m)
@@ -1309,6 +1336,7 @@ struct RescoreArgs {
     int64_t *__restrict__ out_idx;
     int *__restrict__ flagged;             // [1 + B]: count, then the users left to the exact fallback
     int k, do_round;
+    PassSummary summ;                      // the filter's stage summary (words == NULL: none, every mask word is scanned)
 };
 
 constexpr int kUserCap = 1536;      // candidates of a user held in LDS
@@ -1395,7 +1423,99 @@ __global__ __launch_bounds__(RescoreShape<SELECT>::kWaves * 64) void k_rescore(c
         for (int j = lane; j < n; j += kWave)
             ids[j] = a.surv[(size_t)b * a.surv_cap + j];
     }
-    for (int c0 = 0; !FROM_LIST && c0 < n_words; c0 += kWave * kChunkWords) {
+    bool summarised = false;
+    if constexpr (!FROM_LIST) {
+        summarised = a.summ.words != nullptr;
+        if (summarised) {
+            // (1a) the flagged stages of the user: lane l of a chunk reads summary word c0 + l; bit t of word q of (half hh, split sp)
+            // is stage sp (items_per_split / stage_items) + 32 q + t.  Their codes (2 stage + hh) are parked in the tile.
+            int *stg = reinterpret_cast<int *>(tile);
+            const int per_half = a.summ.n_splits * a.summ.sw;
+            const int spl_stages = a.summ.items_per_split / a.summ.stage_items;
+            const int n_stages = (a.n_units * kStage + a.summ.stage_items - 1) / a.summ.stage_items;     // (n_units 64-item units)
+            const unsigned *__restrict__ srow = a.summ.words + (size_t)b * 2 * per_half;
+            int ns = 0;
+            for (int c0 = 0; c0 < 2 * per_half; c0 += kWave) {
+                const int j = c0 + lane;
+                unsigned sw = 0u;
+                int hh = 0, stage0 = 0;
+                if (j < 2 * per_half) {
+                    hh = j >= per_half ? 1 : 0;
+                    const int r = j - hh * per_half, sp = r / a.summ.sw, q = r - sp * a.summ.sw;
+                    stage0 = sp * spl_stages + 32 * q;
+                    // words past a split's last stage, and the splits past the catalogue, were never written
+                    if (32 * q < spl_stages && stage0 < n_stages)
+                        sw = srow[j];
+                }
+                const int mine = __popc(sw);
+                int incl = mine;
+#pragma unroll
+                for (int o = 1; o < kWave; o <<= 1) {
+                    const int t = __shfl_up(incl, o);
+                    if (lane >= o)
+                        incl += t;
+                }
+                const int chunk_n = __builtin_amdgcn_readlane(incl, kWave - 1);
+                if (ns + chunk_n > kCap) {       // more flagged stages than candidates a user may bring
+                    give_up(kOverflow);
+                    return;
+                }
+                int off = ns + incl - mine;
+                while (sw) {
+                    const int t = __ffs(sw) - 1;
+                    sw &= sw - 1u;
+                    stg[off++] = 2 * (stage0 + t) + hh;
+                }
+                ns += chunk_n;
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+            // (1b) their words -> item ids
+            const int ups = a.summ.stage_items / kStage;       // words per stage (4 at d <= 64, 2 at d <= 128)
+            for (int c0 = 0; c0 < ns; c0 += kWave) {
+                unsigned word[4] = {0u, 0u, 0u, 0u};
+                int hh = 0, u0w = 0;
+                if (c0 + lane < ns) {
+                    const int code = stg[c0 + lane];
+                    hh = code & 1;
+                    u0w = (code >> 1) * ups;                   // first 64-item unit (= word inside the row half) of the stage
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (i < ups && u0w + i < a.n_units)    // (the catalogue's last stage may be partial: its other words were never written)
+                            word[i] = mrow[hh * a.Wh + u0w + i];
+                }
+                int mine = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    mine += __popc(word[i]);
+                int incl = mine;
+#pragma unroll
+                for (int o = 1; o < kWave; o <<= 1) {
+                    const int t = __shfl_up(incl, o);
+                    if (lane >= o)
+                        incl += t;
+                }
+                const int chunk_n = __builtin_amdgcn_readlane(incl, kWave - 1);
+                if (n + chunk_n > kCap) {
+                    give_up(kOverflow);
+                    return;
+                }
+                int off = n + incl - mine;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    unsigned wd = word[i];
+                    const int base = (u0w + i) * 64 + 4 * hh;
+                    while (wd) {
+                        const int t = __clz(wd);
+                        wd &= ~(0x80000000u >> t);
+                        ids[off++] = base + (t < 16 ? 0 : 32) + (t & 3) + 8 * ((t & 15) >> 2);
+                    }
+                }
+                n += chunk_n;
+            }
+        }
+    }
+    for (int c0 = 0; !FROM_LIST && !summarised && c0 < n_words; c0 += kWave * kChunkWords) {
         unsigned word[kChunkWords];
         const int j0 = c0 + lane * kChunkWords;
         if (j0 + kChunkWords <= n_words && ((size_t)mrow & 15) == 0 && (n_words & 3) == 0) {
@@ -1702,15 +1822,20 @@ int launch_item_pack(const float *It, int I, int d, void *pack, hipStream_t s)
     return check_launch("k_item_pack");
 }
 
+int prefilter_stage_items(int d) { return d <= 64 ? 256 : 128; }      // the ST of launch_prefilter's instantiations
+
 int launch_prefilter(const float *U, const int64_t *user_ids, int B, const void *ipack, int I, int d, const float *tau, int tau_stride,
-                     const float *ubound, unsigned *mask, int Wh, int S, int items_per_split, bool wide, hipStream_t s)
+                     const float *ubound, unsigned *mask, int Wh, int S, int items_per_split, bool wide, const PassSummary &summ, hipStream_t s)
 {
     constexpr int UT = kPreWaves * 32;
     const int n_tiles = (B + UT - 1) / UT;
-    PreArgs a{U, user_ids, static_cast<const unsigned char *>(ipack), item_pack_bytes(I, d), tau, tau_stride, ubound, mask, Wh, B, I, d,
-              items_per_split, n_tiles, S};
-    const dim3 grid(8u * (unsigned)((n_tiles * S + 7) / 8)), block(kPreWaves * 64);
     wide = wide && items_per_split % 256 == 0;         // (a stage's words as one aligned store: the splits must be stage multiples)
+    if (summ.words && (!wide || summ.n_splits != S || summ.items_per_split != items_per_split || summ.stage_items != prefilter_stage_items(d) ||
+                       summ.sw != (items_per_split / summ.stage_items + 31) / 32))
+        return fail_arg("launch_prefilter: the stage summary does not describe this launch");
+    PreArgs a{U, user_ids, static_cast<const unsigned char *>(ipack), item_pack_bytes(I, d), tau, tau_stride, ubound, mask, Wh, B, I, d,
+              items_per_split, n_tiles, S, summ.words, summ.sw};
+    const dim3 grid(8u * (unsigned)((n_tiles * S + 7) / 8)), block(kPreWaves * 64);
 #define TGCN_PRE_LAUNCH(KS, FULLK, ST)                                                                          \
     do {                                                                                                        \
         if (wide)                                                                                               \
@@ -1779,10 +1904,10 @@ int launch_sample_wide(const float *U, const int64_t *user_ids, int B, const voi
 }
 
 int launch_rescore(const float *U, const int64_t *user_ids, int B, const float *It, int d, const float *tau, int tau_stride,
-                   const unsigned *mask, int Wh, int n_units, void *lists, int *totals, int list_cap, hipStream_t s)
+                   const unsigned *mask, int Wh, int n_units, const PassSummary &summ, void *lists, int *totals, int list_cap, hipStream_t s)
 {
     RescoreArgs a{U, user_ids, It, tau, tau_stride, mask, Wh, n_units, nullptr, nullptr, 0, static_cast<float2 *>(lists), totals, B, d,
-                  list_cap, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+                  list_cap, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, summ};
     if ((d & 3) == 0)
         hipLaunchKernelGGL((k_rescore<true, false>), dim3((B + 3) / 4), dim3(256), 0, s, a);
     else
@@ -1791,13 +1916,13 @@ int launch_rescore(const float *U, const int64_t *user_ids, int B, const float *
 }
 
 int launch_rescore_select(const float *U, const int64_t *user_ids, int B, const float *It, int d, const float *tau, int tau_stride,
-                          const unsigned *mask, int Wh, int n_units, int *totals, const int *mask_rowptr, const int *mask_items, int k,
-                          int do_round, float *out_val, int64_t *out_idx, int *flagged, hipStream_t s)
+                          const unsigned *mask, int Wh, int n_units, const PassSummary &summ, int *totals, const int *mask_rowptr,
+                          const int *mask_items, int k, int do_round, float *out_val, int64_t *out_idx, int *flagged, hipStream_t s)
 {
     if (d > 128)
         return fail_arg("launch_rescore_select: narrow rows only");
     RescoreArgs a{U, user_ids, It, tau, tau_stride, mask, Wh, n_units, nullptr, nullptr, 0, nullptr, totals, B, d, 0,
-                  mask_rowptr, mask_items, out_val, out_idx, flagged, k, do_round};
+                  mask_rowptr, mask_items, out_val, out_idx, flagged, k, do_round, summ};
     constexpr int WPB = RescoreShape<true>::kWaves;
     if ((d & 3) == 0)
         hipLaunchKernelGGL((k_rescore<true, false, true>), dim3((B + WPB - 1) / WPB), dim3(WPB * 64), 0, s, a);
@@ -1810,7 +1935,7 @@ int launch_rescore_list(const float *U, const int64_t *user_ids, int B, const fl
                         const int *surv, const int *surv_n, int surv_cap, void *lists, int *totals, int list_cap, hipStream_t s)
 {
     RescoreArgs a{U, user_ids, It, tau, tau_stride, nullptr, 0, 0, surv, surv_n, surv_cap, static_cast<float2 *>(lists), totals, B, d,
-                  list_cap, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+                  list_cap, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, PassSummary{}};
     hipLaunchKernelGGL((k_rescore<true, true>), dim3((B + 3) / 4), dim3(256), 0, s, a);
     return check_launch("k_rescore(list)");
 }
