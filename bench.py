@@ -57,7 +57,6 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3   # fp32 matrix peak (v_mfma_f32_32x32x2_f32)
-BUILD_ON_GPU_FROM = 10_000_000   # interactions from which NormGraph.from_pairs sorts on the GPU (same arrays bit for bit; set-up, untimed)
 MFMA_BF16_PEAK_TF = 2500.0 # dense bf16 matrix peak (v_mfma_f32_32x32x16_bf16; MI355X_MICROARCH.md: ~2.5 PF dense)
 SPMM_SOURCES = ('textgcn_amd/csrc/tgcn_spmm.hip', 'textgcn_amd/propagate.py', 'textgcn_amd/graph.py')
 
@@ -495,7 +494,7 @@ def record_single_gpu(wl, dev, args, steps, warmup, cpu=True, scoring=True, trai
     n_u, n_i, nnz, d, K = synth.CONFIGS[wl]
     t0 = time.time()
     u, i = synth.interactions(n_u, n_i, nnz, seed=0)
-    graph = NormGraph.from_pairs(u, i, n_u, n_i, device=dev if nnz >= BUILD_ON_GPU_FROM else None)
+    graph = NormGraph.from_pairs(u, i, n_u, n_i)
     if not train:
         del u, i
     e0 = synth.embeddings(graph.n, d, seed=0)
@@ -750,7 +749,7 @@ def record_train_step(dev, u, i, graph, n_u, n_i, d, K, steps=10):
             'through': 'textgcn_amd.LightGCN._train_epoch (get_loss -> backward -> optimizer.step, as fit() does)'}
 
 
-def shared_workload(wl, rank, local_rank, barrier, dev=None):
+def shared_workload(wl, rank, local_rank, barrier):
     """N > 1: the synthetic graph and E0 are generated ONCE per node -- local rank 0 builds them (30 s and ~12 GB of host memory
     for config 4; eight concurrent builds would be eight times both) and publishes the arrays as .npy files in a node-local
     directory (memory-backed /dev/shm when present), the other ranks wait at a barrier and memory-map them: a rank then only
@@ -769,7 +768,7 @@ def shared_workload(wl, rank, local_rank, barrier, dev=None):
         os.makedirs(path, exist_ok=True)
         atexit.register(shutil.rmtree, path, ignore_errors=True)
         u, i = synth.interactions(n_u, n_i, nnz, seed=0)
-        g = NormGraph.from_pairs(u, i, n_u, n_i, device=dev if nnz >= BUILD_ON_GPU_FROM else None)
+        g = NormGraph.from_pairs(u, i, n_u, n_i)
         del u, i
         for name, arr in (('rowptr', g.rowptr), ('colidx', g.colidx), ('vals', g.vals),
                           ('e0', synth.embeddings(g.n, d, seed=0).numpy())):
@@ -815,10 +814,10 @@ def run_sharded(args, world, rank, local_rank, dev, dev_index, rehearsal):
     t0 = time.time()
     share_dir = None
     if world > 1:
-        graph, e0, share_dir = shared_workload(wl, rank, local_rank, dist.barrier, dev)
+        graph, e0, share_dir = shared_workload(wl, rank, local_rank, dist.barrier)
     else:
         u, i = synth.interactions(n_u, n_i, nnz, seed=0)
-        graph = NormGraph.from_pairs(u, i, n_u, n_i, device=dev if nnz >= BUILD_ON_GPU_FROM else None)
+        graph = NormGraph.from_pairs(u, i, n_u, n_i)
         del u, i
         e0 = synth.embeddings(graph.n, d, seed=0)
     build_s = time.time() - t0

@@ -366,32 +366,3 @@ def test_row_groups_bit_identical_to_one_wave_per_row(cuda, oracle, d, unroll):
         assert torch.equal(y2.view(torch.int32), y.view(torch.int32))
         assert np.array_equal(bits(acc.cpu().numpy()[short]), bits((acc_in + ref).astype(np.float32)[short])), thr
 
-
-def test_from_pairs_on_the_gpu_builds_the_same_arrays(cuda, golden):
-    """NormGraph.from_pairs(device=...) sorts and counts on the GPU: rowptr / colidx / values equal the host builder's bit for bit
-    (and with them the reference's matrices the host builder is pinned to, tests/test_graph_host.py) -- goldens, repeated pairs,
-    isolated nodes, a node of degree 1 beside one of degree 10^4 (deg^-0.5 over four decades), the empty graph."""
-    from textgcn_amd.graph import NormGraph
-    cases = []
-    for name, prefix in (('g1_dummy', ''), ('g2_synth60', ''), ('g5_medium', '')):
-        g = golden(name)
-        cases.append((g[prefix + 'train_u'], g[prefix + 'train_i'], int(g[prefix + 'n_users']), int(g[prefix + 'n_items'])))
-    rng = np.random.default_rng(11)
-    for n_u, n_i, m in ((1, 1, 1), (7, 5, 0), (300, 170, 4000), (5000, 90, 60000), (20000, 12000, 300000)):
-        u = rng.integers(0, max(n_u - 2, 1), m)                      # the last users / items stay isolated
-        i = (rng.zipf(1.3, m) - 1) % max(n_i - 2, 1)
-        cases.append((u, i, n_u, n_i))
-    u = np.concatenate([np.zeros(10000, np.int64), [1]])
-    i = np.concatenate([np.arange(10000), [0]])
-    cases.append((u, i, 3, 10001))
-    assert len(cases) >= 6
-    for u, i, n_u, n_i in cases:
-        host = NormGraph.from_pairs(u, i, n_u, n_i)
-        dev = NormGraph.from_pairs(u, i, n_u, n_i, device=cuda)
-        assert np.array_equal(dev.rowptr, host.rowptr) and dev.rowptr.dtype == host.rowptr.dtype
-        assert np.array_equal(dev.colidx, host.colidx) and dev.colidx.dtype == host.colidx.dtype
-        assert np.array_equal(bits(dev.vals), bits(host.vals)) and dev.vals.dtype == host.vals.dtype
-    with pytest.raises(ValueError):
-        NormGraph.from_pairs([0, 5], [0, 1], 3, 3, device=cuda)
-    with pytest.raises(ValueError):
-        NormGraph.from_pairs([0], [0], 3, 3, device='cpu')

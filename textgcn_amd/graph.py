@@ -5,8 +5,9 @@ produces -- a coalesced COO matrix sorted by (row, col) with fp32 values -- with
 dgl detour (infeasible at nnz = 100M).  Index work is integer and bit-exact; values follow
 the reference's float64 expression (d_r * a_rc) * d_c rounded once to fp32.
 
-Host side is numpy (this is one-off graph construction, not the timed path; `from_pairs(device=...)` moves its sorts to the
-GPU for graphs of config 4's size); device side is three int32 / fp32 torch tensors handed to the C ABI by pointer.
+Host side is numpy (this is one-off graph construction, not the timed path: config 4's 100 M pairs take ~6 s on the GPU box's
+host cores -- the same steps through torch on the GPU took 75 s, profiles/r04_experiments.md section 10); device side is three
+int32 / fp32 torch tensors handed to the C ABI by pointer.
 """
 from dataclasses import dataclass
 
@@ -41,16 +42,11 @@ class NormGraph:
 
     # ------------------------------------------------------------------ builders
     @classmethod
-    def from_pairs(cls, train_u, train_i, n_users, n_items, device=None):
+    def from_pairs(cls, train_u, train_i, n_users, n_items):
         """Build from the train interactions (internal ids), as dataset.py:122-138 does.
 
         A = R^ + R^T (duplicate train rows add up, dataset.py:132), deg = row sums (:133),
         d = deg^-0.5 in float64 with inf -> 0 (:134-135), value = (d_r * a_rc) * d_c (:136-137) -> fp32 (:156).
-
-        device: a GPU to do the two sorts, the counts and the value products on (config 4's 100 M pairs: ~30 s of numpy -> about a
-        second); the same arrays bit for bit -- the keys and counts are integers, the degrees are sums of integers below 2^53 (exact in
-        any order), deg^-0.5 is still taken on the host by the same numpy call (a device pow may round differently), and the two
-        float64 products and the rounding to fp32 are IEEE operations on either side.  The result lives on the host as before.
         """
         u = _as_index(train_u, 'train_u')
         i = _as_index(train_i, 'train_i')
@@ -62,8 +58,6 @@ class NormGraph:
             raise ValueError('graph too large for int32 indices')
         if len(u) and (u.min() < 0 or u.max() >= n_users or i.min() < 0 or i.max() >= n_items):
             raise ValueError('interaction id out of range')
-        if device is not None:
-            return cls._from_pairs_on_device(u, i, n_users, n_items, device)
         # user rows: key = u * n_items + i ; item rows: key = i * n_users + u  (two half-size sorts)
         ku, mu = np.unique(u * np.int64(max(n_items, 1)) + i, return_counts=True)
         ki, mi = np.unique(i * np.int64(max(n_users, 1)) + u, return_counts=True)
@@ -80,39 +74,6 @@ class NormGraph:
         rowptr = np.zeros(n + 1, dtype=np.int64)
         np.cumsum(np.bincount(rows, minlength=n), out=rowptr[1:])
         return cls(n_users, n_items, rowptr, cols.astype(np.int32), vals)
-
-    @classmethod
-    def _from_pairs_on_device(cls, u, i, n_users, n_items, device):
-        """from_pairs with the sorts on a GPU (validated ids, int64, on the host); see from_pairs for why the bits are the same."""
-        import torch
-        dev = torch.device(device)
-        if dev.type != 'cuda':
-            raise ValueError(f'from_pairs(device=...) is for a GPU, got {dev}')
-        n = n_users + n_items
-        ut, it = torch.from_numpy(u).to(dev), torch.from_numpy(i).to(dev)
-        ni, nu = max(n_items, 1), max(n_users, 1)
-        ku, mu = torch.unique(ut * ni + it, sorted=True, return_counts=True)
-        ki, mi = torch.unique(it * nu + ut, sorted=True, return_counts=True)
-        del ut, it
-        ru = torch.div(ku, ni, rounding_mode='floor')
-        cu = ku - ru * ni
-        ri = torch.div(ki, nu, rounding_mode='floor')
-        ci = ki - ri * nu
-        del ku, ki
-        rows = torch.cat([ru, ri + n_users])
-        cols = torch.cat([cu + n_users, ci])
-        mult = torch.cat([mu, mi]).to(torch.float64)
-        del ru, cu, ri, ci, mu, mi
-        deg = torch.zeros(n, dtype=torch.float64, device=dev).index_add_(0, rows, mult)    # sums of integers: exact in any order
-        with np.errstate(divide='ignore'):
-            d_inv = np.power(deg.cpu().numpy(), -0.5)
-        d_inv[np.isinf(d_inv)] = 0.0
-        d_inv = torch.from_numpy(d_inv).to(dev)
-        vals = ((d_inv[rows] * mult) * d_inv[cols]).to(torch.float32)
-        counts = torch.bincount(rows, minlength=n)
-        rowptr = np.zeros(n + 1, dtype=np.int64)
-        np.cumsum(counts.cpu().numpy(), out=rowptr[1:])
-        return cls(n_users, n_items, rowptr, cols.to(torch.int32).cpu().numpy(), vals.cpu().numpy())
 
     @classmethod
     def from_coo(cls, idx, val, n_users, n_items):
