@@ -152,6 +152,23 @@ def main():
         f = max(glob.glob(os.path.join(args.kt, '*', '*kernel_stats.csv')), key=os.path.getmtime)   # newest run
         shutil.copyfile(f, os.path.join(prof, f'{args.round}_kernel_stats.csv'))
         print('kernel stats ->', f'profiles/{args.round}_kernel_stats.csv')
+        # the stats file averages a kernel over every configuration of the bench run (c2's and c4's layers are the same two kernels):
+        # the trace split by grid size gives the per-configuration layer launches bench.py's roofline.launch_us has to agree with
+        tr = f.replace('kernel_stats.csv', 'kernel_trace.csv')
+        if os.path.exists(tr):
+            import collections
+            import csv
+            groups = collections.defaultdict(list)
+            for r in csv.DictReader(open(tr)):
+                n = short(r['Kernel_Name'])
+                if n.startswith('k_spmm'):
+                    groups[(n, int(r['Grid_Size_X']))].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+            table = [{'kernel': k, 'grid_threads': g, 'calls': len(v), 'avg_us': round(sum(v) / len(v) / 1e3, 1),
+                      'min_us': round(min(v) / 1e3, 1), 'max_us': round(max(v) / 1e3, 1)} for (k, g), v in sorted(groups.items())]
+            with open(os.path.join(prof, f'{args.round}_spmm_launches_by_grid.json'), 'w') as fh:
+                json.dump({'what': 'SpMM launches of the profiled bench.py run, split by grid size (= by configuration): a layer of config 4 is '
+                                   'the largest k_spmm_seg + the largest k_spmm_reduce_groups', 'launches': table}, fh, indent=1)
+            print('per-grid SpMM launches ->', f'profiles/{args.round}_spmm_launches_by_grid.json')
     if not args.pmc:
         return
     summary = {}
