@@ -5,7 +5,7 @@ values = many tied scores, wide dynamic range, rows of zeros, a non-finite row),
 and requires tgcn_score_topk_f32 and tgcn_score_topk_prefilter_f32 (pack built inside the call and handed in) to return the
 bits of tgcn_score_dense_f32 -> tgcn_mask_f32 -> tgcn_topk_f32.
 
-    python tools/fuzz_parity.py --seconds 120 [--seed0 0] [--wide]      (one JSON line per failure, a summary line at the end)"""
+    python tools/fuzz_parity.py --seconds 120 [--seed0 0] [--wide] [--huge]      (one JSON line per failure, a summary line at the end)"""
 import argparse
 import json
 import os
@@ -32,7 +32,7 @@ def near(rng, hi, lo=1):
     return int(rng.integers(lo, hi + 1))
 
 
-def draw_case(seed, wide=False):
+def draw_case(seed, wide=False, huge=False):
     rng = np.random.default_rng(seed)
     d = int(rng.choice(WIDTHS if not wide else [w for w in WIDTHS if w > 128]))
     big = rng.random() < 0.25
@@ -40,6 +40,8 @@ def draw_case(seed, wide=False):
     i = near(rng, 20000 if not big else 70000, lo=1)
     if d > 256:      # keep the dense reference small
         b, i = min(b, 700), min(i, 30000)
+    elif huge and rng.random() < 0.15:      # --huge: catalogues past 131 072 items (the filter's stage summary, the sparser bar forms)
+        b, i = near(rng, 300 if rng.random() < 0.8 else 4300), int(rng.integers(131_000, 420_000))
     k = int(min(i, rng.choice([1, 2, 5, 10, 20, 40, 64, 100, int(rng.integers(1, 129))])))
     style = rng.choice(['gauss', 'ties', 'range', 'zeros', 'nonfinite', 'tiny'])
     if style == 'gauss':
@@ -124,6 +126,7 @@ def main():
     ap.add_argument('--seed0', type=int, default=0)
     ap.add_argument('--max-cases', type=int, default=100000)
     ap.add_argument('--wide', action='store_true', help='only widths above 128 (the wide bf16 filter)')
+    ap.add_argument('--huge', action='store_true', help='one case in seven (of the narrow widths) on a catalogue of 131 000 - 420 000 items')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     t0 = time.time()
@@ -131,7 +134,7 @@ def main():
     by_style = {}
     seed = args.seed0
     while time.time() - t0 < args.seconds and n < args.max_cases:
-        desc, u, it, mask, ids = draw_case(seed, args.wide)
+        desc, u, it, mask, ids = draw_case(seed, args.wide, args.huge)
         try:
             err = run_case(dev, desc, u, it, mask, ids)
         except Exception as e:       # an exception is a finding too
