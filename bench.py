@@ -302,7 +302,7 @@ def candidate_path_roofline(b, n_items, d, k_top, t_call, dev, slot=0):
     candidates).  The call has three floors, none of which the others can hide below: the bf16 matrix pipe (2 K' B I flop, K' =
     the packed row width + the bound's k-step), the candidates' fp32 row gathers at the chip's random-row rate (pairs counted by
     tgcn_score_topk_stats on the last call of `slot`, rate measured live for a table of the item table's size), and the streams
-    every call must move once (the item pack; the narrow path's pass-bit words, written and read).  bound = the largest of the
+    every call must move once (the item pack; the narrow path's pass-bit words, written and -- below 131 072 items -- read).  bound = the largest of the
     three; frac = bound time / measured time of the call."""
     from textgcn_amd import scoring
     # a slot's workspace holds the plan of ITS last call: ask a slot whose last call had this very shape (the tail chunk of a user
@@ -321,7 +321,11 @@ def candidate_path_roofline(b, n_items, d, k_top, t_call, dev, slot=0):
     gather_bytes = st['rescored_pairs'] * 4.0 * d
     t_gather = gather_bytes / rate
     wh = ((n_items + 63) // 64 + 3) & ~3
-    stream_bytes = n_items * (32 * ks + 16) + (0 if d > 128 else 2 * ((b + 255) // 256 * 256) * 2 * wh * 4)
+    # pass-bit words: written once by the filter; read back by the chains' kernel too, unless the call keeps the stage summary
+    # (the one-store-per-stage form on 131 072 items and more: tgcn_score_fused.hip, kSummaryMinWords)
+    tiles = (b + 255) // 256
+    summarised = wh >= 2048 and (b > 4096 or n_items // max(1, min(32, 256 // tiles)) >= 16 * 256)
+    stream_bytes = n_items * (32 * ks + 16) + (0 if d > 128 else (1 if summarised else 2) * (tiles * 256) * 2 * wh * 4)
     t_stream = stream_bytes / (HBM_PEAK_GBS * 1e9)
     floors = {'mfma_bf16': t_mfma, 'candidate_row_gathers': t_gather, 'pack_and_mask_streams': t_stream}
     which = max(floors, key=floors.get)
@@ -336,14 +340,14 @@ def candidate_path_roofline(b, n_items, d, k_top, t_call, dev, slot=0):
                     'lowers the floor and frac together with call_us -- compare call_us across builds, frac within one'}
 
 
-def scoring_region(ue, ie, batches, k_top, dev, barrier, prefilter=False):
+def scoring_region(ue, ie, batches, k_top, dev, barrier, prefilter=False, streams=None):
     """Consecutive calls are independent: issued round-robin on a few HIP streams with their own scratch buffers, as
     LightGCN.predict does, so one call's small selection kernels run under the next call's GEMM.  Returns seconds.
     prefilter: tgcn_score_topk_prefilter_f32 (candidates from a bf16 pass, fp32 chains for every score: the same lists); the
     item-norm factor of its bound is computed inside the timed region, once per region as predict does per call."""
     from textgcn_amd import scoring
     main = torch.cuda.current_stream(dev)
-    N_SCORE_STREAMS = n_score_streams(prefilter)
+    N_SCORE_STREAMS = streams or n_score_streams(prefilter)
     side = [torch.cuda.Stream(dev) for _ in range(N_SCORE_STREAMS)]
 
     def score_all(bts):   # the predict step of base_model.py:254-263, fused (tgcn_score_topk_f32)
@@ -465,16 +469,19 @@ def scoring_record(ue, ie, users_all, mrp, mit, n_i, d, dev, args, barrier, worl
     # the model class scores 16384 users per call (LightGCN.predict_chunk); same kernels, fewer launches
     big = min(16384, len(users_all))
     if large and reduce_max_sum is None and big > bsz:
+        from textgcn_amd import scoring
         n_big = max(1, min(4, len(users_all) // big))
         bb = [batch_masks(users_all[b * big:(b + 1) * big], mrp, mit, dev) for b in range(n_big)]
-        tb, _ = scoring_region(ue, ie, bb, k_top, dev, barrier)
+        # calls in flight as LightGCN.predict_tensors keeps them (two for calls that run for milliseconds: config 4's catalogue)
+        inflight = (scoring.calls_in_flight(big, n_i, n_score_streams(False)), scoring.calls_in_flight(big, n_i, n_score_streams(True)))
+        tb, _ = scoring_region(ue, ie, bb, k_top, dev, barrier, streams=inflight[0])
         pb = sum(int(bt[0].numel()) for bt in bb) * n_i
-        rec['large_batch'] = {'users_per_call': big, 'value': pb / tb, 'unit': 'pairs/s', 'ms_per_call': tb / n_big * 1e3,
+        rec['large_batch'] = {'users_per_call': big, 'value': pb / tb, 'unit': 'pairs/s', 'ms_per_call': tb / n_big * 1e3, 'streams': inflight[0],
                               'mfma_frac': round(2.0 * d * pb / tb / 1e12 / MFMA_F32_PEAK_TF, 4)}
         if d <= 128:
-            tbp, _ = scoring_region(ue, ie, bb, k_top, dev, barrier, prefilter=True)
+            tbp, _ = scoring_region(ue, ie, bb, k_top, dev, barrier, prefilter=True, streams=inflight[1])
             rec['large_batch']['bf16_candidates'] = {
-                'value': pb / tbp, 'unit': 'pairs/s', 'ms_per_call': tbp / n_big * 1e3,
+                'value': pb / tbp, 'unit': 'pairs/s', 'ms_per_call': tbp / n_big * 1e3, 'streams': inflight[1],
                 'roofline': candidate_path_roofline(big, n_i, d, k_top, tbp / n_big, dev)}
     if cpu:
         # bounded CPU sample: the [users, I] matrix of the reference's matmul is 4 I bytes per user (8 MB at config 4)
@@ -543,7 +550,7 @@ def record_single_gpu(wl, dev, args, steps, warmup, cpu=True, scoring=True, trai
         step()
         ue, ie = out[:n_u].contiguous(), out[n_u:].contiguous()
         mrp, mit = graph.train_mask()      # = train_mask_csr(u, i, n_u): the generator's pairs are distinct
-        rec['scoring'] = scoring_record(ue, ie, np.arange(n_u), mrp, mit, n_i, d, dev, args, barrier, cpu=cpu, large=n_i <= 500_000)
+        rec['scoring'] = scoring_record(ue, ie, np.arange(n_u), mrp, mit, n_i, d, dev, args, barrier, cpu=cpu)
         del ue, ie
     if train:
         rec['training'] = record_train_step(dev, u, i, graph, n_u, n_i, d, K)

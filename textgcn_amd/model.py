@@ -732,6 +732,8 @@ class LightGCN(nn.Module):
         # one chunk's small selection kernels run under the next chunk's GEMM (+30-45 % measured)
         main = torch.cuda.current_stream(self.device)
         streams = self._predict_streams()
+        if not custom:      # (calls that run for milliseconds gain nothing from a third and fourth in flight: scoring.calls_in_flight)
+            streams = streams[:scoring.calls_in_flight(min(step, max(len(users), 1)), self.n_items, len(streams))]
         # candidates from the bf16 pass, scores and order from the fp32 chains: the same lists bit for bit (scoring.score_topk);
         # the item-side factor of its error bound is computed once for the whole predict call
         prefilter = bool(getattr(self, 'score_prefilter', True)) and not custom

@@ -155,6 +155,18 @@ def call_stats(dev, b, n_items, d, k, prefilter, slot=0):
     return dict(zip(('fallback_users', 'kept_pairs', 'rescored_pairs', 'logged_pairs'), [int(x) for x in out]))
 
 
+LONG_CALL_PAIRS = 1 << 33     # users x items of one call from which more than two calls in flight only queue
+
+
+def calls_in_flight(users_per_call, n_items, streams):
+    """How many consecutive score_topk calls a caller should keep in flight (on `streams` HIP streams of its own).  A short call
+    leaves the chip idle between its small launches, and a neighbour's kernels fill the gaps: four in flight measured best on
+    50 000 - 60 000 items.  A call whose filter alone runs for milliseconds (16 384 users x 2 M items: 6 ms) fills the chip by itself;
+    further calls only queue behind it and their small launches delay its own: 5.31 / 5.20 / 4.49 T pairs/s with 1 / 2 / 4 calls in
+    flight (tools/score_mode_bench.py --shapes c4 --users 16384) -- two, so that the host's work for the next call still overlaps."""
+    return min(int(streams), 2) if int(users_per_call) * int(n_items) >= LONG_CALL_PAIRS else int(streams)
+
+
 def item_pack(items_emb):
     """The item operand of the prefilter's bf16 pass (tgcn_item_pack_bf16): per row its bf16 image and the row's factors of the
     error bound, as a uint8 tensor.  Pack once per item table and hand it to score_topk(prefilter=True, item_pack=...).
