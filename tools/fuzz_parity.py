@@ -41,7 +41,7 @@ def draw_case(seed, wide=False, huge=False):
     if d > 256:      # keep the dense reference small
         b, i = min(b, 700), min(i, 30000)
     elif huge and rng.random() < 0.15:      # --huge: catalogues past 131 072 items (the filter's stage summary, the sparser bar forms)
-        b, i = near(rng, 300 if rng.random() < 0.8 else 4300), int(rng.integers(131_000, 420_000))
+        b, i = near(rng, 300 if rng.random() < 0.8 else 4300), int(rng.integers(131_000, 760_000))
     k = int(min(i, rng.choice([1, 2, 5, 10, 20, 40, 64, 100, int(rng.integers(1, 129))])))
     style = rng.choice(['gauss', 'ties', 'range', 'zeros', 'nonfinite', 'tiny'])
     if style == 'gauss':
@@ -126,7 +126,7 @@ def main():
     ap.add_argument('--seed0', type=int, default=0)
     ap.add_argument('--max-cases', type=int, default=100000)
     ap.add_argument('--wide', action='store_true', help='only widths above 128 (the wide bf16 filter)')
-    ap.add_argument('--huge', action='store_true', help='one case in seven (of the narrow widths) on a catalogue of 131 000 - 420 000 items')
+    ap.add_argument('--huge', action='store_true', help='one case in seven (of the narrow widths) on a catalogue of 131 000 - 760 000 items')
     args = ap.parse_args()
     dev = torch.device('cuda:0')
     t0 = time.time()
