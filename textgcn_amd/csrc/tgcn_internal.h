@@ -129,10 +129,10 @@ struct PassSummary {
     int sw = 0;                     // summary words per (user, row half, split) = ceil(stages per split / 32)
     int n_splits = 0, items_per_split = 0, stage_items = 0;
 };
-int prefilter_stage_items(int d);   // items per LDS stage of launch_prefilter's kernel for this width
+int prefilter_stage_items(int d, bool long_stages);   // items per LDS stage of launch_prefilter's kernel for this width (long: the ring of two)
 int launch_prefilter(const float *U, const int64_t *user_ids, int B, const void *ipack, int I, int d, const float *tau, int tau_stride,
-                     const float *ubound, unsigned *mask, int Wh, int S, int items_per_split, bool wide, const PassSummary &summ,
-                     hipStream_t stream);
+                     const float *ubound, unsigned *mask, int Wh, int S, int items_per_split, bool wide, bool long_stages,
+                     const PassSummary &summ, hipStream_t stream);
 int pack_row_bytes(int d);                 // bytes of a packed item row; its 16-byte factor chunk is the last one
 int launch_prefilter_wide(const float *U, const int64_t *user_ids, int B, const void *ipack, int I, int d, const float *tau, int tau_stride,
                           const float *ubound, void *logs, int *counts, int S, int items_per_split, int cap2, hipStream_t stream);

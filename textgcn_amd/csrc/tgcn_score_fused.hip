@@ -37,6 +37,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int kSampleStride = 32;  // items per sampled item (16 where the denser sample pays: make_plan)
 constexpr double kBarRisk = 3e-6;  // per user: the chance that the bar tau_u lands above the user's k-th best score (-> exact fallback)
 constexpr int kUsersPerWG = 128;   // 4 waves x 32 users
+constexpr size_t kLongStagePackBytes = (size_t)64 << 20;   // item packs up to this size take the filter's ring of two (launch_prefilter)
 constexpr int kSummaryMinWords = 2048;   // pass-bit words per (user, row half) from which the bf16 filter keeps its stage summary (131 072 items)
 constexpr int kStage = 64;         // items per LDS stage (2 MFMA sub-tiles of 32)
 constexpr int kSmallI = 8192;      // below this the dense path (score -> mask -> top-k) is used
@@ -1155,7 +1156,7 @@ Plan make_plan(int B, int I, int d, int k)
     // ... and, for large catalogues, their stage summary (PassSummary): at most ceil(stages / 32) + one word per split, per row half
     p.off_summ = o, p.summ_words = 0;
     if (d <= 128 && prefilter_supports(d) && p.Wh >= kSummaryMinWords) {
-        p.summ_words = (p.Wh * kStage / prefilter_stage_items(d) + 31) / 32 + 40;
+        p.summ_words = (p.Wh * kStage / prefilter_stage_items(d, false) + 31) / 32 + 40;
         o += align256((size_t)((B + 255) / 256) * 256 * 2 * p.summ_words * sizeof(unsigned));
     }
     // the wide bf16 filter (K split between two waves per SIMD) logs into 4 segments per (user, split) -- (tile, row half) of the
@@ -1429,7 +1430,14 @@ int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const fl
         const int s_target = max(1, min(32, 256 / tiles));
         const bool wide = B > 4096 || I / s_target >= 16 * 256;
         int ips_pre = p.items_per_split;
-        if (wide) {
+        // splits of at least 16 double-length stages over a pack the caches hold: the ring of two (half the stage boundaries per item;
+        // one stage of lead covers a round trip to the L2 / Infinity Cache, not to HBM -- A/B on one box, four streams: 16 384 users x
+        // 60 k x 128 537 -> 512 us, x 50 k x 64 311 -> 301; config 4's 288 MB pack 845 -> 892, so it keeps the ring of three)
+        const int st_long = prefilter_stage_items(d, true);
+        const bool long_stages = wide && (I + s_target - 1) / s_target >= 16 * st_long && item_pack_bytes(I, d) <= kLongStagePackBytes;
+        if (long_stages) {
+            ips_pre = (((I + s_target - 1) / s_target + st_long - 1) / st_long) * st_long;
+        } else if (wide) {
             ips_pre = (((I + s_target - 1) / s_target + 255) / 256) * 256;
         } else if (d > 64 && I <= (1 << 18)) {
             ips_pre = 1024;      // (768 / 1280 / 2048 with the packed operand: 54 / 53 / 56 us against 46)
@@ -1439,14 +1447,14 @@ int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const fl
         PassSummary summ;
         const int n_splits_pre = (I + ips_pre - 1) / ips_pre;
         if (wide && p.summ_words > 0) {
-            summ.stage_items = prefilter_stage_items(d);
+            summ.stage_items = prefilter_stage_items(d, long_stages);
             summ.items_per_split = ips_pre, summ.n_splits = n_splits_pre;
             summ.sw = (ips_pre / summ.stage_items + 31) / 32;
             if (summ.n_splits * summ.sw <= p.summ_words)        // (always: make_plan's bound is stages / 32 + one word per split)
                 summ.words = reinterpret_cast<unsigned *>(ws + p.off_summ);
         }
-        if ((rc = launch_prefilter(U, user_ids, B, ipack, I, d, tau_ptr, tau_stride, ubound, mask, p.Wh, n_splits_pre, ips_pre, wide, summ,
-                                   s)) != TGCN_OK)
+        if ((rc = launch_prefilter(U, user_ids, B, ipack, I, d, tau_ptr, tau_stride, ubound, mask, p.Wh, n_splits_pre, ips_pre, wide, long_stages,
+                                   summ, s)) != TGCN_OK)
             return rc;
         if (B <= kFuseSelectMaxUsers) {
             // small calls: the fp32 chains and the exact selection in ONE launch, the kept pairs never leave the wave's LDS (round 4)

@@ -304,9 +304,15 @@ struct PreArgs {
 // A stage's rows are requested one whole stage ahead, as the contiguous bytes of the item pack; d <= 64 walks 256-item stages.
 // (Stages converted from the fp32 table inside the loop: 33 / 180 us at 2048 / 16 384 users, d = 64; from the pack 28 / 145;
 // d = 128: 57 / 343 -> 45 / 300.)
-template <int KS, bool FULLK, int ST, int WAVES, bool WIDE>
+// RING = 3: a stage is requested two stages ahead (the form every call size can afford).  RING = 2 with stages TWICE as long (512
+// items at d <= 64, 256 at d <= 128; 144 KB of LDS), requested one stage ahead -- a stage then lasts ~3 us, more than a round trip:
+// for calls with many stages per workgroup.  Cycle stamps (profiles/r04_experiments.md section 12): of a 256-item stage's 4519
+// cycles per wave 1288 are its boundary -- the barrier 662, the burst of requests all eight waves issue behind it 516, the counted
+// wait 110 -- during which the SIMD multiplies nothing; twice the items per boundary.
+template <int KS, bool FULLK, int ST, int WAVES, bool WIDE, int RING = 3>
 __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
 {
+    static_assert(RING == 3 || (RING == 2 && WIDE), "ring of two: the one-store-per-stage form");
     constexpr int T = WAVES * 64;              // threads; WAVES x 32 users per workgroup share every item stage
     constexpr int UT = WAVES * 32;
     constexpr int DQ = 4 * KS;                 // float4 pieces per source row
@@ -316,7 +322,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
     constexpr int NU = (kStage * DQ) / T;      // ... per 64-user piece of the user tile
     static_assert(ST % kStage == 0 && 2 * ST >= UT && (kStage * DQ) % T == 0, "the user tile passes through the stage buffers");
     static_assert(SB >= ST * RB && 2 * SB >= UT * RB, "stage buffers (the user tile passes through both)");
-    __shared__ __attribute__((aligned(16))) unsigned char smem[3 * SB];      // a ring of three stages: one multiplied, two on their way
+    static_assert(RING * SB <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[RING * SB];      // the ring: one stage multiplied, RING - 1 on their way
     const int lane = lane_id();
     const int w = threadIdx.x >> 6;
     const int r32 = lane & 31;
@@ -381,7 +388,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
     // stage and every wave has passed that stage's barrier.  Issued at the stage's start, waited for at its end (vmcnt(0) + barrier).
     // With the rows staged through registers the stage traffic cost a quarter of the launch (tools/wide_ablate.py pre_nostage: 155 ->
     // 116 us at 16 384 users).
-    constexpr int kLead = 2;      // stages between a request and the stage that multiplies it (the ring has kLead + 1 buffers)
+    constexpr int kLead = RING - 1;      // stages between a request and the stage that multiplies it (the ring has kLead + 1 buffers)
     using RingWait = DmaRingWait<NP, kLead>;
     auto dma_stage = [&](int nb, int row0) {
         const size_t base = (size_t)row0 * RB;
@@ -443,7 +450,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
     if (i_beg >= i_end)
         return;
     store_stage(smem, nxt);
-    dma_stage(1, i_beg + ST);      // (the user tile is out of the buffers: its fragments are in registers)
+    if constexpr (kLead == 2)
+        dma_stage(1, i_beg + ST);      // (the user tile is out of the buffers: its fragments are in registers)
     __syncthreads();
     // tau has arrived before the loop: a first use inside it makes hipcc's wait-count pass put s_waitcnt vmcnt(0) in front of
     // EVERY test (the loop-carried state merges the pending tau load with the stage prefetch), which serialises the prefetch
@@ -578,7 +586,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
     // previous stage's words to store -- is its own instance of the body.
     auto stage = [&](auto first_tag, int s0) {
         constexpr bool FIRST = decltype(first_tag)::value;
-        dma_stage(buf >= 1 ? buf - 1 : 2, s0 + kLead * ST);     // ring position (buf + 2) % 3: multiplied last in the previous stage
+        dma_stage(buf + kLead >= RING ? buf + kLead - RING : buf + kLead, s0 + kLead * ST);     // ring position (buf + kLead) % RING: multiplied last in the previous stage
 #pragma unroll
         for (int un = 0; un < UPS; un += 2) {
             const int t0 = s0 + un * kStage;     // first item of this 64-item unit
@@ -608,10 +616,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
             RingWait::wait();
 #ifdef TGCN_CHECK_DMA
         if (s0 + ST < i_end)
-            verify_stage(buf == 2 ? 0 : buf + 1, s0 + ST);
+            verify_stage(buf == RING - 1 ? 0 : buf + 1, s0 + ST);
 #endif
         __syncthreads();
-        buf = buf == 2 ? 0 : buf + 1;
+        buf = buf == RING - 1 ? 0 : buf + 1;
     };
     stage(Yes{}, i_beg);
     for (int s0 = i_beg + ST; s0 < i_end; s0 += ST)
@@ -1471,22 +1479,22 @@ __global__ __launch_bounds__(RescoreShape<SELECT>::kWaves * 64) void k_rescore(c
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_wave_barrier();
             // (1b) their words -> item ids
-            const int ups = a.summ.stage_items / kStage;       // words per stage (4 at d <= 64, 2 at d <= 128)
+            const int ups = a.summ.stage_items / kStage;       // words per stage (4 or 8 at d <= 64, 2 or 4 at d <= 128)
             for (int c0 = 0; c0 < ns; c0 += kWave) {
-                unsigned word[4] = {0u, 0u, 0u, 0u};
+                unsigned word[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
                 int hh = 0, u0w = 0;
                 if (c0 + lane < ns) {
                     const int code = stg[c0 + lane];
                     hh = code & 1;
                     u0w = (code >> 1) * ups;                   // first 64-item unit (= word inside the row half) of the stage
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < 8; ++i)
                         if (i < ups && u0w + i < a.n_units)    // (the catalogue's last stage may be partial: its other words were never written)
                             word[i] = mrow[hh * a.Wh + u0w + i];
                 }
                 int mine = 0;
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 8; ++i)
                     mine += __popc(word[i]);
                 int incl = mine;
 #pragma unroll
@@ -1502,7 +1510,7 @@ __global__ __launch_bounds__(RescoreShape<SELECT>::kWaves * 64) void k_rescore(c
                 }
                 int off = n + incl - mine;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < 8; ++i) {
                     unsigned wd = word[i];
                     const int base = (u0w + i) * 64 + 4 * hh;
                     while (wd) {
@@ -1822,26 +1830,30 @@ int launch_item_pack(const float *It, int I, int d, void *pack, hipStream_t s)
     return check_launch("k_item_pack");
 }
 
-int prefilter_stage_items(int d) { return d <= 64 ? 256 : 128; }      // the ST of launch_prefilter's instantiations
+int prefilter_stage_items(int d, bool long_stages) { return (d <= 64 ? 256 : 128) * (long_stages ? 2 : 1); }      // the ST of launch_prefilter's instantiations
 
 int launch_prefilter(const float *U, const int64_t *user_ids, int B, const void *ipack, int I, int d, const float *tau, int tau_stride,
-                     const float *ubound, unsigned *mask, int Wh, int S, int items_per_split, bool wide, const PassSummary &summ, hipStream_t s)
+                     const float *ubound, unsigned *mask, int Wh, int S, int items_per_split, bool wide, bool long_stages,
+                     const PassSummary &summ, hipStream_t s)
 {
     constexpr int UT = kPreWaves * 32;
     const int n_tiles = (B + UT - 1) / UT;
     wide = wide && items_per_split % 256 == 0;         // (a stage's words as one aligned store: the splits must be stage multiples)
-    if (summ.words && (!wide || summ.n_splits != S || summ.items_per_split != items_per_split || summ.stage_items != prefilter_stage_items(d) ||
-                       summ.sw != (items_per_split / summ.stage_items + 31) / 32))
+    long_stages = long_stages && wide && items_per_split % prefilter_stage_items(d, true) == 0;
+    if (summ.words && (!wide || summ.n_splits != S || summ.items_per_split != items_per_split ||
+                       summ.stage_items != prefilter_stage_items(d, long_stages) || summ.sw != (items_per_split / summ.stage_items + 31) / 32))
         return fail_arg("launch_prefilter: the stage summary does not describe this launch");
     PreArgs a{U, user_ids, static_cast<const unsigned char *>(ipack), item_pack_bytes(I, d), tau, tau_stride, ubound, mask, Wh, B, I, d,
               items_per_split, n_tiles, S, summ.words, summ.sw};
     const dim3 grid(8u * (unsigned)((n_tiles * S + 7) / 8)), block(kPreWaves * 64);
-#define TGCN_PRE_LAUNCH(KS, FULLK, ST)                                                                          \
-    do {                                                                                                        \
-        if (wide)                                                                                               \
-            hipLaunchKernelGGL((k_score_prefilter<KS, FULLK, ST, kPreWaves, true>), grid, block, 0, s, a);      \
-        else                                                                                                    \
-            hipLaunchKernelGGL((k_score_prefilter<KS, FULLK, ST, kPreWaves, false>), grid, block, 0, s, a);     \
+#define TGCN_PRE_LAUNCH(KS, FULLK, ST)                                                                                  \
+    do {                                                                                                                \
+        if (long_stages)                                                                                                \
+            hipLaunchKernelGGL((k_score_prefilter<KS, FULLK, 2 * ST, kPreWaves, true, 2>), grid, block, 0, s, a);       \
+        else if (wide)                                                                                                  \
+            hipLaunchKernelGGL((k_score_prefilter<KS, FULLK, ST, kPreWaves, true>), grid, block, 0, s, a);              \
+        else                                                                                                            \
+            hipLaunchKernelGGL((k_score_prefilter<KS, FULLK, ST, kPreWaves, false>), grid, block, 0, s, a);             \
     } while (0)
     if (d == 64)
         TGCN_PRE_LAUNCH(4, true, 256);
