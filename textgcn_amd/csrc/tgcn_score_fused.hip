@@ -1424,7 +1424,7 @@ int score_topk_impl(const float *U, const int64_t *user_ids, int32_t B, const fl
         // as few item splits as fill the chip ONCE (a 512-thread workgroup per CU: 256 workgroups).  A workgroup's prologue -- its
         // 256 users' rows by two dependent round trips, their bf16 image through LDS into fragments -- hides under nothing, and
         // with 28 splits a 16 384-user launch paid it in seven generations of workgroups: with the MFMAs alone left in the loop
-        // (tools/wide_ablate.py pre_onlymfma) the launch still took 109 us for 53 us of matrix work.  The one-store-per-stage form
+        // (round 3's ablation build pre_onlymfma) the launch still took 109 us for 53 us of matrix work.  The one-store-per-stage form
         // needs splits of whole stages: for large calls, and wherever a split is long enough that the rounding costs nothing.
         const int tiles = (B + 255) / 256;
         const int s_target = max(1, min(32, 256 / tiles));

@@ -386,7 +386,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_score_prefilter(const PreArgs a)
     // inside the loop the next stage goes from the pack straight into the other LDS buffer (LDS-DMA, 16 bytes per lane, a wave
     // instruction = 1 KB contiguous): no staging registers, no ds_write, and the buffer is free -- it was multiplied in the previous
     // stage and every wave has passed that stage's barrier.  Issued at the stage's start, waited for at its end (vmcnt(0) + barrier).
-    // With the rows staged through registers the stage traffic cost a quarter of the launch (tools/wide_ablate.py pre_nostage: 155 ->
+    // With the rows staged through registers the stage traffic cost a quarter of the launch (round 3's ablation build pre_nostage: 155 ->
     // 116 us at 16 384 users).
     constexpr int kLead = RING - 1;      // stages between a request and the stage that multiplies it (the ring has kLead + 1 buffers)
     using RingWait = DmaRingWait<NP, kLead>;
