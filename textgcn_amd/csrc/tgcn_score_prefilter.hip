@@ -1895,7 +1895,15 @@ int launch_sample_wide(const float *U, const int64_t *user_ids, int B, const voi
                        int64_t ld, hipStream_t s)
 {
     const int tiles = (B + 127) / 128, units = (m + kStage - 1) / kStage;
-    const int splits = max(1, min(units, 512 / tiles));
+    // as the filter's plan (tgcn_score_fused.hip make_plan): generations of 256 workgroups x (prologue of ~9 units + the split's units);
+    // 8192 users: 64 tiles x 4 splits in one generation instead of 8 splits in two, each paying the prologue
+    int splits = 1;
+    long best = -1;
+    for (int c = 1; c <= min(units, 16); ++c) {
+        const long cost = (((long)tiles * c + 255) / 256) * (9 + (units + c - 1) / c);
+        if (best < 0 || cost < best)
+            best = cost, splits = c;
+    }
     const int ips = ((units + splits - 1) / splits) * kStage;
     PreWideArgs a{PreArgs{U, user_ids, static_cast<const unsigned char *>(ipack), item_pack_bytes(I, d), nullptr, 0, nullptr, nullptr, 0, B,
                           m, d, ips},
